@@ -1,0 +1,193 @@
+/*
+ * fmd.h -- C ABI of the MI355X-native FM broadcast decoder (libfmd_hip.so).
+ *
+ * Drop-in boundary for ONE path of AlwinEsch/pvr.rtl.radiofm: cFmDecoder::ProcessStream()
+ * and the upward RDS callbacks.  The reference has no C ABI for this path (cFmDecoder is a
+ * hidden C++ class, src/FmDecode.h:91); the entry points below are what a binding of that
+ * class would need, one per reference member, plus batched variants (many independent
+ * channels per call) which are what the GPU is for.  include/fm_decoder.hpp puts the
+ * reference's exact class surface on top of this ABI.
+ *
+ * All citations are relative to /root/reference/src/.  Plain pointers and sizes only; no
+ * torch / HIP types (streams are passed as void* = hipStream_t).  Every function returns
+ * FMD_OK or a negative error; fmd_last_error() gives the text.  There is no CPU fallback:
+ * if no HIP device is usable the create calls fail.
+ */
+#ifndef FMD_H
+#define FMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMD_OK 0
+#define FMD_ERR_ARG (-1)     /* invalid argument / unsupported configuration */
+#define FMD_ERR_DEVICE (-2)  /* HIP runtime error or no usable device */
+#define FMD_ERR_SIZE (-3)    /* samples outside [FMD_MIN_BLOCK, FMD_MAX_BLOCK] */
+#define FMD_ERR_STATE (-4)
+
+/* cRtlSdrSource::default_block_length (RTL_SDR_Source.h:25): the reference's internal buffers
+ * are hard-sized to it (FmDecode.cpp:277-282), so samples <= 65536 is its precondition too. */
+#define FMD_MAX_BLOCK 65536u
+/* Below this the reference's half-band stages stop filtering (DownConvert.cpp:519-520) and
+ * its level meters divide by zero; the GPU path rejects such calls instead of imitating it. */
+#define FMD_MIN_BLOCK 8192u
+
+/* Constructor arguments of cFmDecoder (FmDecode.h:110-116).  table_size / if_filter_order are
+ * the two internal constants BASELINE configs 3 and 5 override; 0 selects the reference
+ * values 64 (FmDecode.cpp:249) and 8*downsample (FmDecode.cpp:262). */
+typedef struct fmd_params
+{
+  double sample_rate_if;
+  double tuning_offset;
+  double sample_rate_pcm;
+  double bandwidth_pcm;
+  unsigned downsample;
+  int us_version;
+  unsigned table_size;
+  unsigned if_filter_order;
+} fmd_params;
+
+/* Upward callbacks = the three cRadioReceiver members the RDS group decoder calls
+ * (RadioReceiver.h:77,80,115; called from RDSGroupDecoder.cpp:403,405,981,990).  Invoked on
+ * the calling thread from inside fmd_process_stream / fmd_batch_process_host.  A NULL entry
+ * behaves like the reference with no dialog open (frames accepted, name accepted, inactive).
+ * frame = ADD(2) SQC MFL payload CRC16(2), unstuffed, valid only during the call. */
+typedef struct fmd_callbacks
+{
+  int (*add_uecp_frame)(void* user, unsigned channel, const uint8_t* frame, unsigned len);
+  int (*set_channel_name)(void* user, unsigned channel, const char name[9]);
+  int (*is_setting_active)(void* user, unsigned channel);
+} fmd_callbacks;
+
+/* Getters of cFmDecoder (FmDecode.h:140-165) */
+typedef struct fmd_status
+{
+  int stereo_detected;   /* StereoDetected()    */
+  float tuning_offset;   /* GetTuningOffset()   */
+  float interface_level; /* GetInterfaceLevel() */
+  float baseband_level;  /* GetBasebandLevel()  */
+  float pilot_level;     /* GetPilotLevel()     */
+  int rds_state;         /* 0 bit sync, 1 block sync, 2 group decode, 3 group resync */
+} fmd_status;
+
+/* One RDS group = the uint16_t[4] the signal processor hands to the group decoder
+ * (RDSProcess.cpp:312,355): the bit-exact parity checkpoint. */
+typedef struct fmd_rds_group
+{
+  uint32_t channel;
+  uint32_t call_index; /* 1-based index of the process call that completed the group */
+  uint16_t blocks[4];
+} fmd_rds_group;
+
+/* ---- single decoder: the cFmDecoder surface --------------------------------------- */
+typedef struct fmd_decoder fmd_decoder;
+
+/* cFmDecoder::cFmDecoder (FmDecode.cpp:237-314) */
+int fmd_create(const fmd_params* params, const fmd_callbacks* cb, void* user, fmd_decoder** out);
+/* cFmDecoder::~cFmDecoder (FmDecode.cpp:316-324) */
+void fmd_destroy(fmd_decoder* d);
+/* cFmDecoder::Reset (FmDecode.cpp:326-338) */
+int fmd_reset(fmd_decoder* d);
+/* cFmDecoder::ProcessStream (FmDecode.cpp:417-502): iq = samples complex<float> (host),
+ * audio = caller buffer of samples*2 floats (RadioReceiver.cpp:519-520); returns the number
+ * of floats written (2 per audio frame) or a negative error. */
+int fmd_process_stream(fmd_decoder* d, const float* iq, unsigned samples, float* audio);
+int fmd_get_status(fmd_decoder* d, fmd_status* st);
+
+/* ---- batch of independent channels on one GPU -------------------------------------- */
+typedef struct fmd_batch fmd_batch;
+
+/* All channels share params (same geometry); tuning_shifts (optional, n_channels entries)
+ * overrides the cFineTuner shift per channel (config 3: many stations from one capture),
+ * NULL derives it from params->tuning_offset like FmDecode.cpp:250.  device = HIP ordinal. */
+int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* tuning_shifts,
+                     int device, const fmd_callbacks* cb, void* user, fmd_batch** out);
+void fmd_batch_destroy(fmd_batch* b);
+int fmd_batch_reset(fmd_batch* b);
+
+/* upper bounds for sizing caller buffers */
+unsigned fmd_batch_channels(const fmd_batch* b);
+unsigned fmd_batch_max_audio_floats(const fmd_batch* b, unsigned samples);
+
+/* Device-resident call, asynchronous on `stream` (hipStream_t, NULL = default stream).
+ *  d_iq            complex<float> IQ in HBM; channel c starts at d_iq + 2*c*iq_channel_stride
+ *                  floats; iq_channel_stride == 0 means one shared capture for all channels.
+ *  d_audio         channel c's interleaved L/R floats at d_audio + c*audio_channel_stride.
+ *  out_floats      (host, optional) floats written per channel -- the same for every
+ *                  channel of a batch, known when the call returns.
+ * RDS groups produced by the call stay queued on the device until fmd_batch_collect_rds. */
+int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_stride,
+                             unsigned samples, float* d_audio, size_t audio_channel_stride,
+                             unsigned* out_floats, void* stream);
+
+/* Host-buffer call: copies in, runs fmd_batch_process_device, copies audio out, collects RDS
+ * groups and runs the UECP group decoder (callbacks fire here).  Synchronous. */
+int fmd_batch_process_host(fmd_batch* b, const float* iq, size_t iq_channel_stride,
+                           unsigned samples, float* audio, size_t audio_channel_stride,
+                           unsigned* out_floats);
+
+/* Copies the queued RDS groups (all channels, call order) to `out`, waits for `stream`.
+ * Returns the number of groups (<= cap) or a negative error.  When run_group_decoder != 0
+ * each group is also fed to that channel's UECP group decoder (callbacks fire). */
+int fmd_batch_collect_rds(fmd_batch* b, fmd_rds_group* out, unsigned cap, int run_group_decoder,
+                          void* stream);
+
+int fmd_batch_get_status(fmd_batch* b, unsigned channel, fmd_status* st);
+
+/* Stage taps for parity tests: copies stage output of the last call for one channel to host.
+ * Returns element count (complex counts as one) or negative error. */
+enum fmd_tap
+{
+  FMD_TAP_DEMOD = 0,    /* complex: IF FIR output            */
+  FMD_TAP_BASEBAND = 1, /* FM PLL output                     */
+  FMD_TAP_PILOT38 = 2,  /* 38 kHz * 2 * baseband             */
+  FMD_TAP_MONO_RS = 3,  /* mono resampler output             */
+  FMD_TAP_STEREO_RS = 4,/* stereo resampler output           */
+  FMD_TAP_RDS_LPF = 5,  /* complex: RDS 75-tap LPF output    */
+  FMD_TAP_RDS_PLL = 6,
+  FMD_TAP_RDS_MF = 7,
+  FMD_TAP_RDS_SYNC = 8
+};
+int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsigned cap_floats);
+
+/* Design constants / taps as the host computed them (for parity with the oracle). */
+int fmd_batch_get_design(fmd_batch* b, int what, float* out, unsigned cap);
+enum fmd_design_item
+{
+  FMD_DESIGN_IF_TAPS = 0,
+  FMD_DESIGN_RS_TAPS = 1,
+  FMD_DESIGN_AUDIO_LPF = 2,
+  FMD_DESIGN_RDS_LPF = 3,
+  FMD_DESIGN_RDS_MF = 4,
+  FMD_DESIGN_SCALARS = 5, /* same order as oracle fmo_get_constants */
+  FMD_DESIGN_LUT0 = 6     /* channel 0 cFineTuner table, interleaved */
+};
+
+/* Device time (ms) the kernels of the last fmd_batch_process_device call took, per stage,
+ * measured with HIP events on the call's stream when profiling is enabled. */
+int fmd_batch_set_profiling(fmd_batch* b, int enable);
+int fmd_batch_get_stage_ms(fmd_batch* b, float* out, unsigned cap);
+const char* fmd_stage_name(unsigned idx);
+
+const char* fmd_last_error(void);
+const char* fmd_version(void);
+
+/* ---- host-only pieces (no GPU needed) ----------------------------------------------- */
+/* UECP group decoder = cRDSGroupDecoder (RDSGroupDecoder.cpp:166-1001). */
+typedef struct fmd_group_decoder fmd_group_decoder;
+fmd_group_decoder* fmd_group_decoder_create(const fmd_callbacks* cb, void* user, unsigned channel);
+void fmd_group_decoder_destroy(fmd_group_decoder* g);
+void fmd_group_decoder_reset(fmd_group_decoder* g);
+void fmd_group_decoder_push(fmd_group_decoder* g, const uint16_t blocks[4]);
+/* cRadioReceiver::AddUECPDataFrame byte stuffing (RadioReceiver.cpp:387-414):
+ * 0xFE, payload with 0xFD escapes, 0xFF.  Returns bytes written (<= cap) or -1. */
+int fmd_uecp_stuff_frame(const uint8_t* frame, unsigned len, uint8_t* out, unsigned cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

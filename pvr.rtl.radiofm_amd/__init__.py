@@ -1,0 +1,348 @@
+"""pvr.rtl.radiofm_amd -- MI355X-native FM broadcast decoder (hot path of pvr.rtl.radiofm).
+
+The product is the C-ABI shared library ``libfmd_hip.so`` (include/fmd.h) built from csrc/.
+This module is only the ctypes plumbing the tests and bench.py use to reach it; the directory
+name contains dots, so load it through ``__graft_entry__.load_package()`` (importlib).
+
+There is no CPU fallback here: if the HIP library is missing or no GPU is usable, the calls
+raise.  Nothing in this package imports or links oracle/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfmd_hip.so")
+_LIB = None
+
+FMD_MAX_BLOCK = 65536
+FMD_MIN_BLOCK = 8192
+
+TAPS = {"demod": 0, "baseband": 1, "pilot38": 2, "mono_rs": 3, "stereo_rs": 4, "rds_lpf": 5,
+        "rds_pll": 6, "rds_mf": 7, "rds_sync": 8}
+DESIGN = {"if_taps": 0, "rs_taps": 1, "audio_lpf": 2, "rds_lpf": 3, "rds_mf": 4, "scalars": 5,
+          "lut0": 6}
+SCALAR_NAMES = [
+    "tuning_shift", "demod_gain", "de_alpha", "pll_alpha", "pll_beta", "nco_hl", "nco_ll",
+    "pilot_minfreq", "pilot_maxfreq", "pilot_b0", "pilot_a1", "pilot_a2", "pilot_lf_b0",
+    "pilot_lf_b1", "pilot_freq", "pilot_lock_delay", "resamp_order", "resamp_step",
+    "rds_rate", "rds_nco_inc", "rds_osc_cos", "rds_osc_sin", "rds_pll_alpha", "rds_pll_beta",
+    "rds_nco_hl", "rds_nco_ll", "fs_bb", "rds_mf_len",
+    "notch_b0", "notch_b1", "notch_b2", "notch_a1", "notch_a2",
+    "bitsync_b0", "bitsync_b1", "bitsync_b2", "bitsync_a1", "bitsync_a2",
+]
+
+
+class FmdParams(C.Structure):
+    _fields_ = [
+        ("sample_rate_if", C.c_double),
+        ("tuning_offset", C.c_double),
+        ("sample_rate_pcm", C.c_double),
+        ("bandwidth_pcm", C.c_double),
+        ("downsample", C.c_uint),
+        ("us_version", C.c_int),
+        ("table_size", C.c_uint),
+        ("if_filter_order", C.c_uint),
+    ]
+
+
+UECP_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint, C.POINTER(C.c_uint8), C.c_uint)
+NAME_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint, C.c_char_p)
+ACTIVE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint)
+
+
+class FmdCallbacks(C.Structure):
+    _fields_ = [("add_uecp_frame", UECP_CB), ("set_channel_name", NAME_CB),
+                ("is_setting_active", ACTIVE_CB)]
+
+
+class FmdStatus(C.Structure):
+    _fields_ = [
+        ("stereo_detected", C.c_int),
+        ("tuning_offset", C.c_float),
+        ("interface_level", C.c_float),
+        ("baseband_level", C.c_float),
+        ("pilot_level", C.c_float),
+        ("rds_state", C.c_int),
+    ]
+
+
+class FmdRdsGroup(C.Structure):
+    _fields_ = [("channel", C.c_uint32), ("call_index", C.c_uint32), ("blocks", C.c_uint16 * 4)]
+
+
+EXPORTS = [
+    "fmd_create", "fmd_destroy", "fmd_reset", "fmd_process_stream", "fmd_get_status",
+    "fmd_batch_create", "fmd_batch_destroy", "fmd_batch_reset", "fmd_batch_channels",
+    "fmd_batch_max_audio_floats", "fmd_batch_process_device", "fmd_batch_process_host",
+    "fmd_batch_collect_rds", "fmd_batch_get_status", "fmd_batch_get_tap", "fmd_batch_get_design",
+    "fmd_batch_set_profiling", "fmd_batch_get_stage_ms", "fmd_stage_name", "fmd_last_error",
+    "fmd_version", "fmd_group_decoder_create", "fmd_group_decoder_destroy",
+    "fmd_group_decoder_reset", "fmd_group_decoder_push", "fmd_uecp_stuff_frame",
+]
+
+
+def build():
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libfmd_hip.so is not built (run __graft_entry__.build()); "
+                               "this package has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, u, i = C.c_void_p, C.c_uint, C.c_int
+        L.fmd_last_error.restype = C.c_char_p
+        L.fmd_version.restype = C.c_char_p
+        L.fmd_stage_name.restype = C.c_char_p
+        L.fmd_stage_name.argtypes = [u]
+        L.fmd_create.argtypes = [C.POINTER(FmdParams), C.POINTER(FmdCallbacks), vp, C.POINTER(vp)]
+        L.fmd_destroy.argtypes = [vp]
+        L.fmd_reset.argtypes = [vp]
+        L.fmd_process_stream.argtypes = [vp, vp, u, vp]
+        L.fmd_get_status.argtypes = [vp, C.POINTER(FmdStatus)]
+        L.fmd_batch_create.argtypes = [C.POINTER(FmdParams), u, vp, i, C.POINTER(FmdCallbacks), vp,
+                                       C.POINTER(vp)]
+        L.fmd_batch_destroy.argtypes = [vp]
+        L.fmd_batch_reset.argtypes = [vp]
+        L.fmd_batch_channels.restype = u
+        L.fmd_batch_channels.argtypes = [vp]
+        L.fmd_batch_max_audio_floats.restype = u
+        L.fmd_batch_max_audio_floats.argtypes = [vp, u]
+        L.fmd_batch_process_device.argtypes = [vp, vp, C.c_size_t, u, vp, C.c_size_t,
+                                               C.POINTER(u), vp]
+        L.fmd_batch_process_host.argtypes = [vp, vp, C.c_size_t, u, vp, C.c_size_t, C.POINTER(u)]
+        L.fmd_batch_collect_rds.argtypes = [vp, vp, u, i, vp]
+        L.fmd_batch_get_status.argtypes = [vp, u, C.POINTER(FmdStatus)]
+        L.fmd_batch_get_tap.argtypes = [vp, i, u, vp, u]
+        L.fmd_batch_get_design.argtypes = [vp, i, vp, u]
+        L.fmd_batch_set_profiling.argtypes = [vp, i]
+        L.fmd_batch_get_stage_ms.argtypes = [vp, vp, u]
+        L.fmd_group_decoder_create.restype = vp
+        L.fmd_group_decoder_create.argtypes = [C.POINTER(FmdCallbacks), vp, u]
+        L.fmd_group_decoder_destroy.argtypes = [vp]
+        L.fmd_group_decoder_reset.argtypes = [vp]
+        L.fmd_group_decoder_push.argtypes = [vp, vp]
+        L.fmd_uecp_stuff_frame.argtypes = [vp, u, vp, u]
+        _LIB = L
+    return _LIB
+
+
+class FmdError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc < 0:
+        raise FmdError("fmd error %d: %s" % (rc, lib().fmd_last_error().decode()))
+    return rc
+
+
+def make_params(sample_rate_if, tuning_offset, sample_rate_pcm=48000.0, bandwidth_pcm=15000.0,
+                downsample=1, us_version=False, table_size=0, if_filter_order=0):
+    return FmdParams(sample_rate_if, tuning_offset, sample_rate_pcm, bandwidth_pcm, downsample,
+                     int(us_version), table_size, if_filter_order)
+
+
+class _CallbackSink:
+    """Python stand-in for the three cRadioReceiver callbacks; records what arrives."""
+
+    def __init__(self):
+        self.frames = {}
+        self.names = {}
+        self.setting_active = False
+
+        def on_frame(_user, ch, data, n):
+            self.frames.setdefault(ch, []).append(bytes(data[:n]))
+            return 1
+
+        def on_name(_user, ch, name):
+            self.names[ch] = name[:8].decode("latin1")
+            return 1
+
+        def on_active(_user, ch):
+            return 1 if self.setting_active else 0
+
+        self.struct = FmdCallbacks(UECP_CB(on_frame), NAME_CB(on_name), ACTIVE_CB(on_active))
+
+
+class Batch:
+    """C channels of the FM decoder on one GPU (fmd_batch_*)."""
+
+    def __init__(self, params, n_channels, tuning_shifts=None, device=0, record_callbacks=True):
+        self.sink = _CallbackSink() if record_callbacks else None
+        h = C.c_void_p()
+        shifts = None
+        if tuning_shifts is not None:
+            shifts = np.ascontiguousarray(tuning_shifts, dtype=np.int32)
+            assert shifts.size == n_channels
+        _check(lib().fmd_batch_create(
+            C.byref(params), n_channels, shifts.ctypes.data if shifts is not None else None, device,
+            C.byref(self.sink.struct) if self.sink else None, None, C.byref(h)))
+        self._h = h
+        self.n_channels = n_channels
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().fmd_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def reset(self):
+        _check(lib().fmd_batch_reset(self._h))
+
+    def max_audio_floats(self, samples):
+        return lib().fmd_batch_max_audio_floats(self._h, samples)
+
+    def process_host(self, iq, shared=False):
+        """iq: [C, N] complex64 (or [N] when shared).  Returns [C, n_floats] float32 audio."""
+        iq = np.ascontiguousarray(iq)
+        if iq.dtype != np.complex64:
+            iq = iq.astype(np.float32).view(np.complex64)
+        if shared:
+            n = iq.size
+            stride = 0
+        else:
+            iq = iq.reshape(self.n_channels, -1)
+            n = iq.shape[1]
+            stride = n
+        a_stride = self.max_audio_floats(n)
+        audio = np.zeros((self.n_channels, a_stride), dtype=np.float32)
+        nf = C.c_uint()
+        _check(lib().fmd_batch_process_host(self._h, iq.ctypes.data, stride, n, audio.ctypes.data,
+                                            a_stride, C.byref(nf)))
+        return audio[:, :nf.value]
+
+    def process_device(self, d_iq_ptr, iq_stride, samples, d_audio_ptr, audio_stride, stream=None):
+        nf = C.c_uint()
+        _check(lib().fmd_batch_process_device(self._h, d_iq_ptr, iq_stride, samples, d_audio_ptr,
+                                              audio_stride, C.byref(nf), stream))
+        return nf.value
+
+    def collect_rds(self, cap=65536, run_group_decoder=False, stream=None):
+        buf = (FmdRdsGroup * cap)()
+        n = _check(lib().fmd_batch_collect_rds(self._h, buf, cap, int(run_group_decoder), stream))
+        return [(g.channel, g.call_index, tuple(int(x) for x in g.blocks)) for g in buf[:n]]
+
+    def status(self, channel=0):
+        st = FmdStatus()
+        _check(lib().fmd_batch_get_status(self._h, channel, C.byref(st)))
+        return st
+
+    def tap(self, name, channel=0):
+        cap = 2 * 65536
+        buf = np.zeros(cap, dtype=np.float32)
+        n = _check(lib().fmd_batch_get_tap(self._h, TAPS[name], channel, buf.ctypes.data, cap))
+        if name in ("demod", "rds_lpf"):
+            return buf[:2 * n].view(np.complex64).copy()
+        return buf[:n].copy()
+
+    def design(self, name):
+        buf = np.zeros(16384, dtype=np.float32)
+        n = _check(lib().fmd_batch_get_design(self._h, DESIGN[name], buf.ctypes.data, buf.size))
+        return buf[:n].copy()
+
+    def scalars(self):
+        return dict(zip(SCALAR_NAMES, self.design("scalars")))
+
+    def set_profiling(self, on=True):
+        _check(lib().fmd_batch_set_profiling(self._h, int(on)))
+
+    def stage_ms(self):
+        buf = np.zeros(32, dtype=np.float32)
+        n = _check(lib().fmd_batch_get_stage_ms(self._h, buf.ctypes.data, buf.size))
+        return {lib().fmd_stage_name(i).decode(): float(buf[i]) for i in range(n)}
+
+
+class FmDecoder:
+    """The reference's cFmDecoder surface (FmDecode.h:110-165) on the GPU library."""
+
+    def __init__(self, sample_rate_if, tuning_offset, sample_rate_pcm, bandwidth_pcm=15000.0,
+                 downsample=1, USver=False):
+        self.sink = _CallbackSink()
+        p = make_params(sample_rate_if, tuning_offset, sample_rate_pcm, bandwidth_pcm, downsample,
+                        USver)
+        h = C.c_void_p()
+        _check(lib().fmd_create(C.byref(p), C.byref(self.sink.struct), None, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().fmd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def Reset(self):
+        _check(lib().fmd_reset(self._h))
+
+    def ProcessStream(self, samples_in):
+        iq = np.ascontiguousarray(samples_in)
+        if iq.dtype != np.complex64:
+            iq = iq.astype(np.float32).view(np.complex64)
+        audio = np.empty(2 * iq.size, dtype=np.float32)  # RadioReceiver.cpp:519-520 sizing
+        n = _check(lib().fmd_process_stream(self._h, iq.ctypes.data, iq.size, audio.ctypes.data))
+        return audio[:n]
+
+    def _status(self):
+        st = FmdStatus()
+        _check(lib().fmd_get_status(self._h, C.byref(st)))
+        return st
+
+    def StereoDetected(self):
+        return bool(self._status().stereo_detected)
+
+    def GetTuningOffset(self):
+        return self._status().tuning_offset
+
+    def GetInterfaceLevel(self):
+        return self._status().interface_level
+
+    def GetBasebandLevel(self):
+        return self._status().baseband_level
+
+    def GetPilotLevel(self):
+        return self._status().pilot_level
+
+
+class GroupDecoder:
+    """Host-only UECP group decoder (fmd_group_decoder_*)."""
+
+    def __init__(self):
+        self.sink = _CallbackSink()
+        self._h = lib().fmd_group_decoder_create(C.byref(self.sink.struct), None, 0)
+
+    def push(self, blocks):
+        b = (C.c_uint16 * 4)(*blocks)
+        lib().fmd_group_decoder_push(self._h, b)
+
+    def reset(self):
+        lib().fmd_group_decoder_reset(self._h)
+
+    @property
+    def frames(self):
+        return self.sink.frames.get(0, [])
+
+    @property
+    def name(self):
+        return self.sink.names.get(0, "")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().fmd_group_decoder_destroy(self._h)
+            self._h = None
+
+
+def stuff_uecp_frame(frame):
+    out = (C.c_uint8 * (2 * len(frame) + 2))()
+    src = (C.c_uint8 * len(frame))(*frame)
+    n = lib().fmd_uecp_stuff_frame(src, len(frame), out, len(out))
+    return bytes(out[:n])

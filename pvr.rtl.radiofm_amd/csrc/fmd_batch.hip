@@ -1,0 +1,1055 @@
+/*
+ * fmd_batch.hip -- C ABI (include/fmd.h) of the MI355X FM decoder: device memory, the
+ * per-call position plan (host) and the kernel sequence.  gfx950 only, no CPU fallback.
+ *
+ * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared fmd_batch.hip -o libfmd_hip.so
+ */
+#include "../../include/fmd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "fmd_design.hpp"
+#include "fmd_groups.hpp"
+#include "fmd_kernels.hip.h"
+
+namespace
+{
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                            \
+  do                                                                                            \
+  {                                                                                             \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(FMD_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+
+enum Stage
+{
+  ST_IF_FIR = 0,
+  ST_DEMOD_SERIAL,
+  ST_RDS_HALFBAND,
+  ST_RDS_LPF,
+  ST_RDS_SERIAL,
+  ST_RESAMPLE,
+  ST_AUDIO_LPF,
+  ST_AUDIO_TAIL,
+  ST_ROLL,
+  ST_COUNT
+};
+const char* kStageNames[ST_COUNT] = {"if_fir",      "demod_serial", "rds_halfband",
+                                     "rds_lpf",     "rds_serial",   "resample",
+                                     "audio_lpf",   "audio_tail",   "history_roll"};
+
+template <typename T>
+struct DevBuf
+{
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count)
+  {
+    n = count;
+    if (hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess)
+      return -1;
+    return hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)) == hipSuccess ? 0 : -1;
+  }
+  void release()
+  {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+  }
+};
+
+} // namespace
+
+struct fmd_batch
+{
+  fmd::Params params;
+  fmd::Design des;
+  unsigned C = 0, CP = 0;
+  int device = 0;
+  fmd_callbacks cb{};
+  void* user = nullptr;
+  std::vector<int> shifts;
+
+  // host-tracked, batch-uniform positions
+  unsigned if_pos = 0;     // cDownsampleFilter::m_pos_int
+  unsigned lut_idx = 0;    // cFineTuner::m_index
+  float rs_pos = 0.0f;     // cDownsampleFilter::m_pos_frac (mono == stereo)
+  unsigned rds_lpf_g = 0;  // samples since init of the RDS LPF, mod taps
+  int mf_state = 0;        // cFirFilter::m_State of the matched filter
+  unsigned alpf_g = 0;     // samples since init of the audio LPF, mod taps
+  int hist_sel = 0;        // IF history ping-pong
+  uint32_t call_index = 0;
+
+  // geometry
+  unsigned Mmax = 0, Mstride = 0, Amax = 0, Rmax = 0;
+  std::vector<unsigned> hb_nmax; // max input length per HB stage
+  // last call
+  unsigned lastM = 0, lastA = 0, lastR = 0;
+
+  // device memory
+  DevBuf<float2> lut, hist[2], demod, mix, rdsraw, rlpf, rs, alp;
+  std::vector<DevBuf<float2>> hbbuf; // input buffers of stages 1..n-1 (stage 0 reads mix)
+  DevBuf<float> if_coeff, rs_coeff, bb, raw, rds_lpf_taps, mf_taps2, audio_taps, ktab;
+  DevBuf<float> tap_pll, tap_mf, tap_sync;
+  DevBuf<int> pidx;
+  DevBuf<float> fstate; // all float state arrays, CP each
+  DevBuf<int> istate;
+  DevBuf<uint16_t> r_data;
+  DevBuf<float> mfring;
+  DevBuf<fmd::RdsGroupRec> queue;
+  DevBuf<unsigned> queue_count;
+  unsigned queue_cap = 0;
+  fmd::ChannelState st{};
+  std::vector<fmd::HbCoef> hbcoef;
+
+  // host staging for the host-buffer entry point
+  DevBuf<float> h_iq, h_audio;
+  size_t h_iq_cap = 0, h_audio_cap = 0;
+
+  std::vector<std::unique_ptr<fmd::GroupDecoder>> gdec;
+
+  bool profiling = false;
+  hipEvent_t ev[ST_COUNT + 1] = {};
+  bool ev_valid = false;
+  float stage_ms[ST_COUNT] = {};
+
+  ~fmd_batch()
+  {
+    (void)hipSetDevice(device);
+    lut.release();
+    hist[0].release();
+    hist[1].release();
+    demod.release();
+    mix.release();
+    rdsraw.release();
+    rlpf.release();
+    rs.release();
+    alp.release();
+    for (auto& b : hbbuf)
+      b.release();
+    if_coeff.release();
+    rs_coeff.release();
+    bb.release();
+    raw.release();
+    rds_lpf_taps.release();
+    mf_taps2.release();
+    audio_taps.release();
+    ktab.release();
+    tap_pll.release();
+    tap_mf.release();
+    tap_sync.release();
+    pidx.release();
+    fstate.release();
+    istate.release();
+    r_data.release();
+    mfring.release();
+    queue.release();
+    queue_count.release();
+    h_iq.release();
+    h_audio.release();
+    if (ev_valid)
+      for (auto& e : ev)
+        (void)hipEventDestroy(e);
+  }
+};
+
+namespace
+{
+
+constexpr int kNumFloatState = 28;
+constexpr int kNumIntState = 9;
+
+int upload(void* dst, const void* src, size_t bytes)
+{
+  return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+
+void bind_state(fmd_batch* b)
+{
+  float* f = b->fstate.p;
+  const size_t CP = b->CP;
+  int k = 0;
+  auto nf = [&]() { return f + CP * size_t(k++); };
+  fmd::ChannelState& s = b->st;
+  s.nco_phase = nf();
+  s.nco_incr = nf();
+  s.dc_off = nf();
+  s.if_level = nf();
+  s.bb_mean = nf();
+  s.bb_level = nf();
+  s.p_i1 = nf();
+  s.p_i2 = nf();
+  s.p_q1 = nf();
+  s.p_q2 = nf();
+  s.p_x1 = nf();
+  s.p_freq = nf();
+  s.p_phase = nf();
+  s.p_level = nf();
+  s.osc_re = nf();
+  s.osc_im = nf();
+  s.r_phase = nf();
+  s.r_freq = nf();
+  s.r_w1 = nf();
+  s.r_w2 = nf();
+  s.r_last_sync = nf();
+  s.r_last_slope = nf();
+  s.r_last_data = nf();
+  s.de_re = nf();
+  s.de_im = nf();
+  s.n_w1a = nf();
+  s.n_w2a = nf();
+  s.n_w1b = nf();
+  // n_w2b shares the tail slot
+  s.n_w2b = f + CP * size_t(kNumFloatState);
+  int* i = b->istate.p;
+  int q = 0;
+  auto ni = [&]() { return i + CP * size_t(q++); };
+  s.p_lock_cnt = ni();
+  s.stereo = ni();
+  s.r_last_bit = ni();
+  s.r_bits = reinterpret_cast<uint32_t*>(ni());
+  s.r_block = ni();
+  s.r_bitpos = ni();
+  s.r_state = ni();
+  s.r_boff = ni();
+  s.r_errors = ni();
+  s.r_seq = reinterpret_cast<uint32_t*>(i + CP * size_t(kNumIntState));
+  s.r_data = b->r_data.p;
+  s.r_mfring = b->mfring.p;
+}
+
+/* state a freshly constructed cFmDecoder has (ctor values that are not zero) */
+int init_signal_state(fmd_batch* b)
+{
+  const size_t CP = b->CP;
+  std::vector<float> v(CP);
+  std::fill(v.begin(), v.end(), b->des.p_freq0); // cPilotPhaseLock: m_freq = freq*2pi (:131)
+  if (upload(b->st.p_freq, v.data(), CP * sizeof(float)))
+    return -1;
+  std::fill(v.begin(), v.end(), 1.0f); // CRDSDownConvert: m_Osc1 = (1, 0) (DownConvert.cpp:284)
+  if (upload(b->st.osc_re, v.data(), CP * sizeof(float)))
+    return -1;
+  return 0;
+}
+
+template <typename T>
+int zero_rows(T* p, size_t rows, size_t CP)
+{
+  return hipMemset(p, 0, rows * CP * sizeof(T)) == hipSuccess ? 0 : -1;
+}
+
+/* cFmDecoder::Reset (FmDecode.cpp:326-338) + cRDSRxSignalProcessor::Reset (RDSProcess.cpp:92-118):
+ * clears the demod/RDS recurrences and re-initialises the three RDS filters; leaves tuner index,
+ * FIR/resampler histories, pilot PLL, half-band histories, oscillator, de-emphasis, notch,
+ * audio LPF and the block-sync shift register untouched, like the reference. */
+int do_reset(fmd_batch* b)
+{
+  const size_t CP = b->CP;
+  fmd::ChannelState& s = b->st;
+  float* fz[] = {s.if_level, s.bb_mean,     s.bb_level,     s.dc_off,      s.nco_incr, s.nco_phase,
+                 s.r_phase,  s.r_freq,      s.r_w1,         s.r_w2,        s.r_last_sync,
+                 s.r_last_slope, s.r_last_data};
+  for (float* p : fz)
+    if (hipMemset(p, 0, CP * sizeof(float)) != hipSuccess)
+      return -1;
+  int* iz[] = {s.stereo, s.r_last_bit, s.r_bitpos, s.r_block, s.r_state, s.r_boff};
+  for (int* p : iz)
+    if (hipMemset(p, 0, CP * sizeof(int)) != hipSuccess)
+      return -1;
+  // RDS LPF ring (history rows of rdsraw), matched filter ring, positions
+  if (zero_rows(b->rdsraw.p, b->des.rds_lpf_taps.size() - 1, CP))
+    return -1;
+  if (hipMemset(b->mfring.p, 0, b->mfring.n * sizeof(float)) != hipSuccess)
+    return -1;
+  b->rds_lpf_g = 0;
+  b->mf_state = 0;
+  for (auto& g : b->gdec)
+    if (g)
+      g->reset();
+  return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* fmd_last_error(void)
+{
+  return g_err.c_str();
+}
+
+const char* fmd_version(void)
+{
+  return "fmd-hip 0.1 (gfx950)";
+}
+
+const char* fmd_stage_name(unsigned idx)
+{
+  return idx < ST_COUNT ? kStageNames[idx] : "";
+}
+
+int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* tuning_shifts,
+                     int device, const fmd_callbacks* cb, void* user, fmd_batch** out)
+{
+  if (!params || !out || n_channels == 0)
+    return fail(FMD_ERR_ARG, "fmd_batch_create: null argument or zero channels");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(FMD_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev)
+    return fail(FMD_ERR_ARG, "fmd_batch_create: device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+
+  std::unique_ptr<fmd_batch> b(new fmd_batch);
+  b->device = device;
+  b->params.sample_rate_if = params->sample_rate_if;
+  b->params.tuning_offset = params->tuning_offset;
+  b->params.sample_rate_pcm = params->sample_rate_pcm;
+  b->params.bandwidth_pcm = params->bandwidth_pcm;
+  b->params.downsample = params->downsample;
+  b->params.us_version = params->us_version != 0;
+  b->params.table_size = params->table_size;
+  b->params.if_filter_order = params->if_filter_order;
+  try
+  {
+    b->des = fmd::make_design(b->params);
+  }
+  catch (const std::exception& e)
+  {
+    return fail(FMD_ERR_ARG, e.what());
+  }
+  const fmd::Design& d = b->des;
+  if (d.if_order > FMD_MIN_BLOCK)
+    return fail(FMD_ERR_ARG, "if_filter_order larger than the minimum block");
+  for (const auto& h : d.hb)
+    if (h.len == 11)
+      return fail(FMD_ERR_ARG, "baseband rate >= 320 kHz needs the 11-tap half-band class (unsupported)");
+  if (cb)
+    b->cb = *cb;
+  b->user = user;
+  const unsigned C = n_channels;
+  const unsigned CP = (C + 63u) & ~63u;
+  b->C = C;
+  b->CP = CP;
+
+  // cFineTuner tables, one per channel
+  b->shifts.resize(C);
+  const int def_shift = fmd::tuning_shift_for(b->params);
+  std::vector<float> lut(size_t(2) * d.table_size * C);
+  for (unsigned c = 0; c < C; c++)
+  {
+    b->shifts[c] = tuning_shifts ? tuning_shifts[c] : def_shift;
+    if (c > 0 && b->shifts[c] == b->shifts[c - 1])
+      std::copy_n(&lut[size_t(2) * d.table_size * (c - 1)], 2 * d.table_size, &lut[size_t(2) * d.table_size * c]);
+    else
+    {
+      auto t = fmd::make_tuner_lut(d.table_size, b->shifts[c]);
+      std::copy(t.begin(), t.end(), &lut[size_t(2) * d.table_size * c]);
+    }
+  }
+
+  // geometry
+  b->Mmax = (FMD_MAX_BLOCK + d.D - 1) / d.D + 1;
+  b->Mstride = (b->Mmax + 15u) & ~15u;
+  b->Amax = unsigned(double(b->Mmax) / double(d.rs_step)) + 4;
+  {
+    unsigned n = b->Mmax;
+    for (size_t s = 0; s < d.hb.size(); s++)
+    {
+      b->hb_nmax.push_back(n);
+      n = (n + 1) / 2;
+    }
+    b->Rmax = n;
+  }
+  const unsigned T_lpf = unsigned(d.rds_lpf_taps.size());
+  const unsigned T_mf = unsigned(d.rds_mf_taps.size());
+  const unsigned T_alp = unsigned(d.lpf_taps.size());
+
+  int bad = 0;
+  bad |= b->lut.alloc(size_t(d.table_size) * C);
+  bad |= b->hist[0].alloc(size_t(d.if_order) * C);
+  bad |= b->hist[1].alloc(size_t(d.if_order) * C);
+  bad |= b->demod.alloc(size_t(b->Mstride) * C);
+  bad |= b->if_coeff.alloc(d.if_coeff.size());
+  bad |= b->rs_coeff.alloc(d.rs_coeff.size());
+  bad |= b->bb.alloc(size_t(d.rs_order + b->Mmax) * CP);
+  bad |= b->raw.alloc(size_t(d.rs_order + b->Mmax) * CP);
+  if (d.hb.empty())
+    return fail(FMD_ERR_ARG, "baseband rate too low for the RDS decimation chain");
+  bad |= b->mix.alloc(size_t(d.hb[0].len - 1 + b->Mmax) * CP);
+  b->hbbuf.resize(d.hb.size() - 1);
+  for (size_t s = 1; s < d.hb.size(); s++)
+    bad |= b->hbbuf[s - 1].alloc(size_t(d.hb[s].len - 1 + b->hb_nmax[s]) * CP);
+  bad |= b->rdsraw.alloc(size_t(T_lpf - 1 + b->Rmax) * CP);
+  bad |= b->rlpf.alloc(size_t(b->Rmax) * CP);
+  bad |= b->tap_pll.alloc(size_t(b->Rmax) * CP);
+  bad |= b->tap_mf.alloc(size_t(b->Rmax) * CP);
+  bad |= b->tap_sync.alloc(size_t(b->Rmax) * CP);
+  bad |= b->rs.alloc(size_t(T_alp - 1 + b->Amax) * CP);
+  bad |= b->alp.alloc(size_t(b->Amax) * CP);
+  bad |= b->rds_lpf_taps.alloc(T_lpf);
+  bad |= b->mf_taps2.alloc(size_t(2) * T_mf);
+  bad |= b->audio_taps.alloc(T_alp);
+  bad |= b->ktab.alloc(size_t(b->Amax) * (d.rs_order + 1));
+  bad |= b->pidx.alloc(b->Amax);
+  bad |= b->fstate.alloc(size_t(kNumFloatState + 1) * CP);
+  bad |= b->istate.alloc(size_t(kNumIntState + 1) * CP);
+  bad |= b->r_data.alloc(size_t(4) * CP);
+  bad |= b->mfring.alloc(size_t(T_mf) * CP);
+  b->queue_cap = std::max(4096u, 8u * C);
+  bad |= b->queue.alloc(b->queue_cap);
+  bad |= b->queue_count.alloc(1);
+  if (bad)
+    return fail(FMD_ERR_DEVICE, std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError()));
+
+  bad |= upload(b->lut.p, lut.data(), lut.size() * sizeof(float));
+  bad |= upload(b->if_coeff.p, d.if_coeff.data(), d.if_coeff.size() * sizeof(float));
+  bad |= upload(b->rs_coeff.p, d.rs_coeff.data(), d.rs_coeff.size() * sizeof(float));
+  bad |= upload(b->rds_lpf_taps.p, d.rds_lpf_taps.data(), T_lpf * sizeof(float));
+  bad |= upload(b->audio_taps.p, d.lpf_taps.data(), T_alp * sizeof(float));
+  {
+    std::vector<float> t2(size_t(2) * T_mf);
+    for (unsigned i = 0; i < 2 * T_mf; i++)
+      t2[i] = d.rds_mf_taps[i % T_mf];
+    bad |= upload(b->mf_taps2.p, t2.data(), t2.size() * sizeof(float));
+  }
+  for (const auto& h : d.hb)
+  {
+    fmd::HbCoef hc{};
+    for (int i = 0; i < h.len; i++)
+      hc.c[i] = h.coef[size_t(i)];
+    b->hbcoef.push_back(hc);
+  }
+  bind_state(b.get());
+  bad |= init_signal_state(b.get());
+  if (bad)
+    return fail(FMD_ERR_DEVICE, "upload of constants failed");
+  if (do_reset(b.get())) // the cFmDecoder ctor ends with Reset() (FmDecode.cpp:313)
+    return fail(FMD_ERR_DEVICE, "state reset failed");
+
+  b->gdec.resize(C);
+  HIPCHK(hipDeviceSynchronize());
+  *out = b.release();
+  return FMD_OK;
+}
+
+void fmd_batch_destroy(fmd_batch* b)
+{
+  delete b;
+}
+
+int fmd_batch_reset(fmd_batch* b)
+{
+  if (!b)
+    return fail(FMD_ERR_ARG, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  if (do_reset(b))
+    return fail(FMD_ERR_DEVICE, "state reset failed");
+  HIPCHK(hipDeviceSynchronize());
+  return FMD_OK;
+}
+
+unsigned fmd_batch_channels(const fmd_batch* b)
+{
+  return b ? b->C : 0;
+}
+
+unsigned fmd_batch_max_audio_floats(const fmd_batch* b, unsigned samples)
+{
+  if (!b)
+    return 0;
+  const unsigned M = (samples + b->des.D - 1) / b->des.D + 1;
+  return 2 * (unsigned(double(M) / double(b->des.rs_step)) + 4);
+}
+
+int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_stride,
+                             unsigned samples, float* d_audio, size_t audio_channel_stride,
+                             unsigned* out_floats, void* stream_)
+{
+  if (!b || !d_iq || !d_audio)
+    return fail(FMD_ERR_ARG, "fmd_batch_process_device: null argument");
+  if (samples > FMD_MAX_BLOCK || samples < FMD_MIN_BLOCK)
+    return fail(FMD_ERR_SIZE, "samples must be within [FMD_MIN_BLOCK, FMD_MAX_BLOCK]");
+  const fmd::Design& d = b->des;
+  const unsigned C = b->C, CP = b->CP, N = samples, D = d.D;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIPCHK(hipSetDevice(b->device));
+
+  /* ---- position plan (batch-uniform, mirrors the reference's bookkeeping) ---- */
+  const unsigned pos = b->if_pos;
+  const unsigned M = pos < N ? (N - pos + D - 1) / D : 0; // DownConvert.cpp:112,123
+  if (M == 0)
+    return fail(FMD_ERR_SIZE, "block shorter than the decimator phase");
+  std::vector<unsigned> hb_in(d.hb.size());
+  unsigned R = M;
+  for (size_t s = 0; s < d.hb.size(); s++)
+  {
+    hb_in[s] = R;
+    if (R < 2u * unsigned(d.hb[s].len - 1))
+      return fail(FMD_ERR_SIZE, "block too short for the RDS half-band chain at this rate");
+    R = (R + 1) / 2; // DownConvert.cpp:526
+  }
+  // fractional resampler walk (DownConvert.cpp:203-232), float arithmetic as written there
+  const float p = b->rs_pos;
+  const float pstep = d.rs_step;
+  unsigned A = 0;
+  float pf = p;
+  unsigned pi = unsigned(int(pf));
+  while (pi < M)
+  {
+    A++;
+    pf = p + float(A) * pstep;
+    pi = unsigned(int(pf));
+  }
+  float new_rs_pos = pf - float(M);
+  if (new_rs_pos < 0)
+    new_rs_pos = 0;
+  if (A > b->Amax || M > b->Mmax)
+    return fail(FMD_ERR_STATE, "internal: plan exceeds buffer geometry");
+  if (size_t(2) * A > audio_channel_stride && C > 1)
+    return fail(FMD_ERR_ARG, "audio_channel_stride smaller than the audio produced");
+
+  const unsigned T_lpf = unsigned(d.rds_lpf_taps.size());
+  const unsigned T_mf = unsigned(d.rds_mf_taps.size());
+  const unsigned T_alp = unsigned(d.lpf_taps.size());
+  const unsigned Hbb = d.rs_order;
+  b->call_index++;
+
+  if (b->profiling && !b->ev_valid)
+  {
+    for (auto& e : b->ev)
+      HIPCHK(hipEventCreate(&e));
+    b->ev_valid = true;
+  }
+  auto mark = [&](int i) {
+    if (b->profiling)
+      (void)hipEventRecord(b->ev[i], stream);
+  };
+  mark(0);
+
+  /* ---- K1: tuner + IF decimating FIR ---- */
+  {
+    constexpr int TILE = 256;
+    const unsigned ntiles = (M + TILE - 1) / TILE;
+    const size_t lds = (size_t(TILE - 1) * D + d.if_order) * sizeof(float2);
+    if (lds > 160 * 1024)
+      return fail(FMD_ERR_ARG, "IF filter window does not fit in LDS");
+    static bool attr_set = false;
+    if (!attr_set)
+    {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fmd::k_if_fir<TILE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(fmd::k_if_fir<TILE>, dim3(C, ntiles), dim3(TILE), lds, stream,
+                       reinterpret_cast<const float2*>(d_iq), iq_channel_stride, N,
+                       b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, d.table_size,
+                       b->lut_idx, b->if_coeff.p, d.if_order, D, pos, M, b->demod.p, b->Mstride);
+  }
+  mark(1);
+
+  /* ---- K2: baseband-rate recurrences ---- */
+  {
+    fmd::DemodConsts k{};
+    k.pll_alpha = d.pll_alpha;
+    k.pll_beta = d.pll_beta;
+    k.nco_hl = d.nco_hl;
+    k.nco_ll = d.nco_ll;
+    k.demod_gain = d.demod_gain;
+    k.p_minfreq = d.p_minfreq;
+    k.p_maxfreq = d.p_maxfreq;
+    k.p_b0 = d.p_b0;
+    k.p_a1 = d.p_a1;
+    k.p_a2 = d.p_a2;
+    k.p_lf_b0 = d.p_lf_b0;
+    k.p_lf_b1 = d.p_lf_b1;
+    k.p_minsignal = d.p_minsignal;
+    k.p_lock_delay = d.p_lock_delay;
+    k.osc_cos = d.rds_osc_cos;
+    k.osc_sin = d.rds_osc_sin;
+    hipLaunchKernelGGL(fmd::k_demod_serial, dim3(CP / 64), dim3(64), 0, stream,
+                       reinterpret_cast<const float2*>(d_iq), iq_channel_stride, N, b->lut.p,
+                       d.table_size, b->lut_idx, b->demod.p, b->Mstride, M, C, CP, k, b->st, b->bb.p,
+                       Hbb, b->raw.p, b->mix.p, unsigned(d.hb[0].len - 1));
+  }
+  mark(2);
+
+  /* ---- K3: half-band chain ---- */
+  {
+    const float2* in = b->mix.p;
+    for (size_t s = 0; s < d.hb.size(); s++)
+    {
+      const unsigned n_out = (hb_in[s] + 1) / 2;
+      const bool last = (s + 1 == d.hb.size());
+      float2* outp = last ? b->rdsraw.p : b->hbbuf[s].p;
+      const unsigned Hout = last ? (T_lpf - 1) : unsigned(d.hb[s + 1].len - 1);
+      hipLaunchKernelGGL(fmd::k_halfband, dim3(CP / 64, (n_out + 3) / 4), dim3(64, 4), 0, stream, in,
+                         outp, n_out, d.hb[s].len, b->hbcoef[s], C, CP, Hout);
+      in = outp;
+    }
+  }
+  mark(3);
+
+  /* ---- K4: RDS 75-tap low-pass ---- */
+  hipLaunchKernelGGL(fmd::k_ring_fir, dim3(CP / 64, (R + 3) / 4), dim3(64, 4), 0, stream,
+                     b->rdsraw.p, b->rlpf.p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C, CP, 0u);
+  mark(4);
+
+  /* ---- K5: RDS recurrences and block sync ---- */
+  {
+    fmd::RdsConsts k{};
+    k.pll_alpha = d.rds_pll_alpha;
+    k.pll_beta = d.rds_pll_beta;
+    k.nco_hl = d.rds_nco_hl;
+    k.nco_ll = d.rds_nco_ll;
+    k.bs_b0 = d.bitsync.b0;
+    k.bs_b1 = d.bitsync.b1;
+    k.bs_b2 = d.bitsync.b2;
+    k.bs_a1 = d.bitsync.a1;
+    k.bs_a2 = d.bitsync.a2;
+    k.mf_taps = int(T_mf);
+    hipLaunchKernelGGL(fmd::k_rds_serial, dim3(CP / 64), dim3(64), size_t(T_mf) * 64 * sizeof(float),
+                       stream, b->rlpf.p, R, C, CP, k, b->mf_taps2.p, b->mf_state, b->st,
+                       b->call_index, b->queue.p, b->queue_count.p, b->queue_cap, b->tap_pll.p,
+                       b->tap_mf.p, b->tap_sync.p);
+  }
+  mark(5);
+
+  /* ---- K6/K7: fractional resamplers (mono + stereo) ---- */
+  hipLaunchKernelGGL(fmd::k_rs_table, dim3(A), dim3(64), 0, stream, b->rs_coeff.p, d.rs_order, p,
+                     pstep, A, b->ktab.p, b->pidx.p);
+  hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 3) / 4), dim3(64, 4), 0, stream, b->bb.p,
+                     b->raw.p, Hbb, d.rs_order, b->ktab.p, b->pidx.p, A, b->rs.p, T_alp - 1, C, CP);
+  mark(6);
+
+  /* ---- audio 15 kHz low-pass on the (stereo, mono) pair ---- */
+  hipLaunchKernelGGL(fmd::k_ring_fir, dim3(CP / 64, (A + 3) / 4), dim3(64, 4), 0, stream, b->rs.p,
+                     b->alp.p, A, int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
+  mark(7);
+
+  /* ---- K8: de-emphasis, notch, L/R ---- */
+  {
+    fmd::AudioConsts k{};
+    k.de_alpha = d.de_alpha;
+    k.n_b0 = d.notch.b0;
+    k.n_b1 = d.notch.b1;
+    k.n_b2 = d.notch.b2;
+    k.n_a1 = d.notch.a1;
+    k.n_a2 = d.notch.a2;
+    hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, stream, b->alp.p, A, C, CP, k,
+                       b->st, d_audio, audio_channel_stride);
+  }
+  mark(8);
+
+  /* ---- history rolls: keep the last H rows of every windowed buffer for the next call ---- */
+  {
+    const dim3 g((CP + 255) / 256), t(256);
+    hipLaunchKernelGGL(fmd::k_roll<float>, g, t, 0, stream, b->bb.p, Hbb, M, CP);
+    hipLaunchKernelGGL(fmd::k_roll<float>, g, t, 0, stream, b->raw.p, Hbb, M, CP);
+    hipLaunchKernelGGL(fmd::k_roll<float2>, g, t, 0, stream, b->mix.p, unsigned(d.hb[0].len - 1), hb_in[0], CP);
+    for (size_t s = 1; s < d.hb.size(); s++)
+      hipLaunchKernelGGL(fmd::k_roll<float2>, g, t, 0, stream, b->hbbuf[s - 1].p,
+                         unsigned(d.hb[s].len - 1), hb_in[s], CP);
+    hipLaunchKernelGGL(fmd::k_roll<float2>, g, t, 0, stream, b->rdsraw.p, T_lpf - 1, R, CP);
+    hipLaunchKernelGGL(fmd::k_roll<float2>, g, t, 0, stream, b->rs.p, T_alp - 1, A, CP);
+  }
+  mark(9);
+  HIPCHK(hipGetLastError());
+
+  /* ---- advance the host-tracked positions ---- */
+  b->if_pos = pos + M * D - N;                      // DownConvert.cpp:132
+  b->lut_idx = (b->lut_idx + N) % d.table_size;     // FmDecode.cpp:81
+  b->rs_pos = new_rs_pos;                           // DownConvert.cpp:230-232
+  b->rds_lpf_g = (b->rds_lpf_g + R) % T_lpf;
+  b->mf_state = int(((long long)b->mf_state - (long long)R) % (long long)T_mf);
+  if (b->mf_state < 0)
+    b->mf_state += int(T_mf);
+  b->alpf_g = (b->alpf_g + A) % T_alp;
+  b->hist_sel ^= 1;
+  b->lastM = M;
+  b->lastA = A;
+  b->lastR = R;
+  if (out_floats)
+    *out_floats = 2 * A;
+  return FMD_OK;
+}
+
+int fmd_batch_collect_rds(fmd_batch* b, fmd_rds_group* out, unsigned cap, int run_group_decoder,
+                          void* stream_)
+{
+  if (!b)
+    return fail(FMD_ERR_ARG, "null batch");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIPCHK(hipSetDevice(b->device));
+  unsigned n = 0;
+  HIPCHK(hipMemcpyAsync(&n, b->queue_count.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  if (n > b->queue_cap)
+    n = b->queue_cap; // overflow: the oldest queue_cap groups are kept
+  std::vector<fmd::RdsGroupRec> recs(n);
+  if (n)
+    HIPCHK(hipMemcpyAsync(recs.data(), b->queue.p, size_t(n) * sizeof(fmd::RdsGroupRec),
+                          hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemsetAsync(b->queue_count.p, 0, sizeof(unsigned), stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  std::sort(recs.begin(), recs.end(), [](const fmd::RdsGroupRec& x, const fmd::RdsGroupRec& y) {
+    if (x.call_index != y.call_index)
+      return x.call_index < y.call_index;
+    if (x.channel != y.channel)
+      return x.channel < y.channel;
+    return x.seq < y.seq;
+  });
+  unsigned k = 0;
+  for (const auto& r : recs)
+  {
+    if (run_group_decoder && r.channel < b->C)
+    {
+      auto& g = b->gdec[r.channel];
+      if (!g)
+        g.reset(new fmd::GroupDecoder(&b->cb, b->user, r.channel));
+      g->push(r.blocks);
+    }
+    if (out && k < cap)
+    {
+      out[k].channel = r.channel;
+      out[k].call_index = r.call_index;
+      for (int q = 0; q < 4; q++)
+        out[k].blocks[q] = r.blocks[q];
+      k++;
+    }
+  }
+  return int(out ? k : n);
+}
+
+int fmd_batch_process_host(fmd_batch* b, const float* iq, size_t iq_channel_stride, unsigned samples,
+                           float* audio, size_t audio_channel_stride, unsigned* out_floats)
+{
+  if (!b || !iq || !audio)
+    return fail(FMD_ERR_ARG, "fmd_batch_process_host: null argument");
+  HIPCHK(hipSetDevice(b->device));
+  const unsigned C = b->C;
+  const size_t dev_iq_stride = iq_channel_stride ? samples : 0;
+  const size_t iq_floats = size_t(2) * samples * (iq_channel_stride ? C : 1);
+  const size_t a_stride = fmd_batch_max_audio_floats(b, samples);
+  if (iq_floats > b->h_iq_cap)
+  {
+    b->h_iq.release();
+    if (b->h_iq.alloc(iq_floats))
+      return fail(FMD_ERR_DEVICE, "staging allocation failed");
+    b->h_iq_cap = iq_floats;
+  }
+  if (a_stride * C > b->h_audio_cap)
+  {
+    b->h_audio.release();
+    if (b->h_audio.alloc(a_stride * C))
+      return fail(FMD_ERR_DEVICE, "staging allocation failed");
+    b->h_audio_cap = a_stride * C;
+  }
+  if (iq_channel_stride)
+    HIPCHK(hipMemcpy2D(b->h_iq.p, size_t(2) * samples * sizeof(float), iq,
+                       size_t(2) * iq_channel_stride * sizeof(float), size_t(2) * samples * sizeof(float),
+                       C, hipMemcpyHostToDevice));
+  else
+    HIPCHK(hipMemcpy(b->h_iq.p, iq, iq_floats * sizeof(float), hipMemcpyHostToDevice));
+  unsigned nf = 0;
+  int rc = fmd_batch_process_device(b, b->h_iq.p, dev_iq_stride, samples, b->h_audio.p, a_stride, &nf,
+                                    nullptr);
+  if (rc != FMD_OK)
+    return rc;
+  if (C > 1 && nf > audio_channel_stride)
+    return fail(FMD_ERR_ARG, "audio_channel_stride smaller than the audio produced");
+  HIPCHK(hipMemcpy2D(audio, (C > 1 ? audio_channel_stride : size_t(nf)) * sizeof(float), b->h_audio.p,
+                     a_stride * sizeof(float), size_t(nf) * sizeof(float), C, hipMemcpyDeviceToHost));
+  rc = fmd_batch_collect_rds(b, nullptr, 0, 1, nullptr);
+  if (rc < 0)
+    return rc;
+  if (out_floats)
+    *out_floats = nf;
+  return FMD_OK;
+}
+
+int fmd_batch_get_status(fmd_batch* b, unsigned channel, fmd_status* stt)
+{
+  if (!b || !stt || channel >= b->C)
+    return fail(FMD_ERR_ARG, "fmd_batch_get_status: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  float if_level = 0, bb_mean = 0, bb_level = 0, p_level = 0;
+  int stereo = 0, rstate = 0;
+  HIPCHK(hipMemcpy(&if_level, b->st.if_level + channel, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&bb_mean, b->st.bb_mean + channel, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&bb_level, b->st.bb_level + channel, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&p_level, b->st.p_level + channel, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&stereo, b->st.stereo + channel, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&rstate, b->st.r_state + channel, 4, hipMemcpyDeviceToHost));
+  stt->stereo_detected = stereo;
+  // FmDecode.h:146-150
+  const float tuned = float(-b->shifts[channel]) * b->des.fs_if / float(int(b->des.table_size));
+  stt->tuning_offset = tuned + bb_mean * b->des.freq_dev;
+  stt->interface_level = if_level;
+  stt->baseband_level = bb_level;
+  stt->pilot_level = 2 * p_level; // FmDecode.h:75
+  stt->rds_state = rstate;
+  return FMD_OK;
+}
+
+int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsigned cap_floats)
+{
+  if (!b || !out || channel >= b->C)
+    return fail(FMD_ERR_ARG, "fmd_batch_get_tap: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  const size_t CP = b->CP;
+  const void* src = nullptr;
+  size_t esize = 4, rows = 0, first_row = 0;
+  const unsigned T_alp = unsigned(b->des.lpf_taps.size());
+  switch (tap)
+  {
+    case FMD_TAP_DEMOD:
+      if (size_t(2) * b->lastM > cap_floats)
+        return fail(FMD_ERR_ARG, "tap buffer too small");
+      HIPCHK(hipMemcpy(out, b->demod.p + size_t(channel) * b->Mstride, size_t(b->lastM) * 8,
+                       hipMemcpyDeviceToHost));
+      return int(b->lastM);
+    /* windowed buffers were rolled at the end of the call: the block's rows are still in place
+     * at [H, H+n) except the first H rows region, which now holds the tail -- read the data rows */
+    case FMD_TAP_BASEBAND:
+      src = b->bb.p;
+      first_row = b->des.rs_order;
+      rows = b->lastM;
+      break;
+    case FMD_TAP_PILOT38:
+      src = b->raw.p;
+      first_row = b->des.rs_order;
+      rows = b->lastM;
+      break;
+    case FMD_TAP_MONO_RS:
+    case FMD_TAP_STEREO_RS:
+      src = reinterpret_cast<const float*>(b->rs.p) + (tap == FMD_TAP_MONO_RS ? 1 : 0);
+      esize = 4;
+      first_row = T_alp - 1;
+      rows = b->lastA;
+      {
+        if (rows > cap_floats)
+          return fail(FMD_ERR_ARG, "tap buffer too small");
+        const char* s = reinterpret_cast<const char*>(src) + (first_row * CP + channel) * 8;
+        HIPCHK(hipMemcpy2D(out, 4, s, CP * 8, 4, rows, hipMemcpyDeviceToHost));
+        return int(rows);
+      }
+    case FMD_TAP_RDS_LPF:
+      src = b->rlpf.p;
+      esize = 8;
+      rows = b->lastR;
+      break;
+    case FMD_TAP_RDS_PLL:
+      src = b->tap_pll.p;
+      rows = b->lastR;
+      break;
+    case FMD_TAP_RDS_MF:
+      src = b->tap_mf.p;
+      rows = b->lastR;
+      break;
+    case FMD_TAP_RDS_SYNC:
+      src = b->tap_sync.p;
+      rows = b->lastR;
+      break;
+    default:
+      return fail(FMD_ERR_ARG, "unknown tap");
+  }
+  if (rows * (esize / 4) > cap_floats)
+    return fail(FMD_ERR_ARG, "tap buffer too small");
+  const char* s = reinterpret_cast<const char*>(src) + (first_row * CP + channel) * esize;
+  if (rows)
+    HIPCHK(hipMemcpy2D(out, esize, s, CP * esize, esize, rows, hipMemcpyDeviceToHost));
+  return int(rows);
+}
+
+int fmd_batch_get_design(fmd_batch* b, int what, float* out, unsigned cap)
+{
+  if (!b || !out)
+    return fail(FMD_ERR_ARG, "fmd_batch_get_design: bad argument");
+  const fmd::Design& d = b->des;
+  std::vector<float> v;
+  switch (what)
+  {
+    case FMD_DESIGN_IF_TAPS:
+      v = d.if_coeff;
+      break;
+    case FMD_DESIGN_RS_TAPS:
+      v = d.rs_coeff;
+      break;
+    case FMD_DESIGN_AUDIO_LPF:
+      v = d.lpf_taps;
+      break;
+    case FMD_DESIGN_RDS_LPF:
+      v = d.rds_lpf_taps;
+      break;
+    case FMD_DESIGN_RDS_MF:
+      v = d.rds_mf_taps;
+      break;
+    case FMD_DESIGN_LUT0:
+      v = fmd::make_tuner_lut(d.table_size, b->shifts[0]);
+      break;
+    case FMD_DESIGN_SCALARS:
+      v = {float(b->shifts[0]), d.demod_gain,  d.de_alpha,     d.pll_alpha,  d.pll_beta,
+           d.nco_hl,            d.nco_ll,      d.p_minfreq,    d.p_maxfreq,  d.p_b0,
+           d.p_a1,              d.p_a2,        d.p_lf_b0,      d.p_lf_b1,    d.p_freq0,
+           float(d.p_lock_delay), float(d.rs_order), d.rs_step, d.rds_rate,  d.rds_nco_inc,
+           d.rds_osc_cos,       d.rds_osc_sin, d.rds_pll_alpha, d.rds_pll_beta, d.rds_nco_hl,
+           d.rds_nco_ll,        d.fs_bb,       float(d.rds_mf_taps.size()),
+           d.notch.b0, d.notch.b1, d.notch.b2, d.notch.a1, d.notch.a2,
+           d.bitsync.b0, d.bitsync.b1, d.bitsync.b2, d.bitsync.a1, d.bitsync.a2};
+      break;
+    default:
+      return fail(FMD_ERR_ARG, "unknown design item");
+  }
+  for (size_t i = 0; i < v.size() && i < cap; i++)
+    out[i] = v[i];
+  return int(v.size());
+}
+
+int fmd_batch_set_profiling(fmd_batch* b, int enable)
+{
+  if (!b)
+    return fail(FMD_ERR_ARG, "null batch");
+  b->profiling = enable != 0;
+  return FMD_OK;
+}
+
+int fmd_batch_get_stage_ms(fmd_batch* b, float* out, unsigned cap)
+{
+  if (!b || !out)
+    return fail(FMD_ERR_ARG, "bad argument");
+  if (!b->profiling || !b->ev_valid)
+    return fail(FMD_ERR_STATE, "profiling not enabled or no call made");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipEventSynchronize(b->ev[ST_COUNT]));
+  for (int i = 0; i < ST_COUNT; i++)
+  {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]));
+    b->stage_ms[i] = ms;
+    if (unsigned(i) < cap)
+      out[i] = ms;
+  }
+  return ST_COUNT;
+}
+
+/* ---- single decoder = batch of one -------------------------------------------------------- */
+struct fmd_decoder
+{
+  fmd_batch* b;
+};
+
+int fmd_create(const fmd_params* params, const fmd_callbacks* cb, void* user, fmd_decoder** out)
+{
+  if (!out)
+    return fail(FMD_ERR_ARG, "null out");
+  *out = nullptr;
+  fmd_batch* b = nullptr;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int rc = fmd_batch_create(params, 1, nullptr, dev, cb, user, &b);
+  if (rc != FMD_OK)
+    return rc;
+  *out = new fmd_decoder{b};
+  return FMD_OK;
+}
+
+void fmd_destroy(fmd_decoder* d)
+{
+  if (!d)
+    return;
+  fmd_batch_destroy(d->b);
+  delete d;
+}
+
+int fmd_reset(fmd_decoder* d)
+{
+  return d ? fmd_batch_reset(d->b) : fail(FMD_ERR_ARG, "null decoder");
+}
+
+int fmd_process_stream(fmd_decoder* d, const float* iq, unsigned samples, float* audio)
+{
+  if (!d)
+    return fail(FMD_ERR_ARG, "null decoder");
+  unsigned nf = 0;
+  int rc = fmd_batch_process_host(d->b, iq, 0, samples, audio, 0, &nf);
+  return rc == FMD_OK ? int(nf) : rc;
+}
+
+int fmd_get_status(fmd_decoder* d, fmd_status* st)
+{
+  return d ? fmd_batch_get_status(d->b, 0, st) : fail(FMD_ERR_ARG, "null decoder");
+}
+
+/* ---- host-only pieces ----------------------------------------------------------------------- */
+struct fmd_group_decoder
+{
+  fmd::GroupDecoder g;
+  fmd_group_decoder(const fmd_callbacks* cb, void* user, unsigned ch) : g(cb, user, ch) {}
+};
+
+fmd_group_decoder* fmd_group_decoder_create(const fmd_callbacks* cb, void* user, unsigned channel)
+{
+  return new fmd_group_decoder(cb, user, channel);
+}
+void fmd_group_decoder_destroy(fmd_group_decoder* g)
+{
+  delete g;
+}
+void fmd_group_decoder_reset(fmd_group_decoder* g)
+{
+  if (g)
+    g->g.reset();
+}
+void fmd_group_decoder_push(fmd_group_decoder* g, const uint16_t blocks[4])
+{
+  if (g)
+    g->g.push(blocks);
+}
+
+int fmd_uecp_stuff_frame(const uint8_t* frame, unsigned len, uint8_t* out, unsigned cap)
+{
+  // cRadioReceiver::AddUECPDataFrame (RadioReceiver.cpp:387-414)
+  unsigned k = 0;
+  auto put = [&](uint8_t v) {
+    if (k < cap)
+      out[k] = v;
+    k++;
+  };
+  put(0xFE);
+  for (unsigned i = 0; i < len; i++)
+  {
+    const uint8_t v = frame[i];
+    if (v < 0xFD)
+      put(v);
+    else
+    {
+      put(0xFD);
+      put(uint8_t((v & 3) - 1));
+    }
+  }
+  put(0xFF);
+  return k <= cap ? int(k) : -1;
+}
+
+} // extern "C"

@@ -1,0 +1,736 @@
+/*
+ * fmd_kernels.hip.h -- gfx950 kernels of the batched FM decoder.
+ *
+ * Data layout in HBM (C channels, CP = C rounded up to 64):
+ *   IQ input        [C][N]      complex<float>, one contiguous stream per channel (API layout)
+ *   demod           [C][Mstride] complex<float>  channel-major (written coalesced by the FIR)
+ *   everything else [row][CP]   "time-major": one row per sample instant, channels contiguous,
+ *                               so a wavefront = 64 channels at one instant and every access is a
+ *                               coalesced 256/512-byte row segment.  Buffers that feed a windowed
+ *                               stage start with H "history" rows (the last H samples of the
+ *                               previous call), so a window never needs a branch.
+ * All positions (decimator phase, resampler fraction, tuner index, FIR ring index) are the same
+ * for every channel of a batch and are tracked on the host; only signal state is per channel.
+ *
+ * Arithmetic is float with the reference's promotions, sequential accumulation in the
+ * reference's order, and no FMA contraction (the file is compiled with -ffp-contract=off), so
+ * the outputs are bit-comparable with the CPU path.  Citations: /root/reference/src/.
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fmd_math.h"
+
+namespace fmd
+{
+
+struct DemodConsts
+{
+  // FM PLL (FmDecode.cpp:305-312, :254)
+  float pll_alpha, pll_beta, nco_hl, nco_ll, demod_gain;
+  // pilot PLL (FmDecode.cpp:88-140)
+  float p_minfreq, p_maxfreq, p_b0, p_a1, p_a2, p_lf_b0, p_lf_b1, p_minsignal;
+  int p_lock_delay;
+  // RDS quadrature oscillator (DownConvert.cpp:311-320)
+  float osc_cos, osc_sin;
+};
+
+struct RdsConsts
+{
+  float pll_alpha, pll_beta, nco_hl, nco_ll;
+  float bs_b0, bs_b1, bs_b2, bs_a1, bs_a2; // bit-sync resonator
+  int mf_taps;
+};
+
+struct AudioConsts
+{
+  float de_alpha;
+  float n_b0, n_b1, n_b2, n_a1, n_a2; // 19 kHz notch
+};
+
+/* per-channel signal state, structure of arrays, each array CP long */
+struct ChannelState
+{
+  // FM PLL
+  float *nco_phase, *nco_incr, *dc_off;
+  // level meters
+  float *if_level, *bb_mean, *bb_level;
+  // pilot PLL
+  float *p_i1, *p_i2, *p_q1, *p_q2, *p_x1, *p_freq, *p_phase, *p_level;
+  int *p_lock_cnt, *stereo;
+  // RDS oscillator
+  float *osc_re, *osc_im;
+  // RDS PLL / bit sync / slicer
+  float *r_phase, *r_freq, *r_w1, *r_w2, *r_last_sync, *r_last_slope, *r_last_data;
+  int* r_last_bit;
+  // RDS block sync
+  uint32_t* r_bits;
+  int *r_block, *r_bitpos, *r_state, *r_boff, *r_errors;
+  uint16_t* r_data; // [4][CP]
+  uint32_t* r_seq;
+  // matched filter ring [mf_taps][CP]
+  float* r_mfring;
+  // de-emphasis, notch
+  float *de_re, *de_im, *n_w1a, *n_w2a, *n_w1b, *n_w2b;
+};
+
+struct RdsGroupRec
+{
+  uint32_t channel;
+  uint32_t call_index;
+  uint32_t seq;
+  uint16_t blocks[4];
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+  // std::complex<float> product: (ac - bd) + i(ad + bc), four products and two sums, each rounded
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* K1: cFineTuner (FmDecode.cpp:66-82) fused into cDownsampleFilter::Process(complex)           */
+/*     (DownConvert.cpp:98-154).  One workgroup = one channel x TILE outputs.  The tuned IQ     */
+/*     window (overlap-save: (TILE-1)*D + order samples) is staged once in LDS; each thread     */
+/*     then accumulates its output over taps j = 1..order in the reference's order.  Taps are   */
+/*     wave-uniform (scalar loads).                                                             */
+/* ------------------------------------------------------------------------------------------ */
+template <int TILE>
+__global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, size_t chan_stride,
+                                                 unsigned N, const float2* __restrict__ hist_in,
+                                                 float2* __restrict__ hist_out,
+                                                 const float2* __restrict__ lut, unsigned T,
+                                                 unsigned lut_idx0, const float* __restrict__ coeff,
+                                                 unsigned order, unsigned D, unsigned pos, unsigned M,
+                                                 float2* __restrict__ out, unsigned Mstride)
+{
+  extern __shared__ float2 win[];
+  const unsigned c = blockIdx.x;
+  const unsigned m0 = blockIdx.y * TILE;
+  const unsigned tid = threadIdx.x;
+  const unsigned nout = min((unsigned)TILE, M - m0);
+  const int k_lo = (int)(pos + m0 * D) - (int)order; // absolute index of win[0]
+  const unsigned count = (nout - 1) * D + order;
+  const float2* __restrict__ x = iq + (size_t)c * chan_stride;
+  const float2* __restrict__ l = lut + (size_t)c * T;
+  const float2* __restrict__ h = hist_in + (size_t)c * order;
+
+  for (unsigned i = tid; i < count; i += TILE)
+  {
+    const int k = k_lo + (int)i;
+    float2 v;
+    if (k >= 0)
+      v = cmul(x[k], l[(lut_idx0 + (unsigned)k) % T]);
+    else
+      v = h[(int)order + k]; // tail of the previous call, already tuned
+    win[i] = v;
+  }
+  __syncthreads();
+
+  if (tid < nout)
+  {
+    const float2* w = win + tid * D + order; // w[-j] = x[p - j]
+    float2 acc = make_float2(0.0f, 0.0f);
+#pragma unroll 8
+    for (unsigned j = 1; j <= order; j++)
+    {
+      const float k = coeff[j];
+      const float2 s = w[-(int)j];
+      acc.x += s.x * k;
+      acc.y += s.y * k;
+    }
+    out[(size_t)c * Mstride + m0 + tid] = acc;
+  }
+
+  // the workgroup of the last tile also saves the last `order` tuned samples (:146-151)
+  if (blockIdx.y == gridDim.y - 1)
+  {
+    float2* __restrict__ ho = hist_out + (size_t)c * order;
+    for (unsigned i = tid; i < order; i += TILE)
+    {
+      const unsigned k = N - order + i;
+      ho[i] = cmul(x[k], l[(lut_idx0 + k) % T]);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* K2: everything that is a sample-by-sample recurrence at the baseband rate, one lane per     */
+/*     channel: RMSLevelApprox (FmDecode.cpp:505-519), the FM PLL demodulator (:362-415),       */
+/*     SamplesMeanRMS (:522-539), cPilotPhaseLock::Process (:143-229) with the 2*baseband       */
+/*     multiply (:455-456), and the RDS quadrature-oscillator mix (DownConvert.cpp:429-466).    */
+/* ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(64) void k_demod_serial(
+    const float2* __restrict__ iq, size_t chan_stride, unsigned N, const float2* __restrict__ lut,
+    unsigned T, unsigned lut_idx0, const float2* __restrict__ demod, unsigned Mstride, unsigned M,
+    unsigned C, unsigned CP, DemodConsts k, ChannelState st, float* __restrict__ bb, unsigned Hbb,
+    float* __restrict__ raw, float2* __restrict__ mix, unsigned Hmix)
+{
+  const unsigned c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C)
+    return;
+
+  { // IF level over the first ceil(N/64) tuned samples, EMA (FmDecode.cpp:427)
+    const unsigned n = (N + 63) / 64;
+    const float2* __restrict__ x = iq + (size_t)c * chan_stride;
+    const float2* __restrict__ l = lut + (size_t)c * T;
+    float level = 0.0f;
+    for (unsigned i = 0; i < n; ++i)
+    {
+      const float2 s = cmul(x[i], l[(lut_idx0 + i) % T]);
+      level += s.x * s.x + s.y * s.y;
+    }
+    const float rms = sqrtf(level / (float)n);
+    st.if_level[c] = 0.95f * st.if_level[c] + 0.05f * rms;
+  }
+
+  float nco_phase = st.nco_phase[c], nco_incr = st.nco_incr[c], dc = st.dc_off[c];
+  float p_i1 = st.p_i1[c], p_i2 = st.p_i2[c], p_q1 = st.p_q1[c], p_q2 = st.p_q2[c];
+  float p_x1 = st.p_x1[c], p_freq = st.p_freq[c], p_phase = st.p_phase[c];
+  float p_level = 1000.0f; // FmDecode.cpp:147
+  float o_re = st.osc_re[c], o_im = st.osc_im[c];
+  float vsum = 0.0f, vsumsq = 0.0f;
+
+  const float4* __restrict__ row = reinterpret_cast<const float4*>(demod + (size_t)c * Mstride);
+  for (unsigned m0 = 0; m0 < M; m0 += 8)
+  {
+    float4 chunk[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      chunk[q] = row[(m0 >> 1) + q];
+    const float* cf = reinterpret_cast<const float*>(chunk);
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+    {
+      const unsigned m = m0 + u;
+      if (m >= M)
+        break;
+      const float sre = cf[2 * u], sim = cf[2 * u + 1];
+      /* ---- FM PLL (FmDecode.cpp:371-413) ---- */
+      float sn, cs;
+      fmd_sincos_nco(nco_phase, &sn, &cs);
+      const float dre = cs * sre - sn * sim; // ComplexType(Cos, Sin) * signal[i]
+      const float dim = cs * sim + sn * sre;
+      const float err = -fmd_atan2f(dim, dre);
+      nco_incr += k.pll_beta * err;
+      if (nco_incr < k.nco_ll)
+        nco_incr = k.nco_ll;
+      if (nco_incr > k.nco_hl)
+        nco_incr = k.nco_hl;
+      nco_phase += nco_incr + k.pll_alpha * err;
+      if ((double)nco_phase >= FMD_K_2PI)
+        nco_phase = (float)fmod((double)nco_phase, FMD_K_2PI);
+      while (nco_phase < 0)
+        nco_phase = (float)((double)nco_phase + FMD_K_2PI);
+      const float pinc = 2 * nco_incr;
+      dc = (float)((1 - 0.0001) * (double)dc + 0.0001 * (double)pinc);
+      const float v = (pinc - dc) * k.demod_gain;
+      bb[(size_t)(Hbb + m) * CP + c] = v;
+      vsum += v;
+      vsumsq += v * v;
+
+      /* ---- pilot PLL (FmDecode.cpp:151-217) ---- */
+      float ps, pc;
+      fmd_sincos_nco(p_phase, &ps, &pc);
+      const float tone = 2 * ps * pc;
+      float ph_i = ps * v;
+      float ph_q = pc * v;
+      ph_i = k.p_b0 * ph_i - k.p_a1 * p_i1 - k.p_a2 * p_i2;
+      ph_q = k.p_b0 * ph_q - k.p_a1 * p_q1 - k.p_a2 * p_q2;
+      p_i2 = p_i1;
+      p_i1 = ph_i;
+      p_q2 = p_q1;
+      p_q1 = ph_q;
+      float perr;
+      if (ph_i > fabsf(ph_q))
+        perr = ph_q / ph_i;
+      else if (ph_q > 0)
+        perr = 1;
+      else
+        perr = -1;
+      p_level = (ph_i < p_level) ? ph_i : p_level;
+      p_freq += k.p_lf_b0 * perr + k.p_lf_b1 * p_x1;
+      p_x1 = perr;
+      {
+        const float t = (p_freq < k.p_maxfreq) ? p_freq : k.p_maxfreq;
+        p_freq = (k.p_minfreq < t) ? t : k.p_minfreq;
+      }
+      p_phase += p_freq;
+      if ((double)p_phase > FMD_K_2PI)
+        p_phase = (float)((double)p_phase - FMD_K_2PI);
+      raw[(size_t)(Hbb + m) * CP + c] = tone * (2 * v); // FmDecode.cpp:456
+
+      /* ---- RDS oscillator mix (DownConvert.cpp:436-442, :464-465), imag(input) == 0 ---- */
+      float2 osc;
+      osc.x = o_re * k.osc_cos - o_im * k.osc_sin;
+      osc.y = o_im * k.osc_cos + o_re * k.osc_sin;
+      const float gn = (float)(1.95 - (double)(o_re * o_re + o_im * o_im));
+      o_re = gn * osc.x;
+      o_im = gn * osc.y;
+      const float zero = 0.0f;
+      mix[(size_t)(Hmix + m) * CP + c] =
+          make_float2((v * osc.x) - (zero * osc.y), (v * osc.y) + (zero * osc.x));
+    }
+  }
+
+  st.nco_phase[c] = nco_phase;
+  st.nco_incr[c] = nco_incr;
+  st.dc_off[c] = dc;
+  st.p_i1[c] = p_i1;
+  st.p_i2[c] = p_i2;
+  st.p_q1[c] = p_q1;
+  st.p_q2[c] = p_q2;
+  st.p_x1[c] = p_x1;
+  st.p_freq[c] = p_freq;
+  st.p_phase[c] = p_phase;
+  st.p_level[c] = p_level;
+  st.osc_re[c] = o_re;
+  st.osc_im[c] = o_im;
+
+  { // lock status (FmDecode.cpp:219-228)
+    int cnt = st.p_lock_cnt[c];
+    if (2 * p_level > k.p_minsignal)
+    {
+      if (cnt < k.p_lock_delay)
+        cnt += (int)M;
+    }
+    else
+      cnt = 0;
+    st.p_lock_cnt[c] = cnt;
+    st.stereo[c] = cnt >= k.p_lock_delay;
+  }
+  { // baseband stats (FmDecode.cpp:439-442)
+    const float mean = vsum / (float)M;
+    const float rms = sqrtf(vsumsq / (float)M);
+    st.bb_mean[c] = 0.95f * st.bb_mean[c] + 0.05f * mean;
+    st.bb_level[c] = 0.95f * st.bb_level[c] + 0.05f * rms;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* K3: CHalfBandDecimateBy2::DecBy2 (DownConvert.cpp:512-550), time-parallel.  in has L-1       */
+/*     history rows in front; output k reads rows 2k .. 2k+L-1.  Tap 0 is counted twice and     */
+/*     the centre tap added last, like the reference.                                           */
+/* ------------------------------------------------------------------------------------------ */
+struct HbCoef
+{
+  float c[52];
+};
+
+__global__ __launch_bounds__(256) void k_halfband(const float2* __restrict__ in,
+                                                  float2* __restrict__ out, unsigned n_out, int L,
+                                                  HbCoef hc, unsigned C, unsigned CP, unsigned Hout)
+{
+  const unsigned c = blockIdx.x * 64 + threadIdx.x;
+  const unsigned kk = blockIdx.y * blockDim.y + threadIdx.y;
+  if (c >= C || kk >= n_out)
+    return;
+  const float2* __restrict__ p = in + (size_t)(2 * kk) * CP + c;
+  const int mid = (L - 1) / 2;
+  float2 x = p[0];
+  float ar = x.x * hc.c[0];
+  float ai = x.y * hc.c[0];
+  for (int j = 0; j < L; j += 2)
+  {
+    x = p[(size_t)j * CP];
+    ar = ar + x.x * hc.c[j];
+    ai = ai + x.y * hc.c[j];
+  }
+  x = p[(size_t)mid * CP];
+  ar = ar + x.x * hc.c[mid];
+  ai = ai + x.y * hc.c[mid];
+  out[(size_t)(Hout + kk) * CP + c] = make_float2(ar, ai);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* K4: cFirFilter::Process(complex) / ProcessTwo (FirFilter.cpp:330-350, :387-413),            */
+/*     time-parallel.  The reference walks its ring buffer from slot 0, so output i (global     */
+/*     index g = g0 + i since the filter was initialised) sums ages a0, a0+1, ..., T-1, 0, ...  */
+/*     with a0 = g mod T, starting from the first product (no leading zero).  in has T-1        */
+/*     history rows in front (zeros after init).  I and Q taps are the same table.              */
+/* ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_ring_fir(const float2* __restrict__ in,
+                                                  float2* __restrict__ out, unsigned n, int T,
+                                                  const float* __restrict__ taps, unsigned g0,
+                                                  unsigned C, unsigned CP, unsigned Hout)
+{
+  const unsigned c = blockIdx.x * 64 + threadIdx.x;
+  const unsigned i = blockIdx.y * blockDim.y + threadIdx.y;
+  if (c >= C || i >= n)
+    return;
+  // row of x[i - a] is (T-1 + i - a)
+  const float2* __restrict__ p = in + (size_t)(T - 1 + i) * CP + c;
+  int a = (int)((g0 + i) % (unsigned)T);
+  float2 x = p[-(ptrdiff_t)a * CP];
+  float ar = taps[a] * x.x;
+  float ai = taps[a] * x.y;
+  for (int s = 1; s < T; s++)
+  {
+    a = (a + 1 == T) ? 0 : a + 1;
+    x = p[-(ptrdiff_t)a * CP];
+    ar += taps[a] * x.x;
+    ai += taps[a] * x.y;
+  }
+  out[(size_t)(Hout + i) * CP + c] = make_float2(ar, ai);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* K5: RDS recurrences at the RDS rate, one lane per channel: ProcessRdsPll                      */
+/*     (RDSProcess.cpp:222-270), matched filter cFirFilter::Process(real) with its ring buffer   */
+/*     kept per lane in HBM-backed state (FirFilter.cpp:360-377), squaring + bit-sync resonator  */
+/*     (RDSProcess.cpp:137-142, IirFilter.cpp:78-87), peak slicer (:144-179), ProcessNewRdsBit   */
+/*     (:272-375) and CheckBlock with Meggitt FEC (:377-431).                                    */
+/* ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ uint32_t rds_check_block(uint32_t& in_bits, uint32_t offset, bool fec)
+{
+  const uint32_t parckh[16] = {0x2DC, 0x16E, 0x0B7, 0x287, 0x39F, 0x313, 0x355, 0x376,
+                               0x1BB, 0x201, 0x3DC, 0x1EE, 0x0F7, 0x2A7, 0x38F, 0x31B};
+  uint32_t tb = 0x3FFFFFF & in_bits;
+  uint32_t syn = tb >> 16;
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+  {
+    if (tb & 0x8000)
+      syn ^= parckh[i];
+    tb <<= 1;
+  }
+  syn ^= offset;
+  if (syn && fec)
+  {
+    uint32_t mask = 1u << 25;
+    for (int i = 0; i < 16; i++)
+    {
+      if (syn & 0x200)
+      {
+        if ((syn & 0x1F) == 0)
+        {
+          in_bits ^= mask;
+          syn <<= 1;
+        }
+        else
+        {
+          syn <<= 1;
+          syn ^= 0x5B9;
+        }
+      }
+      else
+        syn <<= 1;
+      mask >>= 1;
+    }
+    syn &= 0x3FF;
+  }
+  return syn;
+}
+
+__global__ __launch_bounds__(64) void k_rds_serial(const float2* __restrict__ lpf, unsigned R,
+                                                   unsigned C, unsigned CP, RdsConsts k,
+                                                   const float* __restrict__ mf_taps2, // doubled
+                                                   int mf_state0, ChannelState st, uint32_t call_index,
+                                                   RdsGroupRec* __restrict__ queue,
+                                                   unsigned* __restrict__ queue_count,
+                                                   unsigned queue_cap, float* __restrict__ tap_pll,
+                                                   float* __restrict__ tap_mf,
+                                                   float* __restrict__ tap_sync)
+{
+  extern __shared__ float ring[]; // [mf_taps][64]
+  const unsigned lane = threadIdx.x;
+  const unsigned c = blockIdx.x * 64 + lane;
+  if (c >= C)
+    return;
+  const int T = k.mf_taps;
+  for (int j = 0; j < T; j++)
+    ring[j * 64 + lane] = st.r_mfring[(size_t)j * CP + c];
+
+  const uint32_t offs[8] = {0x3D8, 0x3D4, 0x25C, 0x258, 0x3D8, 0x3D4, 0x3CC, 0x258};
+  float phase = st.r_phase[c], freq = st.r_freq[c];
+  float w1 = st.r_w1[c], w2 = st.r_w2[c];
+  float last_sync = st.r_last_sync[c], last_slope = st.r_last_slope[c], last_data = st.r_last_data[c];
+  int last_bit = st.r_last_bit[c];
+  uint32_t bits = st.r_bits[c];
+  int block = st.r_block[c], bitpos = st.r_bitpos[c], state = st.r_state[c], boff = st.r_boff[c],
+      errors = st.r_errors[c];
+  uint16_t bd[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    bd[q] = st.r_data[(size_t)q * CP + c];
+  uint32_t seq = st.r_seq[c];
+  int mstate = mf_state0;
+
+  for (unsigned i = 0; i < R; i++)
+  {
+    const float2 in = lpf[(size_t)i * CP + c];
+    /* PLL de-rotation */
+    float sn, cs;
+    fmd_sincos_nco(phase, &sn, &cs);
+    const float tr = cs * in.x - sn * in.y;
+    const float ti = cs * in.y + sn * in.x;
+    const float err = -fmd_rds_arctan2(ti, tr);
+    freq += (k.pll_beta * err);
+    if (freq > k.nco_hl)
+      freq = k.nco_hl;
+    else if (freq < k.nco_ll)
+      freq = k.nco_ll;
+    phase += (freq + k.pll_alpha * err);
+    tap_pll[(size_t)i * CP + c] = ti;
+
+    /* matched filter through the ring (slot order = the reference's summation order) */
+    ring[mstate * 64 + lane] = ti;
+    const float* h = mf_taps2 + (T - mstate);
+    float d = h[0] * ring[lane];
+    for (int j = 1; j < T; ++j)
+      d += h[j] * ring[j * 64 + lane];
+    if (--mstate < 0)
+      mstate += T;
+    tap_mf[(size_t)i * CP + c] = d;
+
+    /* bit-sync resonator on d*d */
+    const float mag = d * d;
+    const float w0 = mag - k.bs_a1 * w1 - k.bs_a2 * w2;
+    const float sv = k.bs_b0 * w0 + k.bs_b1 * w1 + k.bs_b2 * w2;
+    w2 = w1;
+    w1 = w0;
+    tap_sync[(size_t)i * CP + c] = sv;
+
+    /* slicer at the positive peak of the sync sine */
+    const float slope = sv - last_sync;
+    last_sync = sv;
+    if ((slope < 0.0f) && (last_slope * slope) < 0.0f)
+    {
+      const int bit = (last_data >= 0) ? 1 : 0;
+      const int nb = bit ^ last_bit;
+      last_bit = bit;
+      /* ---- ProcessNewRdsBit ---- */
+      bits = (bits << 1) | (uint32_t)nb;
+      bool emit = false;
+      if (state == 0)
+      {
+        if (!rds_check_block(bits, offs[0], false))
+        {
+          bitpos = 0;
+          boff = 0;
+          bd[0] = (uint16_t)(bits >> 10);
+          block = 1;
+          state = 1;
+        }
+      }
+      else if (++bitpos >= 26)
+      {
+        bitpos = 0;
+        if (state == 3)
+        {
+          if (++block > 3)
+          {
+            block = 0;
+            state = 2;
+          }
+        }
+        else
+        {
+          const uint32_t bad = rds_check_block(bits, offs[block + boff], state == 2);
+          if (bad)
+          {
+            if (state == 1)
+              state = 0;
+            else
+            {
+              errors++;
+              if (errors > 0) // BLOCK_ERROR_LIMIT 0
+                state = 0;
+              else
+              {
+                if (++block > 3)
+                  block = 0;
+                if (block != 0)
+                  state = 3;
+              }
+            }
+          }
+          else
+          {
+            const uint16_t word = (uint16_t)(bits >> 10);
+            if (block == 0) bd[0] = word;
+            else if (block == 1) bd[1] = word;
+            else if (block == 2) bd[2] = word;
+            else bd[3] = word;
+            boff = (block == 1 && (word & 0x0800)) ? 4 : 0;
+            if (state == 1)
+            {
+              if (block >= 3)
+              {
+                block = 0;
+                errors = 0;
+                state = 2;
+                emit = true;
+              }
+              else
+                block++;
+            }
+            else
+            {
+              if (++block > 3)
+              {
+                block = 0;
+                errors = 0;
+                emit = true;
+              }
+            }
+          }
+        }
+      }
+      if (emit)
+      {
+        const unsigned slot = atomicAdd(queue_count, 1u);
+        if (slot < queue_cap)
+        {
+          RdsGroupRec r;
+          r.channel = c;
+          r.call_index = call_index;
+          r.seq = seq;
+          r.blocks[0] = bd[0];
+          r.blocks[1] = bd[1];
+          r.blocks[2] = bd[2];
+          r.blocks[3] = bd[3];
+          queue[slot] = r;
+        }
+        seq++;
+      }
+    }
+    last_data = d;
+    last_slope = slope;
+  }
+  phase = fmodf(phase, (float)FMD_K_2PI); // RDSProcess.cpp:269
+
+  for (int j = 0; j < T; j++)
+    st.r_mfring[(size_t)j * CP + c] = ring[j * 64 + lane];
+  st.r_phase[c] = phase;
+  st.r_freq[c] = freq;
+  st.r_w1[c] = w1;
+  st.r_w2[c] = w2;
+  st.r_last_sync[c] = last_sync;
+  st.r_last_slope[c] = last_slope;
+  st.r_last_data[c] = last_data;
+  st.r_last_bit[c] = last_bit;
+  st.r_bits[c] = bits;
+  st.r_block[c] = block;
+  st.r_bitpos[c] = bitpos;
+  st.r_state[c] = state;
+  st.r_boff[c] = boff;
+  st.r_errors[c] = errors;
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    st.r_data[(size_t)q * CP + c] = bd[q];
+  st.r_seq[c] = seq;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* K6/K7: cDownsampleFilter::Process(real), fractional branch (DownConvert.cpp:195-233).       */
+/*     The interpolated tap k_j = coeff[j]*k0 + coeff[j+1]*k1 depends only on the output index  */
+/*     (positions are batch-uniform), so it is tabulated once per call (k_rs_table) and the     */
+/*     filter proper is a plain per-output dot product over the window, in j order.             */
+/* ------------------------------------------------------------------------------------------ */
+__global__ void k_rs_table(const float* __restrict__ coeff, unsigned order, float p, float pstep,
+                           unsigned A, float* __restrict__ ktab, int* __restrict__ pidx)
+{
+  const unsigned i = blockIdx.x;
+  if (i >= A)
+    return;
+  const float pf = p + (float)i * pstep;
+  const int pi = (int)pf;
+  const float k1 = pf - (float)pi;
+  const float k0 = 1 - k1;
+  for (unsigned j = threadIdx.x; j <= order; j += blockDim.x)
+    ktab[(size_t)i * (order + 1) + j] = coeff[j] * k0 + coeff[j + 1] * k1;
+  if (threadIdx.x == 0)
+    pidx[i] = pi;
+}
+
+__global__ __launch_bounds__(256) void k_resample(const float* __restrict__ bb,
+                                                  const float* __restrict__ raw, unsigned Hbb,
+                                                  unsigned order, const float* __restrict__ ktab,
+                                                  const int* __restrict__ pidx, unsigned A,
+                                                  float2* __restrict__ out, unsigned Hout, unsigned C,
+                                                  unsigned CP)
+{
+  const unsigned c = blockIdx.x * 64 + threadIdx.x;
+  const unsigned i = blockIdx.y * blockDim.y + threadIdx.y;
+  if (c >= C || i >= A)
+    return;
+  const int pi = pidx[i];
+  const float* __restrict__ kt = ktab + (size_t)i * (order + 1);
+  const size_t base = (size_t)(Hbb + (unsigned)pi) * CP + c;
+  float ym = 0.0f, ys = 0.0f;
+  for (unsigned j = 0; j <= order; j++)
+  {
+    const float kj = kt[j];
+    ym += kj * bb[base - (size_t)j * CP];
+    ys += kj * raw[base - (size_t)j * CP];
+  }
+  out[(size_t)(Hout + i) * CP + c] = make_float2(ys, ym); // (stereo, mono) = ProcessTwo's (A, B)
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* K8: audio tail, one lane per channel: ProcessDeemphasisFilter (FmDecode.cpp:348-359),        */
+/*     19 kHz notch cIirFilter::ProcessTwo (IirFilter.cpp:89-105), L/R matrix (:473-499).       */
+/* ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp, unsigned A,
+                                                   unsigned C, unsigned CP, AudioConsts k,
+                                                   ChannelState st, float* __restrict__ audio,
+                                                   size_t audio_stride)
+{
+  const unsigned c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C)
+    return;
+  float de_re = st.de_re[c], de_im = st.de_im[c];
+  float w1a = st.n_w1a[c], w2a = st.n_w2a[c], w1b = st.n_w1b[c], w2b = st.n_w2b[c];
+  const int stereo = st.stereo[c];
+  float2* __restrict__ o = reinterpret_cast<float2*>(audio + (size_t)c * audio_stride);
+  for (unsigned i = 0; i < A; ++i)
+  {
+    const float2 v = lp[(size_t)i * CP + c]; // x = stereo, y = mono
+    de_re = (1.0f - k.de_alpha) * de_re + k.de_alpha * v.x;
+    const float s0 = de_re * 2.0f;
+    de_im = (1.0f - k.de_alpha) * de_im + k.de_alpha * v.y;
+    const float m0 = de_im * 2.0f;
+    const float w0a = s0 - k.n_a1 * w1a - k.n_a2 * w2a;
+    const float w0b = m0 - k.n_a1 * w1b - k.n_a2 * w2b;
+    const float s = k.n_b0 * w0a + k.n_b1 * w1a + k.n_b2 * w2a;
+    const float m = k.n_b0 * w0b + k.n_b1 * w1b + k.n_b2 * w2b;
+    w2a = w1a;
+    w1a = w0a;
+    w2b = w1b;
+    w1b = w0b;
+    float2 lr;
+    if (stereo)
+      lr = make_float2((m + s) * 0.5f, (m - s) * 0.5f);
+    else
+    {
+      const float mm = m * 0.5f;
+      lr = make_float2(mm, mm);
+    }
+    o[i] = lr;
+  }
+  st.de_re[c] = de_re;
+  st.de_im[c] = de_im;
+  st.n_w1a[c] = w1a;
+  st.n_w2a[c] = w2a;
+  st.n_w1b[c] = w1b;
+  st.n_w2b[c] = w2b;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* history roll: rows [n, n+H) -> [0, H) of a time-major buffer (element size ES floats)        */
+/* ------------------------------------------------------------------------------------------ */
+template <typename T>
+__global__ void k_roll(T* __restrict__ buf, unsigned H, unsigned n, unsigned CP)
+{
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= CP)
+    return;
+  // ascending order is safe for any n >= 1 (destination row r < source row r + n)
+  for (unsigned r = 0; r < H; r++)
+    buf[(size_t)r * CP + c] = buf[(size_t)(r + n) * CP + c];
+}
+
+} // namespace fmd

@@ -1,0 +1,258 @@
+/*
+ * fmd_math.h -- transcendental helpers for the HIP kernels, written so that their float
+ * results equal what the reference's CPU build produces:
+ *
+ *  - fmd_atan2f(): the reference calls atan2(float,float) -> glibc atan2f
+ *    (FmDecode.cpp:395).  glibc 2.35 (this image; libm is a third-party dependency of the
+ *    reference, not vendored) implements atan2f/atanf with the fdlibm float algorithms
+ *    (sysdeps/ieee754/flt-32/e_atan2f.c, s_atanf.c; Sun Microsystems 1993).  The published
+ *    algorithm is restated here operation for operation in float arithmetic; with
+ *    -ffp-contract=off every IEEE add/mul/div rounds like the host's, so the result is
+ *    bit-identical (tests/test_device_math.py sweeps it against the host libm).
+ *  - fmd_sincos_nco(): the reference uses the x87 fsincos instruction on the float phase
+ *    and stores the 64-bit-mantissa result to float (FmDecode.cpp:167,386,
+ *    RDSProcess.cpp:245).  That is the correctly rounded float sin/cos except for
+ *    double-rounding cases of probability ~2^-40.  Here: evaluate in FP64 (< 1 ulp of
+ *    double), round once to float; disagreement probability ~2^-28 per call.
+ *  - fmd_rds_arctan2(): the reference's own polynomial arctan (RDSProcess.cpp:187-217),
+ *    float with double intermediates.
+ *
+ * Usable from host C++ (for CPU tests of the restatement) and from HIP device code.
+ */
+#ifndef FMD_MATH_H
+#define FMD_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#ifdef __HIPCC__
+#define FMD_HD __host__ __device__ static inline
+#else
+#define FMD_HD static inline
+#endif
+
+#define FMD_K_2PI (2.0 * 3.14159265358979323846)
+#define FMD_K_PI (3.14159265358979323846)
+#define FMD_K_PI2 (FMD_K_PI / 2.0)
+
+FMD_HD uint32_t fmd_f2u(float f)
+{
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
+FMD_HD float fmd_u2f(uint32_t u)
+{
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+/* fdlibm s_atanf.c */
+FMD_HD float fmd_atanf(float x)
+{
+  const float atanhi0 = 4.6364760399e-01f, atanhi1 = 7.8539812565e-01f,
+              atanhi2 = 9.8279368877e-01f, atanhi3 = 1.5707962513e+00f;
+  const float atanlo0 = 5.0121582440e-09f, atanlo1 = 3.7748947079e-08f,
+              atanlo2 = 3.4473217170e-08f, atanlo3 = 7.5497894159e-08f;
+  const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
+              aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
+              aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f,
+              aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+  const float one = 1.0f;
+  float w, s1, s2, z;
+  int32_t hx = (int32_t)fmd_f2u(x);
+  int32_t ix = hx & 0x7fffffff;
+  int id;
+  float hi = 0.0f, lo = 0.0f;
+  if (ix >= 0x4c000000)
+  { /* |x| >= 2^25 */
+    if (ix > 0x7f800000)
+      return x + x; /* NaN */
+    if (hx > 0)
+      return atanhi3 + atanlo3;
+    return -atanhi3 - atanlo3;
+  }
+  if (ix < 0x3ee00000)
+  { /* |x| < 0.4375 */
+    if (ix < 0x31000000)
+      return x; /* |x| < 2^-29 */
+    id = -1;
+  }
+  else
+  {
+    x = fabsf(x);
+    if (ix < 0x3f980000)
+    { /* |x| < 1.1875 */
+      if (ix < 0x3f300000)
+      { /* 7/16 <= |x| < 11/16 */
+        id = 0;
+        x = (2.0f * x - one) / (2.0f + x);
+        hi = atanhi0;
+        lo = atanlo0;
+      }
+      else
+      { /* 11/16 <= |x| < 19/16 */
+        id = 1;
+        x = (x - one) / (x + one);
+        hi = atanhi1;
+        lo = atanlo1;
+      }
+    }
+    else
+    {
+      if (ix < 0x401c0000)
+      { /* |x| < 2.4375 */
+        id = 2;
+        x = (x - 1.5f) / (one + 1.5f * x);
+        hi = atanhi2;
+        lo = atanlo2;
+      }
+      else
+      { /* 2.4375 <= |x| < 2^25 */
+        id = 3;
+        x = -1.0f / x;
+        hi = atanhi3;
+        lo = atanlo3;
+      }
+    }
+  }
+  z = x * x;
+  w = z * z;
+  s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+  s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+  if (id < 0)
+    return x - x * (s1 + s2);
+  z = hi - ((x * (s1 + s2) - lo) - x);
+  return (hx < 0) ? -z : z;
+}
+
+/* fdlibm e_atan2f.c */
+FMD_HD float fmd_atan2f(float y, float x)
+{
+  const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f,
+              pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  float z;
+  int32_t hx = (int32_t)fmd_f2u(x), hy = (int32_t)fmd_f2u(y);
+  int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+  if ((ix > 0x7f800000) || (iy > 0x7f800000))
+    return x + y; /* NaN */
+  if (hx == 0x3f800000)
+    return fmd_atanf(y); /* x = 1.0 */
+  int m = ((hy >> 31) & 1) | ((hx >> 30) & 2); /* 2*sign(x) + sign(y) */
+  if (iy == 0)
+  {
+    switch (m)
+    {
+      case 0:
+      case 1:
+        return y;
+      case 2:
+        return pi + tiny;
+      default:
+        return -pi - tiny;
+    }
+  }
+  if (ix == 0)
+    return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  if (ix == 0x7f800000)
+  {
+    if (iy == 0x7f800000)
+    {
+      switch (m)
+      {
+        case 0:
+          return pi_o_4 + tiny;
+        case 1:
+          return -pi_o_4 - tiny;
+        case 2:
+          return 3.0f * pi_o_4 + tiny;
+        default:
+          return -3.0f * pi_o_4 - tiny;
+      }
+    }
+    else
+    {
+      switch (m)
+      {
+        case 0:
+          return 0.0f;
+        case 1:
+          return -0.0f;
+        case 2:
+          return pi + tiny;
+        default:
+          return -pi - tiny;
+      }
+    }
+  }
+  if (iy == 0x7f800000)
+    return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  int32_t k = (iy - ix) >> 23;
+  if (k > 60)
+    z = pi_o_2 + 0.5f * pi_lo; /* |y/x| > 2^60 */
+  else if (hx < 0 && k < -60)
+    z = 0.0f; /* |y|/x < -2^60 */
+  else
+    z = fmd_atanf(fabsf(y / x));
+  switch (m)
+  {
+    case 0:
+      return z;
+    case 1:
+      return fmd_u2f(fmd_f2u(z) ^ 0x80000000u);
+    case 2:
+      return pi - (z - pi_lo);
+    default:
+      return (z - pi_lo) - pi;
+  }
+}
+
+/* sin/cos of a float phase evaluated in double and rounded once to float */
+FMD_HD void fmd_sincos_nco(float phase, float* s, float* c)
+{
+  double sd, cd;
+#ifdef __HIP_DEVICE_COMPILE__
+  sincos((double)phase, &sd, &cd);
+#else
+  sd = sin((double)phase);
+  cd = cos((double)phase);
+#endif
+  *s = (float)sd;
+  *c = (float)cd;
+}
+
+/* RDSProcess.cpp:187-217 */
+FMD_HD float fmd_rds_arctan2(float y, float x)
+{
+  if (x == 0.0f)
+  {
+    if (y > 0.0f)
+      return (float)FMD_K_PI2;
+    if (y == 0.0f)
+      return 0.0f;
+    return (float)-FMD_K_PI2;
+  }
+  float angle;
+  float z = y / x;
+  if (fabsf(z) < 1.0f)
+  {
+    angle = (float)((double)z / (1.0 + 0.2854 * (double)z * (double)z));
+    if (x < 0.0f)
+    {
+      if (y < 0.0f)
+        return (float)((double)angle - FMD_K_PI);
+      return (float)((double)angle + FMD_K_PI);
+    }
+  }
+  else
+  {
+    angle = (float)(FMD_K_PI2 - (double)z / ((double)(z * z) + 0.2854));
+    if (y < 0.0f)
+      return (float)((double)angle - FMD_K_PI);
+  }
+  return angle;
+}
+
+#endif

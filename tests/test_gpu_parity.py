@@ -1,0 +1,189 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, stage by stage and
+end to end, on the same seeded synthetic IQ.
+
+Bars (BASELINE.json north_star): float audio within 1e-5 RMS of the CPU path, RDS group
+bits bit-exact.  The kernels are written to be bit-faithful, so the stage taps are compared
+for exact equality first and the RMS gate is reported as the contract.
+"""
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+
+AUDIO_RMS_TOL = 1e-5  # BASELINE.json: "float audio within 1e-5 RMS"
+N = 65536
+
+
+def _rms(a, b):
+    a = np.asarray(a, dtype=np.complex128 if np.iscomplexobj(a) else np.float64)
+    b = np.asarray(b, dtype=a.dtype)
+    return float(np.sqrt(np.mean(np.abs(a - b) ** 2))) if a.size else 0.0
+
+
+def _bits_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+def test_design_matches_oracle(pkg, oracle):
+    """Host-side constants/taps of the product equal the oracle's restatement bit for bit."""
+    for fs, D in ((2.4e6, 11), (1.0e6, 4), (10e6, 46)):
+        b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 1)
+        o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+        assert _bits_equal(b.design("if_taps"), o.if_taps())
+        assert _bits_equal(b.design("audio_lpf"), o.audio_taps())
+        assert _bits_equal(b.design("rds_lpf"), o.rds_lpf_taps())
+        assert _bits_equal(b.design("rds_mf"), o.rds_mf_taps())
+        assert _bits_equal(b.design("lut0"), o.lut().view(np.float32))
+        sc, oc = b.scalars(), o.constants()
+        for k, v in oc.items():
+            assert np.float32(sc[k]) == np.float32(v), (fs, k, sc[k], v)
+        b.close()
+
+
+STAGES = ["demod", "baseband", "pilot38", "mono_rs", "stereo_rs", "rds_lpf", "rds_pll", "rds_mf",
+          "rds_sync"]
+
+
+@pytest.mark.parametrize("fs,D,nblk", [(2.4e6, 11, 20), (1.0e6, 4, 10)])
+def test_stage_taps_bit_exact(pkg, oracle, fmsig, fs, D, nblk):
+    """Every stage output of every block equals the oracle's, bit for bit (noisy stereo+RDS)."""
+    p = fmsig.default_params(fs, noise_sigma=0.01)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 1)
+    for blk in range(nblk):
+        iq = fmsig.generate_f32(p, blk * N, N)
+        a_ref = o.process_stream(iq)
+        a_gpu = b.process_host(iq.view(np.complex64), shared=True)[0]
+        taps = o.taps()
+        for name in STAGES:
+            g = b.tap(name)
+            r = taps[name]
+            assert g.shape == r.shape, (blk, name, g.shape, r.shape)
+            assert _bits_equal(g.view(np.float32), r.view(np.float32)), \
+                "block %d stage %s: rms diff %g" % (blk, name, _rms(g, r))
+        assert a_gpu.shape == a_ref.shape
+        assert _rms(a_gpu, a_ref) <= AUDIO_RMS_TOL
+        assert _bits_equal(a_gpu, a_ref), "block %d audio: rms diff %g" % (blk, _rms(a_gpu, a_ref))
+        so, sg = o.status(), b.status()
+        assert sg.stereo_detected == so.stereo
+        for f_o, f_g in ((so.if_level, sg.interface_level), (so.baseband_level, sg.baseband_level),
+                         (so.pilot_level, sg.pilot_level), (so.tuning_offset, sg.tuning_offset)):
+            assert np.float32(f_o) == np.float32(f_g)
+    b.close()
+
+
+def test_config2_stereo_rds_six_seconds(pkg, oracle, fmsig):
+    """BASELINE config 2: 1 stereo channel + RDS, 2.4 MS/s, >= 6 s through the cFmDecoder
+    surface: audio <= 1e-5 RMS on every block, every RDS group identical and in the same
+    call, UECP frames identical, PS name delivered."""
+    fs, D = 2.4e6, 11
+    p = fmsig.default_params(fs, noise_sigma=0.005)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    d = pkg.FmDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    nblk = int(6.0 * fs / N) + 1
+    worst = 0.0
+    for blk in range(nblk):
+        iq = fmsig.generate_f32(p, blk * N, N)
+        a_ref = o.process_stream(iq)
+        a_gpu = d.ProcessStream(iq.view(np.complex64))
+        assert a_gpu.shape == a_ref.shape
+        worst = max(worst, _rms(a_gpu, a_ref))
+    assert worst <= AUDIO_RMS_TOL
+    assert d.StereoDetected() and o.status().stereo == 1
+    assert d.sink.frames.get(0, []) == o.uecp_frames()
+    assert d.sink.names.get(0) == o.channel_name() == "TESTFM01"
+    assert len(o.rds_groups()) > 50
+
+
+def test_rds_groups_bit_exact_and_call_aligned(pkg, oracle, fmsig):
+    fs, D = 2.4e6, 11
+    p = fmsig.default_params(fs, noise_sigma=0.02, pi=0xC0DE, ps="GPU RDS ")
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 1)
+    got = []
+    for blk in range(80):
+        iq = fmsig.generate_f32(p, blk * N, N)
+        o.process_stream(iq)
+        b.process_host(iq.view(np.complex64), shared=True)
+    # process_host already drained the queue through the group decoder; compare its frames
+    assert b.sink.frames.get(0, []) == o.uecp_frames()
+    # raw group path: run again from a fresh pair and collect groups explicitly
+    o2 = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    b2 = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 1)
+    import torch
+    a_dev = torch.zeros(b2.max_audio_floats(N), dtype=torch.float32, device="cuda")
+    for blk in range(80):
+        iq = fmsig.generate_f32(p, blk * N, N)
+        o2.process_stream(iq)
+        x = torch.from_numpy(iq).cuda()
+        b2.process_device(x.data_ptr(), 0, N, a_dev.data_ptr(), a_dev.numel(),
+                          torch.cuda.current_stream().cuda_stream)
+        got += [(ci, blocks) for _ch, ci, blocks in
+                b2.collect_rds(stream=torch.cuda.current_stream().cuda_stream)]
+    assert got == o2.rds_groups()
+    assert len(got) > 10
+
+
+def test_batch_channels_independent(pkg, oracle, fmsig):
+    """Several different stations in one batch: each channel equals its own oracle run."""
+    fs, D = 2.4e6, 11
+    C = 5
+    ps = [fmsig.default_params(fs, noise_sigma=0.01, seed=100 + c, f_left=400.0 + 150 * c,
+                               f_right=3000.0 - 170 * c, pi=0x1000 + c, ps="CHAN%04d" % c)
+          for c in range(C)]
+    os_ = [oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for _ in range(C)]
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C)
+    for blk in range(12):
+        iq = np.stack([fmsig.generate_f32(ps[c], blk * N, N) for c in range(C)])
+        a = b.process_host(iq.view(np.complex64).reshape(C, N))
+        for c in range(C):
+            r = os_[c].process_stream(iq[c])
+            assert _bits_equal(a[c], r), (blk, c, _rms(a[c], r))
+    for c in range(C):
+        assert b.sink.frames.get(c, []) == os_[c].uecp_frames()
+
+
+def test_mono_station_config1_geometry(pkg, oracle, fmsig):
+    """config-1 input (mono, noise 0.01) on the GPU path: stays mono, L == R, equals the oracle."""
+    fs, D = 2.4e6, 11
+    p = fmsig.mono_params(fs, noise_sigma=0.01)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    d = pkg.FmDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    for blk in range(24):
+        iq = fmsig.generate_f32(p, blk * N, N)
+        r = o.process_stream(iq)
+        a = d.ProcessStream(iq.view(np.complex64))
+        assert _bits_equal(a, r)
+    assert not d.StereoDetected()
+    assert np.array_equal(a[0::2], a[1::2])
+
+
+def test_ragged_block_sizes_and_reset(pkg, oracle, fmsig):
+    """Block sizes other than 65536 (within the supported range) and Reset() mid-stream."""
+    fs, D = 2.4e6, 11
+    p = fmsig.default_params(fs, noise_sigma=0.01)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    d = pkg.FmDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    sizes = [65536, 8192, 10007, 65535, 32768, 12345, 65536, 9000, 65536, 65536]
+    pos = 0
+    for i, n in enumerate(sizes):
+        if i == 6:
+            o.reset()
+            d.Reset()
+        iq = fmsig.generate_f32(p, pos, n)
+        pos += n
+        r = o.process_stream(iq)
+        a = d.ProcessStream(iq.view(np.complex64))
+        assert a.shape == r.shape, (i, n)
+        assert _bits_equal(a, r), (i, n, _rms(a, r))
+    with pytest.raises(pkg.FmdError):
+        d.ProcessStream(np.zeros(100, np.complex64))  # below FMD_MIN_BLOCK: rejected loudly
