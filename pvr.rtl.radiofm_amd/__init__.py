@@ -95,6 +95,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libfmd_hip.so is not built (run __graft_entry__.build()); "
                                "this package has no CPU fallback")
+        # torch bundles its own libamdhip64 (same soname as /opt/rocm's).  Importing torch first
+        # makes the loader bind this library to that already-loaded runtime, so device pointers,
+        # streams and RCCL from torch and the kernels here share ONE HIP runtime per process.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         vp, u, i = C.c_void_p, C.c_uint, C.c_int
         L.fmd_last_error.restype = C.c_char_p
