@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- IQ MS/s demodulated by the MI355X FM decoder, whole job, with the FIR-stage roofline.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[3], per-GPU shard): 8192 independent synthetic FM stereo+RDS
+channels per GPU at 2.4 MS/s (65 536 over 8 GPUs), one step = one ProcessStream call of 65 536
+IQ samples on every channel: tuner mix -> 88-tap decimating FIR -> FM PLL -> pilot PLL / stereo ->
+RDS chain -> resamplers -> audio filters -> float stereo audio + RDS groups.  Inputs are generated
+on the device and are resident in HBM before the timed region.  With N > 1 every rank owns its
+own channels (no exchange during compute) and rank 0 gathers float audio and RDS groups of
+every step over RCCL.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FS = 2.4e6
+D = 11
+N = 65536
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(seconds=12.0):
+    """The CPU oracle (a port of the reference path, see oracle/fmd_oracle.h) timed on this
+    host: 1 thread, 1 stereo+RDS channel at 2.4 MS/s, 32 distinct blocks replayed in a loop."""
+    from oracle import oracle_py
+    from tools import fmsig_py
+    p = fmsig_py.default_params(FS, noise_sigma=0.01)
+    blocks = [fmsig_py.generate_f32(p, b * N, N) for b in range(32)]
+    dec = oracle_py.OracleDecoder(FS, -0.15 * FS, 48000.0, 15000.0, D)
+    for b in blocks[:4]:
+        dec.process_stream(b)
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        for b in blocks:
+            dec.process_stream(b)
+            n += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n * N / dt / 1e6, 3), "unit": "MS/s", "cores": 1, "kind": "port",
+            "sample": "%d ProcessStream calls of 65536 IQ (32 distinct blocks of one stereo+RDS "
+                      "channel at 2.4 MS/s, replayed), 1 thread, %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--channels", type=int, default=8192, help="channels per GPU")
+    ap.add_argument("--ring", type=int, default=10, help="distinct input blocks resident in HBM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-profile", action="store_true",
+                    help="after the timed region, run 3 extra steps with per-stage events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    from tools import fmsig_py
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)"
+                         % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    pkg = load_package()
+    C = args.channels
+    K, W = args.steps, args.warmup
+    ring = max(1, min(args.ring, K + W))
+
+    # ---- inputs: ring of blocks, [ring][C][N] complex64, generated on the device ----
+    chans = [fmsig_py.channel_params(FS, rank * C + c) for c in range(C)]
+    gen = fmsig_py.DeviceGenerator(chans, dev)
+    iq = torch.empty((ring, C, N, 2), dtype=torch.float32, device=dev)
+    for r in range(ring):
+        gen.generate(iq[r], r * N, N)
+    torch.cuda.synchronize()
+
+    batch = pkg.Batch(pkg.make_params(FS, -0.15 * FS, 48000.0, 15000.0, D), C, device=local_rank,
+                      record_callbacks=False)
+    a_stride = (batch.max_audio_floats(N) + 63) // 64 * 64
+    audio = [torch.zeros((C, a_stride), dtype=torch.float32, device=dev) for _ in range(2)]
+    RCAP = C  # RDS records gathered per rank per step (<= 1 group per channel per 27 ms step)
+    rds_dev = [torch.zeros((RCAP, 4), dtype=torch.int32, device=dev) for _ in range(2)]
+    if world > 1 and rank == 0:
+        g_audio = [[torch.empty_like(audio[0]) for _ in range(world)] for _ in range(2)]
+        g_rds = [[torch.empty_like(rds_dev[0]) for _ in range(world)] for _ in range(2)]
+    stream = torch.cuda.current_stream().cuda_stream
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    pending = [None, None]
+    total_groups = 0
+
+    def step(i):
+        nonlocal total_groups
+        slot = i & 1
+        if pending[slot] is not None:  # gather that still reads this slot's buffers
+            for w in pending[slot]:
+                w.wait()
+            pending[slot] = None
+        nf = batch.process_device(iq[i % ring].data_ptr(), N, N, audio[slot].data_ptr(), a_stride,
+                                  stream)
+        groups = batch.collect_rds(cap=RCAP, stream=stream)  # small D2H, syncs this stream
+        total_groups += len(groups)
+        if world > 1:
+            rec = np.zeros((RCAP, 4), dtype=np.int32)
+            for j, (ch, ci, blk) in enumerate(groups):
+                rec[j] = (ch + 1, ci, blk[0] | (blk[1] << 16), blk[2] | (blk[3] << 16))
+            rds_dev[slot].copy_(torch.from_numpy(rec), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev)
+                w1 = dist.gather(audio[slot], g_audio[slot] if rank == 0 else None, dst=0,
+                                 async_op=True)
+                w2 = dist.gather(rds_dev[slot], g_rds[slot] if rank == 0 else None, dst=0,
+                                 async_op=True)
+            pending[slot] = [w1, w2]
+        return nf
+
+    def drain():
+        for slot in (0, 1):
+            if pending[slot] is not None:
+                for w in pending[slot]:
+                    w.wait()
+                pending[slot] = None
+        torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(W):
+        step(i)
+    drain()
+    batch.set_profiling(1)  # HIP events around the IF FIR kernel of every timed call
+    total_groups = 0
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        nf = step(i)
+    drain()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tg = torch.tensor([total_groups], dtype=torch.int64, device=dev)
+        dist.all_reduce(tg)
+        total_groups = int(tg.item())
+    stage, calls = batch.stage_ms()
+    fir_ms = stage["if_fir"]
+
+    stage_all = None
+    if args.stage_profile:
+        batch.set_profiling(2)
+        for i in range(W + K, W + K + 3):
+            step(i)
+        drain()
+        stage_all, _ = batch.stage_ms()
+    batch.set_profiling(0)
+
+    if rank == 0:
+        samples_per_step = C * N
+        value = world * samples_per_step * K / dt / 1e6
+        # algorithmic bytes of the fused tuner+FIR kernel: read 8 B per IQ sample, write 8/D B
+        # (SURVEY.md 8(d)); one launch processes C*N samples.
+        bytes_per_launch = samples_per_step * (8.0 + 8.0 / D)
+        achieved = bytes_per_launch / (fir_ms * 1e-3) / 1e9
+        out = {
+            "metric": "IQ MS/s demodulated (whole node) + achieved HBM GB/s on FIR stage",
+            "value": round(value, 1), "unit": "MS/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3] per-GPU shard: %d independent FM "
+                                   "stereo+RDS channels/GPU @2.4 MS/s, 65536 IQ/channel/step, "
+                                   "D=11, 88-tap IF FIR, full ProcessStream path" % C,
+                       "channels_per_gpu": C, "samples_per_call": N, "input_ring_blocks": ring,
+                       "audio_floats_per_channel_step": nf, "rds_groups_in_timed_region": total_groups,
+                       "gather": "rank-0 RCCL gather of audio+RDS per step" if world > 1 else "none (1 GPU)"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "k_if_fir (cFineTuner + cDownsampleFilter complex)",
+                         "avg_ms": round(fir_ms, 4), "launches_averaged": calls,
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch)},
+        }
+        if stage_all:
+            out["stage_ms"] = {k: round(v, 4) for k, v in stage_all.items()}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -167,9 +167,13 @@ enum fmd_design_item
   FMD_DESIGN_LUT0 = 6     /* channel 0 cFineTuner table, interleaved */
 };
 
-/* Device time (ms) the kernels of the last fmd_batch_process_device call took, per stage,
- * measured with HIP events on the call's stream when profiling is enabled. */
-int fmd_batch_set_profiling(fmd_batch* b, int enable);
+/* Device time per stage, measured with HIP events recorded on the call's own stream.
+ * level 0 = off, 1 = events around the IF FIR kernel only, 2 = around every stage.  Each call
+ * made while profiling is on gets its own event set (no synchronisation inside the calls);
+ * fmd_batch_get_stage_ms synchronises the device, writes the AVERAGE ms per stage over those
+ * calls (-1 for stages not covered at level 1; index = fmd_stage_name index) and returns the
+ * number of calls averaged.  set_profiling restarts the averaging window. */
+int fmd_batch_set_profiling(fmd_batch* b, int level);
 int fmd_batch_get_stage_ms(fmd_batch* b, float* out, unsigned cap);
 const char* fmd_stage_name(unsigned idx);
 

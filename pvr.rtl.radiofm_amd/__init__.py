@@ -256,13 +256,22 @@ class Batch:
     def scalars(self):
         return dict(zip(SCALAR_NAMES, self.design("scalars")))
 
-    def set_profiling(self, on=True):
-        _check(lib().fmd_batch_set_profiling(self._h, int(on)))
+    def set_profiling(self, level=2):
+        _check(lib().fmd_batch_set_profiling(self._h, int(level)))
 
     def stage_ms(self):
-        buf = np.zeros(32, dtype=np.float32)
-        n = _check(lib().fmd_batch_get_stage_ms(self._h, buf.ctypes.data, buf.size))
-        return {lib().fmd_stage_name(i).decode(): float(buf[i]) for i in range(n)}
+        """(average ms per stage, number of calls averaged); stages not covered read -1."""
+        buf = np.full(32, -1.0, dtype=np.float32)
+        calls = _check(lib().fmd_batch_get_stage_ms(self._h, buf.ctypes.data, buf.size))
+        out = {}
+        i = 0
+        while True:
+            name = lib().fmd_stage_name(i).decode()
+            if not name:
+                break
+            out[name] = float(buf[i])
+            i += 1
+        return out, calls
 
 
 class FmDecoder:

@@ -124,10 +124,11 @@ struct fmd_batch
 
   std::vector<std::unique_ptr<fmd::GroupDecoder>> gdec;
 
-  bool profiling = false;
-  hipEvent_t ev[ST_COUNT + 1] = {};
-  bool ev_valid = false;
-  float stage_ms[ST_COUNT] = {};
+  // profiling: 0 off, 1 = events around the IF FIR kernel only, 2 = around every stage.
+  // One event set per call (up to kMaxProfCalls) so nothing has to synchronise inside a timed loop.
+  int profiling = 0;
+  std::vector<hipEvent_t> ev; // [calls][ST_COUNT + 1]
+  unsigned prof_calls = 0;
 
   ~fmd_batch()
   {
@@ -163,17 +164,15 @@ struct fmd_batch
     queue_count.release();
     h_iq.release();
     h_audio.release();
-    if (ev_valid)
-      for (auto& e : ev)
-        (void)hipEventDestroy(e);
+    for (auto& e : ev)
+      (void)hipEventDestroy(e);
   }
 };
 
 namespace
 {
 
-constexpr int kNumFloatState = 28;
-constexpr int kNumIntState = 9;
+constexpr unsigned kMaxProfCalls = 512;
 
 int upload(void* dst, const void* src, size_t bytes)
 {
@@ -182,56 +181,11 @@ int upload(void* dst, const void* src, size_t bytes)
 
 void bind_state(fmd_batch* b)
 {
-  float* f = b->fstate.p;
-  const size_t CP = b->CP;
-  int k = 0;
-  auto nf = [&]() { return f + CP * size_t(k++); };
-  fmd::ChannelState& s = b->st;
-  s.nco_phase = nf();
-  s.nco_incr = nf();
-  s.dc_off = nf();
-  s.if_level = nf();
-  s.bb_mean = nf();
-  s.bb_level = nf();
-  s.p_i1 = nf();
-  s.p_i2 = nf();
-  s.p_q1 = nf();
-  s.p_q2 = nf();
-  s.p_x1 = nf();
-  s.p_freq = nf();
-  s.p_phase = nf();
-  s.p_level = nf();
-  s.osc_re = nf();
-  s.osc_im = nf();
-  s.r_phase = nf();
-  s.r_freq = nf();
-  s.r_w1 = nf();
-  s.r_w2 = nf();
-  s.r_last_sync = nf();
-  s.r_last_slope = nf();
-  s.r_last_data = nf();
-  s.de_re = nf();
-  s.de_im = nf();
-  s.n_w1a = nf();
-  s.n_w2a = nf();
-  s.n_w1b = nf();
-  // n_w2b shares the tail slot
-  s.n_w2b = f + CP * size_t(kNumFloatState);
-  int* i = b->istate.p;
-  int q = 0;
-  auto ni = [&]() { return i + CP * size_t(q++); };
-  s.p_lock_cnt = ni();
-  s.stereo = ni();
-  s.r_last_bit = ni();
-  s.r_bits = reinterpret_cast<uint32_t*>(ni());
-  s.r_block = ni();
-  s.r_bitpos = ni();
-  s.r_state = ni();
-  s.r_boff = ni();
-  s.r_errors = ni();
-  s.r_seq = reinterpret_cast<uint32_t*>(i + CP * size_t(kNumIntState));
-  s.r_data = b->r_data.p;
-  s.r_mfring = b->mfring.p;
+  b->st.f = b->fstate.p;
+  b->st.i = b->istate.p;
+  b->st.r_data = b->r_data.p;
+  b->st.r_mfring = b->mfring.p;
+  b->st.CP = b->CP;
 }
 
 /* state a freshly constructed cFmDecoder has (ctor values that are not zero) */
@@ -240,10 +194,10 @@ int init_signal_state(fmd_batch* b)
   const size_t CP = b->CP;
   std::vector<float> v(CP);
   std::fill(v.begin(), v.end(), b->des.p_freq0); // cPilotPhaseLock: m_freq = freq*2pi (:131)
-  if (upload(b->st.p_freq, v.data(), CP * sizeof(float)))
+  if (upload(b->st.F(fmd::F_P_FREQ), v.data(), CP * sizeof(float)))
     return -1;
   std::fill(v.begin(), v.end(), 1.0f); // CRDSDownConvert: m_Osc1 = (1, 0) (DownConvert.cpp:284)
-  if (upload(b->st.osc_re, v.data(), CP * sizeof(float)))
+  if (upload(b->st.F(fmd::F_OSC_RE), v.data(), CP * sizeof(float)))
     return -1;
   return 0;
 }
@@ -261,16 +215,16 @@ int zero_rows(T* p, size_t rows, size_t CP)
 int do_reset(fmd_batch* b)
 {
   const size_t CP = b->CP;
-  fmd::ChannelState& s = b->st;
-  float* fz[] = {s.if_level, s.bb_mean,     s.bb_level,     s.dc_off,      s.nco_incr, s.nco_phase,
-                 s.r_phase,  s.r_freq,      s.r_w1,         s.r_w2,        s.r_last_sync,
-                 s.r_last_slope, s.r_last_data};
-  for (float* p : fz)
-    if (hipMemset(p, 0, CP * sizeof(float)) != hipSuccess)
+  using namespace fmd;
+  const ChannelState& s = b->st;
+  const int fz[] = {F_IF_LEVEL, F_BB_MEAN, F_BB_LEVEL, F_DC_OFF, F_NCO_INCR, F_NCO_PHASE, F_R_PHASE,
+                    F_R_FREQ, F_R_W1, F_R_W2, F_R_LAST_SYNC, F_R_LAST_SLOPE, F_R_LAST_DATA};
+  for (int slot : fz)
+    if (hipMemset(s.F(slot), 0, CP * sizeof(float)) != hipSuccess)
       return -1;
-  int* iz[] = {s.stereo, s.r_last_bit, s.r_bitpos, s.r_block, s.r_state, s.r_boff};
-  for (int* p : iz)
-    if (hipMemset(p, 0, CP * sizeof(int)) != hipSuccess)
+  const int iz[] = {I_STEREO, I_R_LAST_BIT, I_R_BITPOS, I_R_BLOCK, I_R_STATE, I_R_BOFF};
+  for (int slot : iz)
+    if (hipMemset(s.I(slot), 0, CP * sizeof(int)) != hipSuccess)
       return -1;
   // RDS LPF ring (history rows of rdsraw), matched filter ring, positions
   if (zero_rows(b->rdsraw.p, b->des.rds_lpf_taps.size() - 1, CP))
@@ -409,8 +363,8 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->audio_taps.alloc(T_alp);
   bad |= b->ktab.alloc(size_t(b->Amax) * (d.rs_order + 1));
   bad |= b->pidx.alloc(b->Amax);
-  bad |= b->fstate.alloc(size_t(kNumFloatState + 1) * CP);
-  bad |= b->istate.alloc(size_t(kNumIntState + 1) * CP);
+  bad |= b->fstate.alloc(size_t(fmd::F_SLOTS) * CP);
+  bad |= b->istate.alloc(size_t(fmd::I_SLOTS) * CP);
   bad |= b->r_data.alloc(size_t(4) * CP);
   bad |= b->mfring.alloc(size_t(T_mf) * CP);
   b->queue_cap = std::max(4096u, 8u * C);
@@ -533,15 +487,22 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
   const unsigned Hbb = d.rs_order;
   b->call_index++;
 
-  if (b->profiling && !b->ev_valid)
+  hipEvent_t* evset = nullptr;
+  if (b->profiling && b->prof_calls < kMaxProfCalls)
   {
-    for (auto& e : b->ev)
+    const size_t need = size_t(b->prof_calls + 1) * (ST_COUNT + 1);
+    while (b->ev.size() < need)
+    {
+      hipEvent_t e;
       HIPCHK(hipEventCreate(&e));
-    b->ev_valid = true;
+      b->ev.push_back(e);
+    }
+    evset = &b->ev[size_t(b->prof_calls) * (ST_COUNT + 1)];
+    b->prof_calls++;
   }
   auto mark = [&](int i) {
-    if (b->profiling)
-      (void)hipEventRecord(b->ev[i], stream);
+    if (evset && (b->profiling >= 2 || i <= 1))
+      (void)hipEventRecord(evset[i], stream);
   };
   mark(0);
 
@@ -549,17 +510,15 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
   {
     constexpr int TILE = 256;
     const unsigned ntiles = (M + TILE - 1) / TILE;
-    const size_t lds = (size_t(TILE - 1) * D + d.if_order) * sizeof(float2);
+    const size_t lds = (size_t(TILE - 1) * D + d.if_order + 4) * sizeof(float2);
     if (lds > 160 * 1024)
       return fail(FMD_ERR_ARG, "IF filter window does not fit in LDS");
-    static bool attr_set = false;
-    if (!attr_set)
-    {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fmd::k_if_fir<TILE>),
+    const bool pow2 = (d.table_size & (d.table_size - 1)) == 0 && d.table_size <= 2 * TILE;
+    auto kfn = pow2 ? &fmd::k_if_fir<TILE, 4, true> : &fmd::k_if_fir<TILE, 4, false>;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(fmd::k_if_fir<TILE>, dim3(C, ntiles), dim3(TILE), lds, stream,
+    hipLaunchKernelGGL(kfn, dim3(C, ntiles), dim3(TILE), lds, stream,
                        reinterpret_cast<const float2*>(d_iq), iq_channel_stride, N,
                        b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, d.table_size,
                        b->lut_idx, b->if_coeff.p, d.if_order, D, pos, M, b->demod.p, b->Mstride);
@@ -794,12 +753,12 @@ int fmd_batch_get_status(fmd_batch* b, unsigned channel, fmd_status* stt)
   HIPCHK(hipDeviceSynchronize());
   float if_level = 0, bb_mean = 0, bb_level = 0, p_level = 0;
   int stereo = 0, rstate = 0;
-  HIPCHK(hipMemcpy(&if_level, b->st.if_level + channel, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&bb_mean, b->st.bb_mean + channel, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&bb_level, b->st.bb_level + channel, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&p_level, b->st.p_level + channel, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&stereo, b->st.stereo + channel, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&rstate, b->st.r_state + channel, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&if_level, b->st.F(fmd::F_IF_LEVEL) + channel, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&bb_mean, b->st.F(fmd::F_BB_MEAN) + channel, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&bb_level, b->st.F(fmd::F_BB_LEVEL) + channel, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&p_level, b->st.F(fmd::F_P_LEVEL) + channel, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&stereo, b->st.I(fmd::I_STEREO) + channel, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&rstate, b->st.I(fmd::I_R_STATE) + channel, 4, hipMemcpyDeviceToHost));
   stt->stereo_detected = stereo;
   // FmDecode.h:146-150
   const float tuned = float(-b->shifts[channel]) * b->des.fs_if / float(int(b->des.table_size));
@@ -926,11 +885,12 @@ int fmd_batch_get_design(fmd_batch* b, int what, float* out, unsigned cap)
   return int(v.size());
 }
 
-int fmd_batch_set_profiling(fmd_batch* b, int enable)
+int fmd_batch_set_profiling(fmd_batch* b, int level)
 {
   if (!b)
     return fail(FMD_ERR_ARG, "null batch");
-  b->profiling = enable != 0;
+  b->profiling = level < 0 ? 0 : (level > 2 ? 2 : level);
+  b->prof_calls = 0; // restart the averaging window
   return FMD_OK;
 }
 
@@ -938,19 +898,26 @@ int fmd_batch_get_stage_ms(fmd_batch* b, float* out, unsigned cap)
 {
   if (!b || !out)
     return fail(FMD_ERR_ARG, "bad argument");
-  if (!b->profiling || !b->ev_valid)
-    return fail(FMD_ERR_STATE, "profiling not enabled or no call made");
+  if (!b->profiling || b->prof_calls == 0)
+    return fail(FMD_ERR_STATE, "profiling not enabled or no call made since it was enabled");
   HIPCHK(hipSetDevice(b->device));
-  HIPCHK(hipEventSynchronize(b->ev[ST_COUNT]));
+  HIPCHK(hipDeviceSynchronize());
+  const int nst = b->profiling >= 2 ? ST_COUNT : 1;
   for (int i = 0; i < ST_COUNT; i++)
   {
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]));
-    b->stage_ms[i] = ms;
+    double sum = 0;
+    if (i < nst)
+      for (unsigned c = 0; c < b->prof_calls; c++)
+      {
+        float ms = 0;
+        hipEvent_t* es = &b->ev[size_t(c) * (ST_COUNT + 1)];
+        HIPCHK(hipEventElapsedTime(&ms, es[i], es[i + 1]));
+        sum += ms;
+      }
     if (unsigned(i) < cap)
-      out[i] = ms;
+      out[i] = i < nst ? float(sum / b->prof_calls) : -1.0f;
   }
-  return ST_COUNT;
+  return int(b->prof_calls);
 }
 
 /* ---- single decoder = batch of one -------------------------------------------------------- */

@@ -50,30 +50,32 @@ struct AudioConsts
   float n_b0, n_b1, n_b2, n_a1, n_a2; // 19 kHz notch
 };
 
-/* per-channel signal state, structure of arrays, each array CP long */
+/* per-channel signal state: structure of arrays, every array CP long, addressed by slot
+ * index from two slabs (one pointer each keeps the kernels' SGPR budget small) */
+enum FSlot
+{
+  F_NCO_PHASE, F_NCO_INCR, F_DC_OFF,                 // FM PLL
+  F_IF_LEVEL, F_BB_MEAN, F_BB_LEVEL,                 // level meters
+  F_P_I1, F_P_I2, F_P_Q1, F_P_Q2, F_P_X1, F_P_FREQ, F_P_PHASE, F_P_LEVEL, // pilot PLL
+  F_OSC_RE, F_OSC_IM,                                // RDS oscillator
+  F_R_PHASE, F_R_FREQ, F_R_W1, F_R_W2, F_R_LAST_SYNC, F_R_LAST_SLOPE, F_R_LAST_DATA,
+  F_DE_RE, F_DE_IM, F_N_W1A, F_N_W2A, F_N_W1B, F_N_W2B, // de-emphasis, notch
+  F_SLOTS
+};
+enum ISlot
+{
+  I_P_LOCK_CNT, I_STEREO, I_R_LAST_BIT, I_R_BITS, I_R_BLOCK, I_R_BITPOS, I_R_STATE, I_R_BOFF,
+  I_R_ERRORS, I_R_SEQ, I_SLOTS
+};
 struct ChannelState
 {
-  // FM PLL
-  float *nco_phase, *nco_incr, *dc_off;
-  // level meters
-  float *if_level, *bb_mean, *bb_level;
-  // pilot PLL
-  float *p_i1, *p_i2, *p_q1, *p_q2, *p_x1, *p_freq, *p_phase, *p_level;
-  int *p_lock_cnt, *stereo;
-  // RDS oscillator
-  float *osc_re, *osc_im;
-  // RDS PLL / bit sync / slicer
-  float *r_phase, *r_freq, *r_w1, *r_w2, *r_last_sync, *r_last_slope, *r_last_data;
-  int* r_last_bit;
-  // RDS block sync
-  uint32_t* r_bits;
-  int *r_block, *r_bitpos, *r_state, *r_boff, *r_errors;
-  uint16_t* r_data; // [4][CP]
-  uint32_t* r_seq;
-  // matched filter ring [mf_taps][CP]
-  float* r_mfring;
-  // de-emphasis, notch
-  float *de_re, *de_im, *n_w1a, *n_w2a, *n_w1b, *n_w2b;
+  float* f;         // [F_SLOTS][CP]
+  int* i;           // [I_SLOTS][CP]
+  uint16_t* r_data; // [4][CP]   block words of the group being assembled
+  float* r_mfring;  // [mf_taps][CP] matched-filter ring
+  unsigned CP;
+  __host__ __device__ float* F(int slot) const { return f + (size_t)slot * CP; }
+  __host__ __device__ int* I(int slot) const { return i + (size_t)slot * CP; }
 };
 
 struct RdsGroupRec
@@ -97,7 +99,11 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 /*     then accumulates its output over taps j = 1..order in the reference's order.  Taps are   */
 /*     wave-uniform (scalar loads).                                                             */
 /* ------------------------------------------------------------------------------------------ */
-template <int TILE>
+/* Staging detail: 16 bytes (two IQ samples) per lane per load, UNROLL loads issued back to back
+ * before the first use so a workgroup keeps several KiB in flight; the tuner table has
+ * T | 2*TILE entries (power of two), so the two table entries a lane needs are the same for
+ * every load it issues and live in registers. */
+template <int TILE, int UNROLL, bool POW2>
 __global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, size_t chan_stride,
                                                  unsigned N, const float2* __restrict__ hist_in,
                                                  float2* __restrict__ hist_out,
@@ -106,32 +112,72 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, 
                                                  unsigned order, unsigned D, unsigned pos, unsigned M,
                                                  float2* __restrict__ out, unsigned Mstride)
 {
-  extern __shared__ float2 win[];
+  extern __shared__ __attribute__((aligned(16))) float2 win[];
   const unsigned c = blockIdx.x;
   const unsigned m0 = blockIdx.y * TILE;
   const unsigned tid = threadIdx.x;
   const unsigned nout = min((unsigned)TILE, M - m0);
-  const int k_lo = (int)(pos + m0 * D) - (int)order; // absolute index of win[0]
-  const unsigned count = (nout - 1) * D + order;
+  const int p_first = (int)(pos + m0 * D);
+  const int k_lo = p_first - (int)order;         // first sample the tile needs
+  const int k_hi = p_first + (int)((nout - 1) * D); // one past the last sample it needs
+  const int k_al = k_lo - (k_lo & 1);            // even, so that even k <-> 16-byte aligned win slot
   const float2* __restrict__ x = iq + (size_t)c * chan_stride;
   const float2* __restrict__ l = lut + (size_t)c * T;
-  const float2* __restrict__ h = hist_in + (size_t)c * order;
 
-  for (unsigned i = tid; i < count; i += TILE)
+  if (k_lo < 0)
+  { // tail of the previous call (already tuned), only for the first tile(s)
+    const float2* __restrict__ h = hist_in + (size_t)c * order;
+    const int nh = min(-k_lo, k_hi - k_lo);
+    for (int i = (int)tid; i < nh; i += TILE)
+      win[i + (k_lo - k_al)] = h[(int)order + k_lo + i];
+  }
   {
-    const int k = k_lo + (int)i;
-    float2 v;
-    if (k >= 0)
-      v = cmul(x[k], l[(lut_idx0 + (unsigned)k) % T]);
+    const int ks = max(k_al, 0); // even
+    const int npairs = (k_hi - ks + 1) >> 1;
+    if (POW2)
+    {
+      const unsigned mask = T - 1;
+      const unsigned li = (lut_idx0 + (unsigned)ks + 2u * tid) & mask;
+      const float2 l0 = l[li], l1 = l[(li + 1) & mask];
+      const float4* __restrict__ src = reinterpret_cast<const float4*>(x + ks);
+      float4* dst = reinterpret_cast<float4*>(win + (ks - k_al));
+      for (int base = 0; base < npairs; base += UNROLL * TILE)
+      {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
+        {
+          const int i = base + u * TILE + (int)tid;
+          if (i < npairs)
+            v[u] = src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
+        {
+          const int i = base + u * TILE + (int)tid;
+          if (i < npairs)
+          {
+            const float2 a = cmul(make_float2(v[u].x, v[u].y), l0);
+            const float2 b = cmul(make_float2(v[u].z, v[u].w), l1);
+            dst[i] = make_float4(a.x, a.y, b.x, b.y);
+          }
+        }
+      }
+    }
     else
-      v = h[(int)order + k]; // tail of the previous call, already tuned
-    win[i] = v;
+    {
+      for (int i = (int)tid; i < 2 * npairs; i += TILE)
+      {
+        const int k = ks + i;
+        win[k - k_al] = cmul(x[k], l[(lut_idx0 + (unsigned)k) % T]);
+      }
+    }
   }
   __syncthreads();
 
   if (tid < nout)
   {
-    const float2* w = win + tid * D + order; // w[-j] = x[p - j]
+    const float2* w = win + (k_lo - k_al) + tid * D + order; // w[-j] = x[p - j]
     float2 acc = make_float2(0.0f, 0.0f);
 #pragma unroll 8
     for (unsigned j = 1; j <= order; j++)
@@ -183,37 +229,34 @@ __global__ __launch_bounds__(64) void k_demod_serial(
       level += s.x * s.x + s.y * s.y;
     }
     const float rms = sqrtf(level / (float)n);
-    st.if_level[c] = 0.95f * st.if_level[c] + 0.05f * rms;
+    st.F(F_IF_LEVEL)[c] = 0.95f * st.F(F_IF_LEVEL)[c] + 0.05f * rms;
   }
 
-  float nco_phase = st.nco_phase[c], nco_incr = st.nco_incr[c], dc = st.dc_off[c];
-  float p_i1 = st.p_i1[c], p_i2 = st.p_i2[c], p_q1 = st.p_q1[c], p_q2 = st.p_q2[c];
-  float p_x1 = st.p_x1[c], p_freq = st.p_freq[c], p_phase = st.p_phase[c];
+  float nco_phase = st.F(F_NCO_PHASE)[c], nco_incr = st.F(F_NCO_INCR)[c], dc = st.F(F_DC_OFF)[c];
+  float p_i1 = st.F(F_P_I1)[c], p_i2 = st.F(F_P_I2)[c], p_q1 = st.F(F_P_Q1)[c], p_q2 = st.F(F_P_Q2)[c];
+  float p_x1 = st.F(F_P_X1)[c], p_freq = st.F(F_P_FREQ)[c], p_phase = st.F(F_P_PHASE)[c];
   float p_level = 1000.0f; // FmDecode.cpp:147
-  float o_re = st.osc_re[c], o_im = st.osc_im[c];
+  float o_re = st.F(F_OSC_RE)[c], o_im = st.F(F_OSC_IM)[c];
   float vsum = 0.0f, vsumsq = 0.0f;
 
-  const float4* __restrict__ row = reinterpret_cast<const float4*>(demod + (size_t)c * Mstride);
-  for (unsigned m0 = 0; m0 < M; m0 += 8)
+  const float2* __restrict__ row = demod + (size_t)c * Mstride;
+  float* __restrict__ bbp = bb + (size_t)Hbb * CP + c;
+  float* __restrict__ rawp = raw + (size_t)Hbb * CP + c;
+  float2* __restrict__ mixp = mix + (size_t)Hmix * CP + c;
+  float2 cur = row[0];
+#pragma unroll 1
+  for (unsigned m = 0; m < M; m++)
   {
-    float4 chunk[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-      chunk[q] = row[(m0 >> 1) + q];
-    const float* cf = reinterpret_cast<const float*>(chunk);
-#pragma unroll
-    for (int u = 0; u < 8; u++)
     {
-      const unsigned m = m0 + u;
-      if (m >= M)
-        break;
-      const float sre = cf[2 * u], sim = cf[2 * u + 1];
+      const float2 nxt = row[(m + 1 < M) ? m + 1 : m]; // fetched one step ahead of its use
+      const float sre = cur.x, sim = cur.y;
+      cur = nxt;
       /* ---- FM PLL (FmDecode.cpp:371-413) ---- */
       float sn, cs;
       fmd_sincos_nco(nco_phase, &sn, &cs);
       const float dre = cs * sre - sn * sim; // ComplexType(Cos, Sin) * signal[i]
       const float dim = cs * sim + sn * sre;
-      const float err = -fmd_atan2f(dim, dre);
+      const float err = -fmd_atan2f_fast(dim, dre);
       nco_incr += k.pll_beta * err;
       if (nco_incr < k.nco_ll)
         nco_incr = k.nco_ll;
@@ -227,7 +270,8 @@ __global__ __launch_bounds__(64) void k_demod_serial(
       const float pinc = 2 * nco_incr;
       dc = (float)((1 - 0.0001) * (double)dc + 0.0001 * (double)pinc);
       const float v = (pinc - dc) * k.demod_gain;
-      bb[(size_t)(Hbb + m) * CP + c] = v;
+      *bbp = v;
+      bbp += CP;
       vsum += v;
       vsumsq += v * v;
 
@@ -260,7 +304,8 @@ __global__ __launch_bounds__(64) void k_demod_serial(
       p_phase += p_freq;
       if ((double)p_phase > FMD_K_2PI)
         p_phase = (float)((double)p_phase - FMD_K_2PI);
-      raw[(size_t)(Hbb + m) * CP + c] = tone * (2 * v); // FmDecode.cpp:456
+      *rawp = tone * (2 * v); // FmDecode.cpp:456
+      rawp += CP;
 
       /* ---- RDS oscillator mix (DownConvert.cpp:436-442, :464-465), imag(input) == 0 ---- */
       float2 osc;
@@ -270,27 +315,27 @@ __global__ __launch_bounds__(64) void k_demod_serial(
       o_re = gn * osc.x;
       o_im = gn * osc.y;
       const float zero = 0.0f;
-      mix[(size_t)(Hmix + m) * CP + c] =
-          make_float2((v * osc.x) - (zero * osc.y), (v * osc.y) + (zero * osc.x));
+      *mixp = make_float2((v * osc.x) - (zero * osc.y), (v * osc.y) + (zero * osc.x));
+      mixp += CP;
     }
   }
 
-  st.nco_phase[c] = nco_phase;
-  st.nco_incr[c] = nco_incr;
-  st.dc_off[c] = dc;
-  st.p_i1[c] = p_i1;
-  st.p_i2[c] = p_i2;
-  st.p_q1[c] = p_q1;
-  st.p_q2[c] = p_q2;
-  st.p_x1[c] = p_x1;
-  st.p_freq[c] = p_freq;
-  st.p_phase[c] = p_phase;
-  st.p_level[c] = p_level;
-  st.osc_re[c] = o_re;
-  st.osc_im[c] = o_im;
+  st.F(F_NCO_PHASE)[c] = nco_phase;
+  st.F(F_NCO_INCR)[c] = nco_incr;
+  st.F(F_DC_OFF)[c] = dc;
+  st.F(F_P_I1)[c] = p_i1;
+  st.F(F_P_I2)[c] = p_i2;
+  st.F(F_P_Q1)[c] = p_q1;
+  st.F(F_P_Q2)[c] = p_q2;
+  st.F(F_P_X1)[c] = p_x1;
+  st.F(F_P_FREQ)[c] = p_freq;
+  st.F(F_P_PHASE)[c] = p_phase;
+  st.F(F_P_LEVEL)[c] = p_level;
+  st.F(F_OSC_RE)[c] = o_re;
+  st.F(F_OSC_IM)[c] = o_im;
 
   { // lock status (FmDecode.cpp:219-228)
-    int cnt = st.p_lock_cnt[c];
+    int cnt = st.I(I_P_LOCK_CNT)[c];
     if (2 * p_level > k.p_minsignal)
     {
       if (cnt < k.p_lock_delay)
@@ -298,14 +343,14 @@ __global__ __launch_bounds__(64) void k_demod_serial(
     }
     else
       cnt = 0;
-    st.p_lock_cnt[c] = cnt;
-    st.stereo[c] = cnt >= k.p_lock_delay;
+    st.I(I_P_LOCK_CNT)[c] = cnt;
+    st.I(I_STEREO)[c] = cnt >= k.p_lock_delay;
   }
   { // baseband stats (FmDecode.cpp:439-442)
     const float mean = vsum / (float)M;
     const float rms = sqrtf(vsumsq / (float)M);
-    st.bb_mean[c] = 0.95f * st.bb_mean[c] + 0.05f * mean;
-    st.bb_level[c] = 0.95f * st.bb_level[c] + 0.05f * rms;
+    st.F(F_BB_MEAN)[c] = 0.95f * st.F(F_BB_MEAN)[c] + 0.05f * mean;
+    st.F(F_BB_LEVEL)[c] = 0.95f * st.F(F_BB_LEVEL)[c] + 0.05f * rms;
   }
 }
 
@@ -444,18 +489,18 @@ __global__ __launch_bounds__(64) void k_rds_serial(const float2* __restrict__ lp
     ring[j * 64 + lane] = st.r_mfring[(size_t)j * CP + c];
 
   const uint32_t offs[8] = {0x3D8, 0x3D4, 0x25C, 0x258, 0x3D8, 0x3D4, 0x3CC, 0x258};
-  float phase = st.r_phase[c], freq = st.r_freq[c];
-  float w1 = st.r_w1[c], w2 = st.r_w2[c];
-  float last_sync = st.r_last_sync[c], last_slope = st.r_last_slope[c], last_data = st.r_last_data[c];
-  int last_bit = st.r_last_bit[c];
-  uint32_t bits = st.r_bits[c];
-  int block = st.r_block[c], bitpos = st.r_bitpos[c], state = st.r_state[c], boff = st.r_boff[c],
-      errors = st.r_errors[c];
+  float phase = st.F(F_R_PHASE)[c], freq = st.F(F_R_FREQ)[c];
+  float w1 = st.F(F_R_W1)[c], w2 = st.F(F_R_W2)[c];
+  float last_sync = st.F(F_R_LAST_SYNC)[c], last_slope = st.F(F_R_LAST_SLOPE)[c], last_data = st.F(F_R_LAST_DATA)[c];
+  int last_bit = st.I(I_R_LAST_BIT)[c];
+  uint32_t bits = (uint32_t)st.I(I_R_BITS)[c];
+  int block = st.I(I_R_BLOCK)[c], bitpos = st.I(I_R_BITPOS)[c], state = st.I(I_R_STATE)[c], boff = st.I(I_R_BOFF)[c],
+      errors = st.I(I_R_ERRORS)[c];
   uint16_t bd[4];
 #pragma unroll
   for (int q = 0; q < 4; q++)
     bd[q] = st.r_data[(size_t)q * CP + c];
-  uint32_t seq = st.r_seq[c];
+  uint32_t seq = (uint32_t)st.I(I_R_SEQ)[c];
   int mstate = mf_state0;
 
   for (unsigned i = 0; i < R; i++)
@@ -604,24 +649,24 @@ __global__ __launch_bounds__(64) void k_rds_serial(const float2* __restrict__ lp
 
   for (int j = 0; j < T; j++)
     st.r_mfring[(size_t)j * CP + c] = ring[j * 64 + lane];
-  st.r_phase[c] = phase;
-  st.r_freq[c] = freq;
-  st.r_w1[c] = w1;
-  st.r_w2[c] = w2;
-  st.r_last_sync[c] = last_sync;
-  st.r_last_slope[c] = last_slope;
-  st.r_last_data[c] = last_data;
-  st.r_last_bit[c] = last_bit;
-  st.r_bits[c] = bits;
-  st.r_block[c] = block;
-  st.r_bitpos[c] = bitpos;
-  st.r_state[c] = state;
-  st.r_boff[c] = boff;
-  st.r_errors[c] = errors;
+  st.F(F_R_PHASE)[c] = phase;
+  st.F(F_R_FREQ)[c] = freq;
+  st.F(F_R_W1)[c] = w1;
+  st.F(F_R_W2)[c] = w2;
+  st.F(F_R_LAST_SYNC)[c] = last_sync;
+  st.F(F_R_LAST_SLOPE)[c] = last_slope;
+  st.F(F_R_LAST_DATA)[c] = last_data;
+  st.I(I_R_LAST_BIT)[c] = last_bit;
+  st.I(I_R_BITS)[c] = (int)bits;
+  st.I(I_R_BLOCK)[c] = block;
+  st.I(I_R_BITPOS)[c] = bitpos;
+  st.I(I_R_STATE)[c] = state;
+  st.I(I_R_BOFF)[c] = boff;
+  st.I(I_R_ERRORS)[c] = errors;
 #pragma unroll
   for (int q = 0; q < 4; q++)
     st.r_data[(size_t)q * CP + c] = bd[q];
-  st.r_seq[c] = seq;
+  st.I(I_R_SEQ)[c] = (int)seq;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -682,9 +727,9 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
   const unsigned c = blockIdx.x * 64 + threadIdx.x;
   if (c >= C)
     return;
-  float de_re = st.de_re[c], de_im = st.de_im[c];
-  float w1a = st.n_w1a[c], w2a = st.n_w2a[c], w1b = st.n_w1b[c], w2b = st.n_w2b[c];
-  const int stereo = st.stereo[c];
+  float de_re = st.F(F_DE_RE)[c], de_im = st.F(F_DE_IM)[c];
+  float w1a = st.F(F_N_W1A)[c], w2a = st.F(F_N_W2A)[c], w1b = st.F(F_N_W1B)[c], w2b = st.F(F_N_W2B)[c];
+  const int stereo = st.I(I_STEREO)[c];
   float2* __restrict__ o = reinterpret_cast<float2*>(audio + (size_t)c * audio_stride);
   for (unsigned i = 0; i < A; ++i)
   {
@@ -711,12 +756,12 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
     }
     o[i] = lr;
   }
-  st.de_re[c] = de_re;
-  st.de_im[c] = de_im;
-  st.n_w1a[c] = w1a;
-  st.n_w2a[c] = w2a;
-  st.n_w1b[c] = w1b;
-  st.n_w2b[c] = w2b;
+  st.F(F_DE_RE)[c] = de_re;
+  st.F(F_DE_IM)[c] = de_im;
+  st.F(F_N_W1A)[c] = w1a;
+  st.F(F_N_W2A)[c] = w2a;
+  st.F(F_N_W1B)[c] = w1b;
+  st.F(F_N_W2B)[c] = w2b;
 }
 
 /* ------------------------------------------------------------------------------------------ */

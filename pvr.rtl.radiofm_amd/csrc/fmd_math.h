@@ -25,11 +25,16 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
 
 #ifdef __HIPCC__
 #define FMD_HD __host__ __device__ static inline
+#define FMD_HD_NOINLINE __host__ __device__ static __attribute__((noinline))
 #else
 #define FMD_HD static inline
+#define FMD_HD_NOINLINE static __attribute__((noinline))
 #endif
 
 #define FMD_K_2PI (2.0 * 3.14159265358979323846)
@@ -129,7 +134,7 @@ FMD_HD float fmd_atanf(float x)
 }
 
 /* fdlibm e_atan2f.c */
-FMD_HD float fmd_atan2f(float y, float x)
+FMD_HD_NOINLINE float fmd_atan2f(float y, float x)
 {
   const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f,
               pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
@@ -209,18 +214,91 @@ FMD_HD float fmd_atan2f(float y, float x)
   }
 }
 
-/* sin/cos of a float phase evaluated in double and rounded once to float */
+/* sin/cos of a float phase evaluated in double and rounded once to float.
+ * Branch-free for the NCO range (|phase| < ~1e5): k = rint(x*2/pi), two-term Cody-Waite
+ * reduction with fma, fdlibm __kernel_sin/__kernel_cos polynomials on [-pi/4, pi/4] (< 1 ulp
+ * of double), quadrant fix-up by selects, then ONE rounding to float. */
 FMD_HD void fmd_sincos_nco(float phase, float* s, float* c)
 {
-  double sd, cd;
-#ifdef __HIP_DEVICE_COMPILE__
-  sincos((double)phase, &sd, &cd);
-#else
-  sd = sin((double)phase);
-  cd = cos((double)phase);
-#endif
-  *s = (float)sd;
-  *c = (float)cd;
+  const double x = (double)phase;
+  const double k = __builtin_rint(x * 6.36619772367581382433e-01);
+  double r = __builtin_fma(-k, 1.57079632673412561417e+00, x);
+  r = __builtin_fma(-k, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  /* sin kernel */
+  double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+  ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+  ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+  ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+  const double sr = __builtin_fma(r * z, ps, r);
+  /* cos kernel */
+  double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+  pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+  pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+  pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * z * pc);
+  const int n = (int)k;
+  double so = (n & 1) ? cr : sr;
+  double co = (n & 1) ? sr : cr;
+  so = (n & 2) ? -so : so;
+  co = ((n + 1) & 2) ? -co : co;
+  *s = (float)so;
+  *c = (float)co;
+}
+
+/* fdlibm atanf with the five argument ranges folded into one division and selects; same
+ * operations in the same order as fmd_atanf() for every finite 2^-29 <= |x| < 2^25 (the
+ * callers route anything else to fmd_atanf).  x must be >= 0. */
+FMD_HD float fmd_atanf_pos_fast(float x)
+{
+  const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
+              aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
+              aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f,
+              aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+  const uint32_t ix = fmd_f2u(x);
+  const bool r0 = ix < 0x3ee00000u; /* < 0.4375: no reduction */
+  const bool r1 = ix < 0x3f300000u; /* < 0.6875 */
+  const bool r2 = ix < 0x3f980000u; /* < 1.1875 */
+  const bool r3 = ix < 0x401c0000u; /* < 2.4375 */
+  /* numerator / denominator of the reduced argument */
+  float num = r0 ? x : (r1 ? (2.0f * x - 1.0f) : (r2 ? (x - 1.0f) : (r3 ? (x - 1.5f) : -1.0f)));
+  float den = r0 ? 1.0f : (r1 ? (2.0f + x) : (r2 ? (x + 1.0f) : (r3 ? (1.0f + 1.5f * x) : x)));
+  const float hi = r1 ? 4.6364760399e-01f : (r2 ? 7.8539812565e-01f : (r3 ? 9.8279368877e-01f : 1.5707962513e+00f));
+  const float lo = r1 ? 5.0121582440e-09f : (r2 ? 3.7748947079e-08f : (r3 ? 3.4473217170e-08f : 7.5497894159e-08f));
+  const float xr = num / den; /* x/1 is exact for the unreduced range */
+  const float z = xr * xr;
+  const float w = z * z;
+  const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+  const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+  const float p = xr * (s1 + s2);
+  const float small = xr - p;
+  const float big = hi - ((p - lo) - xr);
+  return r0 ? small : big;
+}
+
+/* fdlibm atan2f, common case branch-free; rare inputs (zeros, infinities, NaNs, huge ratios,
+ * tiny or huge |y/x|) go through the literal restatement fmd_atan2f(). */
+FMD_HD float fmd_atan2f_fast(float y, float x)
+{
+  const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  const uint32_t hx = fmd_f2u(x), hy = fmd_f2u(y);
+  const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+  const int32_t k = ((int32_t)iy - (int32_t)ix) >> 23;
+  const float q = fabsf(y / x);
+  const uint32_t iq = fmd_f2u(q);
+  const bool rare = (ix - 1u >= 0x7f7fffffu) | (iy - 1u >= 0x7f7fffffu) | (k > 60) | (k < -60) |
+                    (iq < 0x31000000u) | (iq >= 0x4c000000u);
+  if (rare)
+    return fmd_atan2f(y, x);
+  const float z = fmd_atanf_pos_fast(q);
+  const float t = z - pi_lo;
+  const float neg = fmd_u2f(fmd_f2u(z) ^ 0x80000000u);
+  const bool ysign = (hy >> 31) != 0, xsign = (hx >> 31) != 0;
+  return xsign ? (ysign ? (t - pi) : (pi - t)) : (ysign ? neg : z);
 }
 
 /* RDSProcess.cpp:187-217 */

@@ -95,3 +95,70 @@ def rds_groups(p):
     out = np.empty((4, 4), dtype=np.uint16)
     lib().fmsig_rds_groups(C.byref(p), out.ctypes.data)
     return out
+
+
+# ---- device generator (libfmsig_hip.so, HIP) ---------------------------------------------------
+_DLIB = None
+CHAN_DTYPE = np.dtype([
+    ("inv_fs", "<f8"), ("f_offset", "<f8"), ("dev", "<f8"), ("amp", "<f8"),
+    ("a_mono", "<f8"), ("a_stereo", "<f8"), ("a_pilot", "<f8"), ("a_rds", "<f8"),
+    ("f_left", "<f8"), ("f_right", "<f8"), ("noise_sigma", "<f8"), ("seed", "<u8"),
+])
+
+
+def dlib():
+    global _DLIB
+    if _DLIB is None:
+        import torch  # noqa: F401  (one HIP runtime per process, see the product package)
+        path = os.path.join(_HERE, "..", "pvr.rtl.radiofm_amd", "libfmsig_hip.so")
+        L = C.CDLL(path)
+        L.fmsig_device_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint64,
+                                            C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.fmsig_chan_size.restype = C.c_uint
+        assert L.fmsig_chan_size() == CHAN_DTYPE.itemsize
+        _DLIB = L
+    return _DLIB
+
+
+def channel_params(fs, channel, base_seed=1000, noise_sigma=0.01):
+    """Station `channel` of the synthetic multi-channel workload (config 3/4): its own audio
+    tones, noise seed, PI code and PS name."""
+    return default_params(
+        fs, noise_sigma=noise_sigma, seed=base_seed + channel,
+        f_left=400.0 + 13.0 * (channel % 97), f_right=2500.0 + 7.0 * (channel % 211),
+        pi=0x1000 + (channel % 0xE000),
+        ps="C%07d" % (channel % 10000000))
+
+
+class DeviceGenerator:
+    """Generates [C][n] complex64 IQ on the GPU for a list of FmsigParams."""
+
+    def __init__(self, params_list, device="cuda"):
+        import torch
+        self.torch = torch
+        Cn = len(params_list)
+        chans = np.zeros(Cn, dtype=CHAN_DTYPE)
+        dbits = np.zeros((Cn, 832), dtype=np.uint8)
+        for i, p in enumerate(params_list):
+            chans[i] = (1.0 / p.fs, p.f_offset, p.dev, p.amp, p.a_mono, p.a_stereo, p.a_pilot,
+                        p.a_rds, p.f_left, p.f_right, p.noise_sigma, p.seed)
+            dbits[i] = rds_dbits(p)
+        self.C = Cn
+        self.d_chans = torch.from_numpy(chans.view(np.uint8).copy()).to(device)
+        self.d_dbits = torch.from_numpy(dbits.reshape(-1).copy()).to(device)
+
+    def generate(self, out, start, n):
+        """out: torch float32 cuda tensor viewable as [C, n, 2]; start: absolute sample index."""
+        torch = self.torch
+        assert out.is_cuda and out.dtype == torch.float32 and out.numel() >= self.C * n * 2
+        stream = torch.cuda.current_stream().cuda_stream
+        # grid.y is limited to 65535 channels per launch
+        done = 0
+        while done < self.C:
+            cnt = min(32768, self.C - done)
+            rc = dlib().fmsig_device_generate(
+                self.d_chans.data_ptr() + done * CHAN_DTYPE.itemsize,
+                self.d_dbits.data_ptr() + done * 832, 832, cnt, start, n,
+                out.data_ptr() + done * n * 8, n, stream)
+            assert rc == 0
+            done += cnt
