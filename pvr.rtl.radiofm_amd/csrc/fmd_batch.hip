@@ -514,14 +514,22 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
     if (lds > 160 * 1024)
       return fail(FMD_ERR_ARG, "IF filter window does not fit in LDS");
     const bool pow2 = (d.table_size & (d.table_size - 1)) == 0 && d.table_size <= 2 * TILE;
-    auto kfn = pow2 ? &fmd::k_if_fir<TILE, 4, true> : &fmd::k_if_fir<TILE, 4, false>;
+    // loads per lane needed to stage one tile in a single round trip (two samples per load)
+    const unsigned rounds = ((size_t(TILE - 1) * D + d.if_order + 2) / 2 + TILE - 1) / TILE;
+    auto kfn = &fmd::k_if_fir<TILE, 4, false>;
+    if (pow2)
+      kfn = rounds <= 2 ? &fmd::k_if_fir<TILE, 2, true>
+          : rounds <= 4 ? &fmd::k_if_fir<TILE, 4, true>
+          : rounds <= 6 ? &fmd::k_if_fir<TILE, 6, true>
+                        : &fmd::k_if_fir<TILE, 8, true>;
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kfn, dim3(C, ntiles), dim3(TILE), lds, stream,
+    hipLaunchKernelGGL(kfn, dim3(C * ntiles), dim3(TILE), lds, stream,
                        reinterpret_cast<const float2*>(d_iq), iq_channel_stride, N,
                        b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, d.table_size,
-                       b->lut_idx, b->if_coeff.p, d.if_order, D, pos, M, b->demod.p, b->Mstride);
+                       b->lut_idx, b->if_coeff.p, d.if_order, D, pos, M, b->demod.p, b->Mstride,
+                       ntiles, (C % 8 == 0) ? 1u : 0u);
   }
   mark(1);
 

@@ -100,9 +100,14 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 /*     wave-uniform (scalar loads).                                                             */
 /* ------------------------------------------------------------------------------------------ */
 /* Staging detail: 16 bytes (two IQ samples) per lane per load, UNROLL loads issued back to back
- * before the first use so a workgroup keeps several KiB in flight; the tuner table has
- * T | 2*TILE entries (power of two), so the two table entries a lane needs are the same for
- * every load it issues and live in registers. */
+ * (unconditional, index clamped: a branch would make the compiler wait after every load) so a
+ * workgroup has its whole window in flight in one round trip; the tuner table has T | 2*TILE
+ * entries (power of two), so the two table entries a lane needs are the same for every load
+ * it issues and live in registers.
+ * Block -> (channel, tile): block ids are dealt round-robin over the 8 XCDs, so with
+ * xcd_map != 0 each XCD gets whole channels and walks their tiles in order: consecutive tiles
+ * share their `order`-sample halo in that XCD's L2 and every channel is read as one
+ * contiguous 512 KiB stream (measured 0.79 ms vs 0.97 ms channel-fastest, 8192 channels). */
 template <int TILE, int UNROLL, bool POW2>
 __global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, size_t chan_stride,
                                                  unsigned N, const float2* __restrict__ hist_in,
@@ -110,17 +115,29 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, 
                                                  const float2* __restrict__ lut, unsigned T,
                                                  unsigned lut_idx0, const float* __restrict__ coeff,
                                                  unsigned order, unsigned D, unsigned pos, unsigned M,
-                                                 float2* __restrict__ out, unsigned Mstride)
+                                                 float2* __restrict__ out, unsigned Mstride,
+                                                 unsigned ntiles, unsigned xcd_map)
 {
   extern __shared__ __attribute__((aligned(16))) float2 win[];
-  const unsigned c = blockIdx.x;
-  const unsigned m0 = blockIdx.y * TILE;
+  unsigned c, tile;
+  if (xcd_map)
+  {
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    c = (slot / ntiles) * 8u + xcd;
+    tile = slot % ntiles;
+  }
+  else
+  {
+    c = blockIdx.x / ntiles;
+    tile = blockIdx.x % ntiles;
+  }
+  const unsigned m0 = tile * TILE;
   const unsigned tid = threadIdx.x;
   const unsigned nout = min((unsigned)TILE, M - m0);
   const int p_first = (int)(pos + m0 * D);
-  const int k_lo = p_first - (int)order;         // first sample the tile needs
+  const int k_lo = p_first - (int)order;            // first sample the tile needs
   const int k_hi = p_first + (int)((nout - 1) * D); // one past the last sample it needs
-  const int k_al = k_lo - (k_lo & 1);            // even, so that even k <-> 16-byte aligned win slot
+  const int k_al = k_lo - (k_lo & 1);               // even: even k <-> 16-byte aligned win slot
   const float2* __restrict__ x = iq + (size_t)c * chan_stride;
   const float2* __restrict__ l = lut + (size_t)c * T;
 
@@ -146,11 +163,7 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, 
         float4 v[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++)
-        {
-          const int i = base + u * TILE + (int)tid;
-          if (i < npairs)
-            v[u] = src[i];
-        }
+          v[u] = src[max(min(base + u * TILE + (int)tid, npairs - 1), 0)];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++)
         {
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, 
   }
 
   // the workgroup of the last tile also saves the last `order` tuned samples (:146-151)
-  if (blockIdx.y == gridDim.y - 1)
+  if (tile == ntiles - 1)
   {
     float2* __restrict__ ho = hist_out + (size_t)c * order;
     for (unsigned i = tid; i < order; i += TILE)
