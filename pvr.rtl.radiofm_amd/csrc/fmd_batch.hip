@@ -107,6 +107,7 @@ struct fmd_batch
   std::vector<DevBuf<float2>> hbbuf; // input buffers of stages 1..n-1 (stage 0 reads mix)
   DevBuf<float> if_coeff, rs_coeff, bb, raw, rds_lpf_taps, mf_taps2, audio_taps, ktab;
   DevBuf<float> tap_pll, tap_mf, tap_sync;
+  DevBuf<double> sctab;
   DevBuf<int> pidx;
   DevBuf<float> fstate; // all float state arrays, CP each
   DevBuf<int> istate;
@@ -155,6 +156,7 @@ struct fmd_batch
     tap_pll.release();
     tap_mf.release();
     tap_sync.release();
+    sctab.release();
     pidx.release();
     fstate.release();
     istate.release();
@@ -363,6 +365,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->audio_taps.alloc(T_alp);
   bad |= b->ktab.alloc(size_t(b->Amax) * (d.rs_order + 1));
   bad |= b->pidx.alloc(b->Amax);
+  bad |= b->sctab.alloc(d.sincos_tab.size());
   bad |= b->fstate.alloc(size_t(fmd::F_SLOTS) * CP);
   bad |= b->istate.alloc(size_t(fmd::I_SLOTS) * CP);
   bad |= b->r_data.alloc(size_t(4) * CP);
@@ -378,6 +381,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= upload(b->rs_coeff.p, d.rs_coeff.data(), d.rs_coeff.size() * sizeof(float));
   bad |= upload(b->rds_lpf_taps.p, d.rds_lpf_taps.data(), T_lpf * sizeof(float));
   bad |= upload(b->audio_taps.p, d.lpf_taps.data(), T_alp * sizeof(float));
+  bad |= upload(b->sctab.p, d.sincos_tab.data(), d.sincos_tab.size() * sizeof(double));
   {
     std::vector<float> t2(size_t(2) * T_mf);
     for (unsigned i = 0; i < 2 * T_mf; i++)
@@ -552,10 +556,13 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
     k.p_lock_delay = d.p_lock_delay;
     k.osc_cos = d.rds_osc_cos;
     k.osc_sin = d.rds_osc_sin;
-    hipLaunchKernelGGL(fmd::k_demod_serial, dim3(CP / 64), dim3(64), 0, stream,
+    hipLaunchKernelGGL(fmd::k_if_level, dim3(C), dim3(64), 0, stream,
                        reinterpret_cast<const float2*>(d_iq), iq_channel_stride, N, b->lut.p,
-                       d.table_size, b->lut_idx, b->demod.p, b->Mstride, M, C, CP, k, b->st, b->bb.p,
-                       Hbb, b->raw.p, b->mix.p, unsigned(d.hb[0].len - 1));
+                       d.table_size, b->lut_idx, b->st);
+    hipLaunchKernelGGL(fmd::k_demod_serial, dim3(CP / 64), dim3(128), 0, stream, b->demod.p,
+                       b->Mstride, M, C, CP, k, b->st, b->bb.p, Hbb, b->raw.p, b->mix.p,
+                       unsigned(d.hb[0].len - 1), b->sctab.p,
+                       FmdSincosTab{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo});
   }
   mark(2);
 

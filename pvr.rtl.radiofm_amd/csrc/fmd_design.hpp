@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <vector>
 
@@ -73,6 +74,9 @@ struct Design
   std::vector<float> rds_mf_taps;
   float rds_pll_alpha, rds_pll_beta, rds_nco_hl, rds_nco_ll;
   Biquad bitsync;
+  // (sin, cos)(k * 2pi / 1024) for the NCO evaluation (fmd_math.h: fmd_sincos_tab)
+  std::vector<double> sincos_tab;
+  double sct_inv_h, sct_h_hi, sct_h_lo;
 };
 
 // cFineTuner table (FmDecode.cpp:45-58): 2*(cos, sin) of ((shift*i) % size) * step
@@ -358,6 +362,26 @@ inline Design make_design(const Params& p)
     d.rds_mf_taps.assign(mc.begin(), mc.begin() + 2 * L); // first 2L of 2L+1 (:77)
     d.rds_lpf_taps = make_kaiser_lp(1.0f, 40.0f, 2400.0f, float(1.3 * 2400.0), d.rds_rate);
     d.bitsync = make_biquad(BQ_BP, float(bitrate), 500, d.rds_rate);
+  }
+  { // NCO sin/cos table, built in long double so every entry is the correctly rounded double
+    const long double twopi = 6.283185307179586476925286766559005768L;
+    const int n = 1024;
+    d.sincos_tab.resize(size_t(2) * n);
+    for (int k = 0; k < n; k++)
+    {
+      const long double a = twopi * k / (long double)n;
+      d.sincos_tab[size_t(2) * k] = double(sinl(a));
+      d.sincos_tab[size_t(2) * k + 1] = double(cosl(a));
+    }
+    const long double h = twopi / (long double)n;
+    d.sct_inv_h = double(1.0L / h);
+    double hd = double(h);
+    uint64_t u;
+    std::memcpy(&u, &hd, 8);
+    u &= ~((uint64_t(1) << 15) - 1); // 38 significant bits: k * h_hi is exact for |k| < 2^15
+    std::memcpy(&hd, &u, 8);
+    d.sct_h_hi = hd;
+    d.sct_h_lo = double(h - (long double)hd);
   }
   return d;
 }

@@ -216,154 +216,230 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, 
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* K2: everything that is a sample-by-sample recurrence at the baseband rate, one lane per     */
-/*     channel: RMSLevelApprox (FmDecode.cpp:505-519), the FM PLL demodulator (:362-415),       */
-/*     SamplesMeanRMS (:522-539), cPilotPhaseLock::Process (:143-229) with the 2*baseband       */
-/*     multiply (:455-456), and the RDS quadrature-oscillator mix (DownConvert.cpp:429-466).    */
+/* K2a: RMSLevelApprox (FmDecode.cpp:505-519) + EMA (:427).  One wave per channel: the lanes    */
+/*      form the |tuned sample|^2 terms (coalesced), lane 0 adds them in index order.           */
 /* ------------------------------------------------------------------------------------------ */
-__global__ __launch_bounds__(64) void k_demod_serial(
-    const float2* __restrict__ iq, size_t chan_stride, unsigned N, const float2* __restrict__ lut,
-    unsigned T, unsigned lut_idx0, const float2* __restrict__ demod, unsigned Mstride, unsigned M,
-    unsigned C, unsigned CP, DemodConsts k, ChannelState st, float* __restrict__ bb, unsigned Hbb,
-    float* __restrict__ raw, float2* __restrict__ mix, unsigned Hmix)
+__global__ __launch_bounds__(64) void k_if_level(const float2* __restrict__ iq, size_t chan_stride,
+                                                 unsigned N, const float2* __restrict__ lut,
+                                                 unsigned T, unsigned lut_idx0, ChannelState st)
 {
-  const unsigned c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C)
-    return;
-
-  { // IF level over the first ceil(N/64) tuned samples, EMA (FmDecode.cpp:427)
-    const unsigned n = (N + 63) / 64;
-    const float2* __restrict__ x = iq + (size_t)c * chan_stride;
-    const float2* __restrict__ l = lut + (size_t)c * T;
+  __shared__ float term[1024];
+  const unsigned c = blockIdx.x;
+  const unsigned n = (N + 63) / 64; // <= 1024 for N <= 65536
+  const float2* __restrict__ x = iq + (size_t)c * chan_stride;
+  const float2* __restrict__ l = lut + (size_t)c * T;
+  for (unsigned i = threadIdx.x; i < n; i += 64)
+  {
+    const float2 s = cmul(x[i], l[(lut_idx0 + i) % T]);
+    term[i] = s.x * s.x + s.y * s.y;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
     float level = 0.0f;
     for (unsigned i = 0; i < n; ++i)
-    {
-      const float2 s = cmul(x[i], l[(lut_idx0 + i) % T]);
-      level += s.x * s.x + s.y * s.y;
-    }
+      level += term[i];
     const float rms = sqrtf(level / (float)n);
     st.F(F_IF_LEVEL)[c] = 0.95f * st.F(F_IF_LEVEL)[c] + 0.05f * rms;
   }
+}
 
-  float nco_phase = st.F(F_NCO_PHASE)[c], nco_incr = st.F(F_NCO_INCR)[c], dc = st.F(F_DC_OFF)[c];
-  float p_i1 = st.F(F_P_I1)[c], p_i2 = st.F(F_P_I2)[c], p_q1 = st.F(F_P_Q1)[c], p_q2 = st.F(F_P_Q2)[c];
-  float p_x1 = st.F(F_P_X1)[c], p_freq = st.F(F_P_FREQ)[c], p_phase = st.F(F_P_PHASE)[c];
-  float p_level = 1000.0f; // FmDecode.cpp:147
-  float o_re = st.F(F_OSC_RE)[c], o_im = st.F(F_OSC_IM)[c];
-  float vsum = 0.0f, vsumsq = 0.0f;
+/* ------------------------------------------------------------------------------------------ */
+/* K2: everything that is a sample-by-sample recurrence at the baseband rate, one lane per     */
+/*     channel, 64 channels per workgroup.  The workgroup has TWO waves with different roles   */
+/*     (they sit on different SIMDs of the CU, so they issue in parallel):                      */
+/*       wave 0: FM PLL demodulator (FmDecode.cpp:362-415) -> baseband chunk in LDS             */
+/*       wave 1: SamplesMeanRMS (:522-539), cPilotPhaseLock::Process (:143-229) with the        */
+/*               2*baseband multiply (:455-456), RDS quadrature-oscillator mix                  */
+/*               (DownConvert.cpp:429-466), and all stores                                      */
+/*     Chunks of DS samples are double-buffered in LDS, one barrier per chunk.  A lone wave     */
+/*     issues one VALU op every ~4 cycles, so the longest role sets the time per sample.       */
+/* ------------------------------------------------------------------------------------------ */
+constexpr int DS = 32; // samples per LDS chunk
 
-  const float2* __restrict__ row = demod + (size_t)c * Mstride;
-  float* __restrict__ bbp = bb + (size_t)Hbb * CP + c;
-  float* __restrict__ rawp = raw + (size_t)Hbb * CP + c;
-  float2* __restrict__ mixp = mix + (size_t)Hmix * CP + c;
-  float2 cur = row[0];
-#pragma unroll 1
-  for (unsigned m = 0; m < M; m++)
+__global__ __launch_bounds__(128) void k_demod_serial(
+    const float2* __restrict__ demod, unsigned Mstride, unsigned M, unsigned C, unsigned CP,
+    DemodConsts k, ChannelState st, float* __restrict__ bb, unsigned Hbb, float* __restrict__ raw,
+    float2* __restrict__ mix, unsigned Hmix, const double* __restrict__ sctab_g, FmdSincosTab sct)
+{
+  __shared__ float chunk[2][DS][64];
+  __shared__ double sctab[2 * FMD_SINCOS_TAB_SIZE];
+  for (unsigned i = threadIdx.x; i < 2 * FMD_SINCOS_TAB_SIZE; i += 128)
+    sctab[i] = sctab_g[i];
+  __syncthreads();
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned role = threadIdx.x >> 6;
+  const unsigned c0 = blockIdx.x * 64 + lane;
+  const bool active = c0 < C;
+  const unsigned c = active ? c0 : C - 1; // padded lanes shadow the last channel, stores masked
+  const unsigned nchunks = (M + DS - 1) / DS;
+
+  if (role == 0)
   {
+    float nco_phase = st.F(F_NCO_PHASE)[c], nco_incr = st.F(F_NCO_INCR)[c], dc = st.F(F_DC_OFF)[c];
+    const float2* __restrict__ row = demod + (size_t)c * Mstride;
+    float2 cur = row[0];
+    for (unsigned j = 0; j <= nchunks; j++)
     {
-      const float2 nxt = row[(m + 1 < M) ? m + 1 : m]; // fetched one step ahead of its use
-      const float sre = cur.x, sim = cur.y;
-      cur = nxt;
-      /* ---- FM PLL (FmDecode.cpp:371-413) ---- */
-      float sn, cs;
-      fmd_sincos_nco(nco_phase, &sn, &cs);
-      const float dre = cs * sre - sn * sim; // ComplexType(Cos, Sin) * signal[i]
-      const float dim = cs * sim + sn * sre;
-      const float err = -fmd_atan2f_fast(dim, dre);
-      nco_incr += k.pll_beta * err;
-      if (nco_incr < k.nco_ll)
-        nco_incr = k.nco_ll;
-      if (nco_incr > k.nco_hl)
-        nco_incr = k.nco_hl;
-      nco_phase += nco_incr + k.pll_alpha * err;
-      if ((double)nco_phase >= FMD_K_2PI)
-        nco_phase = (float)fmod((double)nco_phase, FMD_K_2PI);
-      while (nco_phase < 0)
-        nco_phase = (float)((double)nco_phase + FMD_K_2PI);
-      const float pinc = 2 * nco_incr;
-      dc = (float)((1 - 0.0001) * (double)dc + 0.0001 * (double)pinc);
-      const float v = (pinc - dc) * k.demod_gain;
-      *bbp = v;
-      bbp += CP;
-      vsum += v;
-      vsumsq += v * v;
-
-      /* ---- pilot PLL (FmDecode.cpp:151-217) ---- */
-      float ps, pc;
-      fmd_sincos_nco(p_phase, &ps, &pc);
-      const float tone = 2 * ps * pc;
-      float ph_i = ps * v;
-      float ph_q = pc * v;
-      ph_i = k.p_b0 * ph_i - k.p_a1 * p_i1 - k.p_a2 * p_i2;
-      ph_q = k.p_b0 * ph_q - k.p_a1 * p_q1 - k.p_a2 * p_q2;
-      p_i2 = p_i1;
-      p_i1 = ph_i;
-      p_q2 = p_q1;
-      p_q1 = ph_q;
-      float perr;
-      if (ph_i > fabsf(ph_q))
-        perr = ph_q / ph_i;
-      else if (ph_q > 0)
-        perr = 1;
-      else
-        perr = -1;
-      p_level = (ph_i < p_level) ? ph_i : p_level;
-      p_freq += k.p_lf_b0 * perr + k.p_lf_b1 * p_x1;
-      p_x1 = perr;
+      if (j < nchunks)
       {
-        const float t = (p_freq < k.p_maxfreq) ? p_freq : k.p_maxfreq;
-        p_freq = (k.p_minfreq < t) ? t : k.p_minfreq;
+        const unsigned m0 = j * DS;
+        const unsigned cnt = min((unsigned)DS, M - m0);
+#pragma unroll 1
+        for (unsigned u = 0; u < cnt; u++)
+        {
+          const unsigned m = m0 + u;
+          const float2 nxt = row[(m + 1 < M) ? m + 1 : m]; // fetched one step ahead of its use
+          const float sre = cur.x, sim = cur.y;
+          cur = nxt;
+          /* ---- FM PLL (FmDecode.cpp:371-413) ---- */
+          float sn, cs;
+          fmd_sincos_tab(nco_phase, sctab, sct, &sn, &cs);
+          const float dre = cs * sre - sn * sim; // ComplexType(Cos, Sin) * signal[i]
+          const float dim = cs * sim + sn * sre;
+          const float err = -fmd_atan2f_fast(dim, dre);
+          nco_incr += k.pll_beta * err;
+          nco_incr = (nco_incr < k.nco_ll) ? k.nco_ll : nco_incr;
+          nco_incr = (nco_incr > k.nco_hl) ? k.nco_hl : nco_incr;
+          nco_phase += nco_incr + k.pll_alpha * err;
+          {
+            /* :404-407  if (phase >= 2pi) phase = fmod(phase, 2pi); while (phase < 0) phase += 2pi;
+             * For phase in [2pi, 4pi) fmod is the exact difference phase - 2pi, and for
+             * [-2pi, 0) the loop runs once; the clamps above keep every step inside
+             * (-2pi, 4pi), anything else takes the literal slow path. */
+            const double pd = (double)nco_phase;
+            const float down = (float)(pd - FMD_K_2PI);
+            const float up = (float)(pd + FMD_K_2PI);
+            const bool ge = pd >= FMD_K_2PI;
+            const bool lt = nco_phase < 0;
+            const float sel = ge ? down : (lt ? up : nco_phase);
+            if (__builtin_expect((pd >= 2.0 * FMD_K_2PI) | (pd < -FMD_K_2PI), 0))
+            {
+              if (ge)
+                nco_phase = (float)fmod(pd, FMD_K_2PI);
+              while (nco_phase < 0)
+                nco_phase = (float)((double)nco_phase + FMD_K_2PI);
+            }
+            else
+              nco_phase = sel;
+          }
+          const float pinc = 2 * nco_incr;
+          dc = (float)((1 - 0.0001) * (double)dc + 0.0001 * (double)pinc);
+          chunk[j & 1][u][lane] = (pinc - dc) * k.demod_gain;
+        }
       }
-      p_phase += p_freq;
-      if ((double)p_phase > FMD_K_2PI)
-        p_phase = (float)((double)p_phase - FMD_K_2PI);
-      *rawp = tone * (2 * v); // FmDecode.cpp:456
-      rawp += CP;
-
-      /* ---- RDS oscillator mix (DownConvert.cpp:436-442, :464-465), imag(input) == 0 ---- */
-      float2 osc;
-      osc.x = o_re * k.osc_cos - o_im * k.osc_sin;
-      osc.y = o_im * k.osc_cos + o_re * k.osc_sin;
-      const float gn = (float)(1.95 - (double)(o_re * o_re + o_im * o_im));
-      o_re = gn * osc.x;
-      o_im = gn * osc.y;
-      const float zero = 0.0f;
-      *mixp = make_float2((v * osc.x) - (zero * osc.y), (v * osc.y) + (zero * osc.x));
-      mixp += CP;
+      __syncthreads();
     }
-  }
-
-  st.F(F_NCO_PHASE)[c] = nco_phase;
-  st.F(F_NCO_INCR)[c] = nco_incr;
-  st.F(F_DC_OFF)[c] = dc;
-  st.F(F_P_I1)[c] = p_i1;
-  st.F(F_P_I2)[c] = p_i2;
-  st.F(F_P_Q1)[c] = p_q1;
-  st.F(F_P_Q2)[c] = p_q2;
-  st.F(F_P_X1)[c] = p_x1;
-  st.F(F_P_FREQ)[c] = p_freq;
-  st.F(F_P_PHASE)[c] = p_phase;
-  st.F(F_P_LEVEL)[c] = p_level;
-  st.F(F_OSC_RE)[c] = o_re;
-  st.F(F_OSC_IM)[c] = o_im;
-
-  { // lock status (FmDecode.cpp:219-228)
-    int cnt = st.I(I_P_LOCK_CNT)[c];
-    if (2 * p_level > k.p_minsignal)
+    if (active)
     {
-      if (cnt < k.p_lock_delay)
-        cnt += (int)M;
+      st.F(F_NCO_PHASE)[c] = nco_phase;
+      st.F(F_NCO_INCR)[c] = nco_incr;
+      st.F(F_DC_OFF)[c] = dc;
     }
-    else
-      cnt = 0;
-    st.I(I_P_LOCK_CNT)[c] = cnt;
-    st.I(I_STEREO)[c] = cnt >= k.p_lock_delay;
   }
-  { // baseband stats (FmDecode.cpp:439-442)
-    const float mean = vsum / (float)M;
-    const float rms = sqrtf(vsumsq / (float)M);
-    st.F(F_BB_MEAN)[c] = 0.95f * st.F(F_BB_MEAN)[c] + 0.05f * mean;
-    st.F(F_BB_LEVEL)[c] = 0.95f * st.F(F_BB_LEVEL)[c] + 0.05f * rms;
+  else
+  {
+    float p_i1 = st.F(F_P_I1)[c], p_i2 = st.F(F_P_I2)[c], p_q1 = st.F(F_P_Q1)[c], p_q2 = st.F(F_P_Q2)[c];
+    float p_x1 = st.F(F_P_X1)[c], p_freq = st.F(F_P_FREQ)[c], p_phase = st.F(F_P_PHASE)[c];
+    float p_level = 1000.0f; // FmDecode.cpp:147
+    float o_re = st.F(F_OSC_RE)[c], o_im = st.F(F_OSC_IM)[c];
+    float vsum = 0.0f, vsumsq = 0.0f;
+    float* __restrict__ bbp = bb + (size_t)Hbb * CP + c;
+    float* __restrict__ rawp = raw + (size_t)Hbb * CP + c;
+    float2* __restrict__ mixp = mix + (size_t)Hmix * CP + c;
+    for (unsigned j = 0; j <= nchunks; j++)
+    {
+      if (j >= 1)
+      {
+        const unsigned m0 = (j - 1) * DS;
+        const unsigned cnt = min((unsigned)DS, M - m0);
+#pragma unroll 1
+        for (unsigned u = 0; u < cnt; u++)
+        {
+          const float v = chunk[(j - 1) & 1][u][lane];
+          vsum += v;
+          vsumsq += v * v;
+          /* ---- pilot PLL (FmDecode.cpp:151-217) ---- */
+          float ps, pc;
+          fmd_sincos_tab(p_phase, sctab, sct, &ps, &pc);
+          const float tone = 2 * ps * pc;
+          float ph_i = ps * v;
+          float ph_q = pc * v;
+          ph_i = k.p_b0 * ph_i - k.p_a1 * p_i1 - k.p_a2 * p_i2;
+          ph_q = k.p_b0 * ph_q - k.p_a1 * p_q1 - k.p_a2 * p_q2;
+          p_i2 = p_i1;
+          p_i1 = ph_i;
+          p_q2 = p_q1;
+          p_q1 = ph_q;
+          /* :194-201 as selects; the quotient is formed unconditionally and only used in lock */
+          const float ratio = ph_q / ph_i;
+          const float sgn = (ph_q > 0) ? 1.0f : -1.0f;
+          const float perr = (ph_i > fabsf(ph_q)) ? ratio : sgn;
+          p_level = (ph_i < p_level) ? ph_i : p_level;
+          p_freq += k.p_lf_b0 * perr + k.p_lf_b1 * p_x1;
+          p_x1 = perr;
+          {
+            const float t = (p_freq < k.p_maxfreq) ? p_freq : k.p_maxfreq;
+            p_freq = (k.p_minfreq < t) ? t : k.p_minfreq;
+          }
+          p_phase += p_freq;
+          {
+            const double pd = (double)p_phase;
+            const float down = (float)(pd - FMD_K_2PI);
+            p_phase = (pd > FMD_K_2PI) ? down : p_phase; // :215-216
+          }
+          /* ---- RDS oscillator mix (DownConvert.cpp:436-442, :464-465), imag(input) == 0 ---- */
+          float2 osc;
+          osc.x = o_re * k.osc_cos - o_im * k.osc_sin;
+          osc.y = o_im * k.osc_cos + o_re * k.osc_sin;
+          const float gn = (float)(1.95 - (double)(o_re * o_re + o_im * o_im));
+          o_re = gn * osc.x;
+          o_im = gn * osc.y;
+          const float zero = 0.0f;
+          if (active)
+          {
+            *bbp = v;
+            *rawp = tone * (2 * v); // FmDecode.cpp:456
+            *mixp = make_float2((v * osc.x) - (zero * osc.y), (v * osc.y) + (zero * osc.x));
+          }
+          bbp += CP;
+          rawp += CP;
+          mixp += CP;
+        }
+      }
+      __syncthreads();
+    }
+    if (active)
+    {
+      st.F(F_P_I1)[c] = p_i1;
+      st.F(F_P_I2)[c] = p_i2;
+      st.F(F_P_Q1)[c] = p_q1;
+      st.F(F_P_Q2)[c] = p_q2;
+      st.F(F_P_X1)[c] = p_x1;
+      st.F(F_P_FREQ)[c] = p_freq;
+      st.F(F_P_PHASE)[c] = p_phase;
+      st.F(F_P_LEVEL)[c] = p_level;
+      st.F(F_OSC_RE)[c] = o_re;
+      st.F(F_OSC_IM)[c] = o_im;
+      { // lock status (FmDecode.cpp:219-228)
+        int cnt = st.I(I_P_LOCK_CNT)[c];
+        if (2 * p_level > k.p_minsignal)
+        {
+          if (cnt < k.p_lock_delay)
+            cnt += (int)M;
+        }
+        else
+          cnt = 0;
+        st.I(I_P_LOCK_CNT)[c] = cnt;
+        st.I(I_STEREO)[c] = cnt >= k.p_lock_delay;
+      }
+      { // baseband stats (FmDecode.cpp:439-442)
+        const float mean = vsum / (float)M;
+        const float rms = sqrtf(vsumsq / (float)M);
+        st.F(F_BB_MEAN)[c] = 0.95f * st.F(F_BB_MEAN)[c] + 0.05f * mean;
+        st.F(F_BB_LEVEL)[c] = 0.95f * st.F(F_BB_LEVEL)[c] + 0.05f * rms;
+      }
+    }
   }
 }
 

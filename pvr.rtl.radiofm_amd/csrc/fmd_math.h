@@ -264,11 +264,26 @@ FMD_HD float fmd_atanf_pos_fast(float x)
   const bool r1 = ix < 0x3f300000u; /* < 0.6875 */
   const bool r2 = ix < 0x3f980000u; /* < 1.1875 */
   const bool r3 = ix < 0x401c0000u; /* < 2.4375 */
-  /* numerator / denominator of the reduced argument */
-  float num = r0 ? x : (r1 ? (2.0f * x - 1.0f) : (r2 ? (x - 1.0f) : (r3 ? (x - 1.5f) : -1.0f)));
-  float den = r0 ? 1.0f : (r1 ? (2.0f + x) : (r2 ? (x + 1.0f) : (r3 ? (1.0f + 1.5f * x) : x)));
-  const float hi = r1 ? 4.6364760399e-01f : (r2 ? 7.8539812565e-01f : (r3 ? 9.8279368877e-01f : 1.5707962513e+00f));
-  const float lo = r1 ? 5.0121582440e-09f : (r2 ? 3.7748947079e-08f : (r3 ? 3.4473217170e-08f : 7.5497894159e-08f));
+  /* all candidate numerators / denominators are formed unconditionally (cheap, finite) so the
+   * choice compiles to selects, not exec-mask branches */
+  const float n1 = 2.0f * x - 1.0f, d1 = 2.0f + x;
+  const float n2 = x - 1.0f, d2 = x + 1.0f;
+  const float n3 = x - 1.5f, d3 = 1.0f + 1.5f * x;
+  float num = -1.0f, den = x, hi = 1.5707962513e+00f, lo = 7.5497894159e-08f;
+  num = r3 ? n3 : num;
+  den = r3 ? d3 : den;
+  hi = r3 ? 9.8279368877e-01f : hi;
+  lo = r3 ? 3.4473217170e-08f : lo;
+  num = r2 ? n2 : num;
+  den = r2 ? d2 : den;
+  hi = r2 ? 7.8539812565e-01f : hi;
+  lo = r2 ? 3.7748947079e-08f : lo;
+  num = r1 ? n1 : num;
+  den = r1 ? d1 : den;
+  hi = r1 ? 4.6364760399e-01f : hi;
+  lo = r1 ? 5.0121582440e-09f : lo;
+  num = r0 ? x : num;
+  den = r0 ? 1.0f : den;
   const float xr = num / den; /* x/1 is exact for the unreduced range */
   const float z = xr * xr;
   const float w = z * z;
@@ -299,6 +314,36 @@ FMD_HD float fmd_atan2f_fast(float y, float x)
   const float neg = fmd_u2f(fmd_f2u(z) ^ 0x80000000u);
   const bool ysign = (hy >> 31) != 0, xsign = (hx >> 31) != 0;
   return xsign ? (ysign ? (t - pi) : (pi - t)) : (ysign ? neg : z);
+}
+
+/* Table-driven variant of fmd_sincos_nco for the per-sample loops: 1024-entry table of
+ * (sin, cos)(k*2pi/1024) in double (built on the host in long double), argument split
+ * phase = k*h + r with |r| <= h/2 = 0.0031 by a two-term Cody-Waite step, then
+ * sin(kh+r) = S + (S*cm1 + C*sr), cos(kh+r) = C + (C*cm1 - S*sr) with the short series
+ * sr = r - r^3/6 + r^5/120, cm1 = -r^2/2 + r^4/24 (truncation < 2e-18).  21 FP64 ops, no
+ * quadrant logic; result rounded once to float like fmd_sincos_nco. */
+struct FmdSincosTab
+{
+  double inv_h, h_hi, h_lo;
+};
+#define FMD_SINCOS_TAB_SIZE 1024
+FMD_HD void fmd_sincos_tab(float phase, const double* tab /* [1024][2] */, struct FmdSincosTab t,
+                           float* s, float* c)
+{
+  const double x = (double)phase;
+  const double kf = __builtin_rint(x * t.inv_h);
+  const int k = (int)kf;
+  double r = __builtin_fma(-kf, t.h_hi, x);
+  r = __builtin_fma(-kf, t.h_lo, r);
+  const double S = tab[2 * (k & (FMD_SINCOS_TAB_SIZE - 1))];
+  const double C = tab[2 * (k & (FMD_SINCOS_TAB_SIZE - 1)) + 1];
+  const double r2 = r * r;
+  const double sr = __builtin_fma(r * r2, __builtin_fma(r2, 1.0 / 120.0, -1.0 / 6.0), r);
+  const double cm1 = r2 * __builtin_fma(r2, 1.0 / 24.0, -0.5);
+  const double so = S + __builtin_fma(C, sr, S * cm1);
+  const double co = C + __builtin_fma(-S, sr, C * cm1);
+  *s = (float)so;
+  *c = (float)co;
 }
 
 /* RDSProcess.cpp:187-217 */
