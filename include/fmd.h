@@ -153,6 +153,9 @@ enum fmd_tap
   FMD_TAP_RDS_SYNC = 8
 };
 int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsigned cap_floats);
+/* The three RDS-recurrence taps (PLL, matched filter, bit sync) cost extra stores per sample and
+ * are only written while enabled (default off). */
+int fmd_batch_set_debug_taps(fmd_batch* b, int enable);
 
 /* Design constants / taps as the host computed them (for parity with the oracle). */
 int fmd_batch_get_design(fmd_batch* b, int what, float* out, unsigned cap);

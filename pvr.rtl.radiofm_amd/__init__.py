@@ -78,7 +78,7 @@ EXPORTS = [
     "fmd_batch_create", "fmd_batch_destroy", "fmd_batch_reset", "fmd_batch_channels",
     "fmd_batch_max_audio_floats", "fmd_batch_process_device", "fmd_batch_process_host",
     "fmd_batch_collect_rds", "fmd_batch_get_status", "fmd_batch_get_tap", "fmd_batch_get_design",
-    "fmd_batch_set_profiling", "fmd_batch_get_stage_ms", "fmd_stage_name", "fmd_last_error",
+    "fmd_batch_set_debug_taps", "fmd_batch_set_profiling", "fmd_batch_get_stage_ms", "fmd_stage_name", "fmd_last_error",
     "fmd_version", "fmd_group_decoder_create", "fmd_group_decoder_destroy",
     "fmd_group_decoder_reset", "fmd_group_decoder_push", "fmd_uecp_stuff_frame",
 ]
@@ -126,6 +126,7 @@ def lib():
         L.fmd_batch_get_tap.argtypes = [vp, i, u, vp, u]
         L.fmd_batch_get_design.argtypes = [vp, i, vp, u]
         L.fmd_batch_set_profiling.argtypes = [vp, i]
+        L.fmd_batch_set_debug_taps.argtypes = [vp, i]
         L.fmd_batch_get_stage_ms.argtypes = [vp, vp, u]
         L.fmd_group_decoder_create.restype = vp
         L.fmd_group_decoder_create.argtypes = [C.POINTER(FmdCallbacks), vp, u]
@@ -247,6 +248,9 @@ class Batch:
         if name in ("demod", "rds_lpf"):
             return buf[:2 * n].view(np.complex64).copy()
         return buf[:n].copy()
+
+    def enable_taps(self, on=True):
+        _check(lib().fmd_batch_set_debug_taps(self._h, int(on)))
 
     def design(self, name):
         buf = np.zeros(16384, dtype=np.float32)

@@ -91,7 +91,7 @@ struct fmd_batch
   unsigned lut_idx = 0;    // cFineTuner::m_index
   float rs_pos = 0.0f;     // cDownsampleFilter::m_pos_frac (mono == stereo)
   unsigned rds_lpf_g = 0;  // samples since init of the RDS LPF, mod taps
-  int mf_state = 0;        // cFirFilter::m_State of the matched filter
+  unsigned mf_g = 0;       // samples since init of the RDS matched filter, mod taps
   unsigned alpf_g = 0;     // samples since init of the audio LPF, mod taps
   int hist_sel = 0;        // IF history ping-pong
   uint32_t call_index = 0;
@@ -103,16 +103,15 @@ struct fmd_batch
   unsigned lastM = 0, lastA = 0, lastR = 0;
 
   // device memory
-  DevBuf<float2> lut, hist[2], demod, mix, rdsraw, rlpf, rs, alp;
+  DevBuf<float2> lut, hist[2], demod, br, mix, rdsraw, rlpf, rs, alp;
   std::vector<DevBuf<float2>> hbbuf; // input buffers of stages 1..n-1 (stage 0 reads mix)
-  DevBuf<float> if_coeff, rs_coeff, bb, raw, rds_lpf_taps, mf_taps2, audio_taps, ktab;
-  DevBuf<float> tap_pll, tap_mf, tap_sync;
+  DevBuf<float> if_coeff, rs_coeff, rds_lpf_taps, mf_taps2, audio_taps, ktab;
+  DevBuf<float> rpll, rmf, tap_sync;
   DevBuf<double> sctab;
   DevBuf<int> pidx;
   DevBuf<float> fstate; // all float state arrays, CP each
   DevBuf<int> istate;
   DevBuf<uint16_t> r_data;
-  DevBuf<float> mfring;
   DevBuf<fmd::RdsGroupRec> queue;
   DevBuf<unsigned> queue_count;
   unsigned queue_cap = 0;
@@ -128,6 +127,7 @@ struct fmd_batch
   // profiling: 0 off, 1 = events around the IF FIR kernel only, 2 = around every stage.
   // One event set per call (up to kMaxProfCalls) so nothing has to synchronise inside a timed loop.
   int profiling = 0;
+  int write_taps = 0; // stage taps of the RDS recurrences are only written on request
   std::vector<hipEvent_t> ev; // [calls][ST_COUNT + 1]
   unsigned prof_calls = 0;
 
@@ -147,21 +147,19 @@ struct fmd_batch
       b.release();
     if_coeff.release();
     rs_coeff.release();
-    bb.release();
-    raw.release();
+    br.release();
     rds_lpf_taps.release();
     mf_taps2.release();
     audio_taps.release();
     ktab.release();
-    tap_pll.release();
-    tap_mf.release();
+    rpll.release();
+    rmf.release();
     tap_sync.release();
     sctab.release();
     pidx.release();
     fstate.release();
     istate.release();
     r_data.release();
-    mfring.release();
     queue.release();
     queue_count.release();
     h_iq.release();
@@ -186,7 +184,6 @@ void bind_state(fmd_batch* b)
   b->st.f = b->fstate.p;
   b->st.i = b->istate.p;
   b->st.r_data = b->r_data.p;
-  b->st.r_mfring = b->mfring.p;
   b->st.CP = b->CP;
 }
 
@@ -231,10 +228,10 @@ int do_reset(fmd_batch* b)
   // RDS LPF ring (history rows of rdsraw), matched filter ring, positions
   if (zero_rows(b->rdsraw.p, b->des.rds_lpf_taps.size() - 1, CP))
     return -1;
-  if (hipMemset(b->mfring.p, 0, b->mfring.n * sizeof(float)) != hipSuccess)
+  if (zero_rows(b->rpll.p, b->des.rds_mf_taps.size() - 1, CP))
     return -1;
   b->rds_lpf_g = 0;
-  b->mf_state = 0;
+  b->mf_g = 0;
   for (auto& g : b->gdec)
     if (g)
       g->reset();
@@ -345,8 +342,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->demod.alloc(size_t(b->Mstride) * C);
   bad |= b->if_coeff.alloc(d.if_coeff.size());
   bad |= b->rs_coeff.alloc(d.rs_coeff.size());
-  bad |= b->bb.alloc(size_t(d.rs_order + b->Mmax) * CP);
-  bad |= b->raw.alloc(size_t(d.rs_order + b->Mmax) * CP);
+  bad |= b->br.alloc(size_t(d.rs_order + b->Mmax) * CP);
   if (d.hb.empty())
     return fail(FMD_ERR_ARG, "baseband rate too low for the RDS decimation chain");
   bad |= b->mix.alloc(size_t(d.hb[0].len - 1 + b->Mmax) * CP);
@@ -355,8 +351,8 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     bad |= b->hbbuf[s - 1].alloc(size_t(d.hb[s].len - 1 + b->hb_nmax[s]) * CP);
   bad |= b->rdsraw.alloc(size_t(T_lpf - 1 + b->Rmax) * CP);
   bad |= b->rlpf.alloc(size_t(b->Rmax) * CP);
-  bad |= b->tap_pll.alloc(size_t(b->Rmax) * CP);
-  bad |= b->tap_mf.alloc(size_t(b->Rmax) * CP);
+  bad |= b->rpll.alloc(size_t(T_mf - 1 + b->Rmax) * CP);
+  bad |= b->rmf.alloc(size_t(b->Rmax) * CP);
   bad |= b->tap_sync.alloc(size_t(b->Rmax) * CP);
   bad |= b->rs.alloc(size_t(T_alp - 1 + b->Amax) * CP);
   bad |= b->alp.alloc(size_t(b->Amax) * CP);
@@ -369,7 +365,6 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->fstate.alloc(size_t(fmd::F_SLOTS) * CP);
   bad |= b->istate.alloc(size_t(fmd::I_SLOTS) * CP);
   bad |= b->r_data.alloc(size_t(4) * CP);
-  bad |= b->mfring.alloc(size_t(T_mf) * CP);
   b->queue_cap = std::max(4096u, 8u * C);
   bad |= b->queue.alloc(b->queue_cap);
   bad |= b->queue_count.alloc(1);
@@ -382,12 +377,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= upload(b->rds_lpf_taps.p, d.rds_lpf_taps.data(), T_lpf * sizeof(float));
   bad |= upload(b->audio_taps.p, d.lpf_taps.data(), T_alp * sizeof(float));
   bad |= upload(b->sctab.p, d.sincos_tab.data(), d.sincos_tab.size() * sizeof(double));
-  {
-    std::vector<float> t2(size_t(2) * T_mf);
-    for (unsigned i = 0; i < 2 * T_mf; i++)
-      t2[i] = d.rds_mf_taps[i % T_mf];
-    bad |= upload(b->mf_taps2.p, t2.data(), t2.size() * sizeof(float));
-  }
+  bad |= upload(b->mf_taps2.p, d.rds_mf_taps.data(), T_mf * sizeof(float));
   for (const auto& h : d.hb)
   {
     fmd::HbCoef hc{};
@@ -560,7 +550,7 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
                        reinterpret_cast<const float2*>(d_iq), iq_channel_stride, N, b->lut.p,
                        d.table_size, b->lut_idx, b->st);
     hipLaunchKernelGGL(fmd::k_demod_serial, dim3(CP / 64), dim3(128), 0, stream, b->demod.p,
-                       b->Mstride, M, C, CP, k, b->st, b->bb.p, Hbb, b->raw.p, b->mix.p,
+                       b->Mstride, M, C, CP, k, b->st, b->br.p, Hbb, b->mix.p,
                        unsigned(d.hb[0].len - 1), b->sctab.p,
                        FmdSincosTab{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo});
   }
@@ -575,7 +565,8 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
       const bool last = (s + 1 == d.hb.size());
       float2* outp = last ? b->rdsraw.p : b->hbbuf[s].p;
       const unsigned Hout = last ? (T_lpf - 1) : unsigned(d.hb[s + 1].len - 1);
-      hipLaunchKernelGGL(fmd::k_halfband, dim3(CP / 64, (n_out + 3) / 4), dim3(64, 4), 0, stream, in,
+      hipLaunchKernelGGL(fmd::k_halfband, dim3(CP / 64, (n_out + 4 * fmd::HB_R - 1) / (4 * fmd::HB_R)),
+                         dim3(64, 4), 0, stream, in,
                          outp, n_out, d.hb[s].len, b->hbcoef[s], C, CP, Hout);
       in = outp;
     }
@@ -583,8 +574,9 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
   mark(3);
 
   /* ---- K4: RDS 75-tap low-pass ---- */
-  hipLaunchKernelGGL(fmd::k_ring_fir, dim3(CP / 64, (R + 3) / 4), dim3(64, 4), 0, stream,
-                     b->rdsraw.p, b->rlpf.p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C, CP, 0u);
+  hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
+                     size_t(T_lpf - 1 + fmd::RF_TI) * 64 * sizeof(float2), stream, b->rdsraw.p,
+                     b->rlpf.p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C, CP, 0u);
   mark(4);
 
   /* ---- K5: RDS recurrences and block sync ---- */
@@ -600,23 +592,30 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
     k.bs_a1 = d.bitsync.a1;
     k.bs_a2 = d.bitsync.a2;
     k.mf_taps = int(T_mf);
-    hipLaunchKernelGGL(fmd::k_rds_serial, dim3(CP / 64), dim3(64), size_t(T_mf) * 64 * sizeof(float),
-                       stream, b->rlpf.p, R, C, CP, k, b->mf_taps2.p, b->mf_state, b->st,
-                       b->call_index, b->queue.p, b->queue_count.p, b->queue_cap, b->tap_pll.p,
-                       b->tap_mf.p, b->tap_sync.p);
+    const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
+    hipLaunchKernelGGL(fmd::k_rds_pll, dim3(CP / 64), dim3(64), 0, stream, b->rlpf.p, R, C, CP, k,
+                       b->st, b->rpll.p, T_mf - 1, b->sctab.p, sct);
+    hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI),
+                       dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), stream,
+                       b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C, CP, 0u);
+    hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, stream, b->rmf.p, R, C, CP, k,
+                       b->st, b->call_index, b->queue.p, b->queue_count.p, b->queue_cap,
+                       b->tap_sync.p, b->write_taps);
   }
   mark(5);
 
   /* ---- K6/K7: fractional resamplers (mono + stereo) ---- */
   hipLaunchKernelGGL(fmd::k_rs_table, dim3(A), dim3(64), 0, stream, b->rs_coeff.p, d.rs_order, p,
                      pstep, A, b->ktab.p, b->pidx.p);
-  hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 3) / 4), dim3(64, 4), 0, stream, b->bb.p,
-                     b->raw.p, Hbb, d.rs_order, b->ktab.p, b->pidx.p, A, b->rs.p, T_alp - 1, C, CP);
+  hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
+                     dim3(64, 4), 0, stream, b->br.p, Hbb, d.rs_order, b->ktab.p, b->pidx.p, A,
+                     b->rs.p, T_alp - 1, C, CP);
   mark(6);
 
   /* ---- audio 15 kHz low-pass on the (stereo, mono) pair ---- */
-  hipLaunchKernelGGL(fmd::k_ring_fir, dim3(CP / 64, (A + 3) / 4), dim3(64, 4), 0, stream, b->rs.p,
-                     b->alp.p, A, int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
+  hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (A + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
+                     size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), stream, b->rs.p, b->alp.p, A,
+                     int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
   mark(7);
 
   /* ---- K8: de-emphasis, notch, L/R ---- */
@@ -635,15 +634,19 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
 
   /* ---- history rolls: keep the last H rows of every windowed buffer for the next call ---- */
   {
-    const dim3 g((CP + 255) / 256), t(256);
-    hipLaunchKernelGGL(fmd::k_roll<float>, g, t, 0, stream, b->bb.p, Hbb, M, CP);
-    hipLaunchKernelGGL(fmd::k_roll<float>, g, t, 0, stream, b->raw.p, Hbb, M, CP);
-    hipLaunchKernelGGL(fmd::k_roll<float2>, g, t, 0, stream, b->mix.p, unsigned(d.hb[0].len - 1), hb_in[0], CP);
+    const dim3 t(256);
+    auto grid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
+    hipLaunchKernelGGL(fmd::k_roll<float2>, grid(Hbb), t, 0, stream, b->br.p, Hbb, M, CP);
+    const unsigned H0 = unsigned(d.hb[0].len - 1);
+    hipLaunchKernelGGL(fmd::k_roll<float2>, grid(H0), t, 0, stream, b->mix.p, H0, hb_in[0], CP);
     for (size_t s = 1; s < d.hb.size(); s++)
-      hipLaunchKernelGGL(fmd::k_roll<float2>, g, t, 0, stream, b->hbbuf[s - 1].p,
-                         unsigned(d.hb[s].len - 1), hb_in[s], CP);
-    hipLaunchKernelGGL(fmd::k_roll<float2>, g, t, 0, stream, b->rdsraw.p, T_lpf - 1, R, CP);
-    hipLaunchKernelGGL(fmd::k_roll<float2>, g, t, 0, stream, b->rs.p, T_alp - 1, A, CP);
+    {
+      const unsigned Hs = unsigned(d.hb[s].len - 1);
+      hipLaunchKernelGGL(fmd::k_roll<float2>, grid(Hs), t, 0, stream, b->hbbuf[s - 1].p, Hs, hb_in[s], CP);
+    }
+    hipLaunchKernelGGL(fmd::k_roll<float2>, grid(T_lpf - 1), t, 0, stream, b->rdsraw.p, T_lpf - 1, R, CP);
+    hipLaunchKernelGGL(fmd::k_roll<float>, grid(T_mf - 1), t, 0, stream, b->rpll.p, T_mf - 1, R, CP);
+    hipLaunchKernelGGL(fmd::k_roll<float2>, grid(T_alp - 1), t, 0, stream, b->rs.p, T_alp - 1, A, CP);
   }
   mark(9);
   HIPCHK(hipGetLastError());
@@ -653,9 +656,7 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
   b->lut_idx = (b->lut_idx + N) % d.table_size;     // FmDecode.cpp:81
   b->rs_pos = new_rs_pos;                           // DownConvert.cpp:230-232
   b->rds_lpf_g = (b->rds_lpf_g + R) % T_lpf;
-  b->mf_state = int(((long long)b->mf_state - (long long)R) % (long long)T_mf);
-  if (b->mf_state < 0)
-    b->mf_state += int(T_mf);
+  b->mf_g = (b->mf_g + R) % T_mf;
   b->alpf_g = (b->alpf_g + A) % T_alp;
   b->hist_sel ^= 1;
   b->lastM = M;
@@ -722,7 +723,7 @@ int fmd_batch_process_host(fmd_batch* b, const float* iq, size_t iq_channel_stri
   const unsigned C = b->C;
   const size_t dev_iq_stride = iq_channel_stride ? samples : 0;
   const size_t iq_floats = size_t(2) * samples * (iq_channel_stride ? C : 1);
-  const size_t a_stride = fmd_batch_max_audio_floats(b, samples);
+  const size_t a_stride = (size_t(fmd_batch_max_audio_floats(b, samples)) + 3) & ~size_t(3);
   if (iq_floats > b->h_iq_cap)
   {
     b->h_iq.release();
@@ -806,15 +807,17 @@ int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsig
     /* windowed buffers were rolled at the end of the call: the block's rows are still in place
      * at [H, H+n) except the first H rows region, which now holds the tail -- read the data rows */
     case FMD_TAP_BASEBAND:
-      src = b->bb.p;
-      first_row = b->des.rs_order;
-      rows = b->lastM;
-      break;
     case FMD_TAP_PILOT38:
-      src = b->raw.p;
-      first_row = b->des.rs_order;
+    {
       rows = b->lastM;
-      break;
+      if (rows > cap_floats)
+        return fail(FMD_ERR_ARG, "tap buffer too small");
+      const char* s0 = reinterpret_cast<const char*>(b->br.p) +
+                       (size_t(b->des.rs_order) * CP + channel) * 8 + (tap == FMD_TAP_PILOT38 ? 4 : 0);
+      if (rows)
+        HIPCHK(hipMemcpy2D(out, 4, s0, CP * 8, 4, rows, hipMemcpyDeviceToHost));
+      return int(rows);
+    }
     case FMD_TAP_MONO_RS:
     case FMD_TAP_STEREO_RS:
       src = reinterpret_cast<const float*>(b->rs.p) + (tap == FMD_TAP_MONO_RS ? 1 : 0);
@@ -834,14 +837,17 @@ int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsig
       rows = b->lastR;
       break;
     case FMD_TAP_RDS_PLL:
-      src = b->tap_pll.p;
+      src = b->rpll.p;
+      first_row = b->des.rds_mf_taps.size() - 1;
       rows = b->lastR;
       break;
     case FMD_TAP_RDS_MF:
-      src = b->tap_mf.p;
+      src = b->rmf.p;
       rows = b->lastR;
       break;
     case FMD_TAP_RDS_SYNC:
+      if (!b->write_taps)
+        return fail(FMD_ERR_STATE, "RDS taps need fmd_batch_set_debug_taps(b, 1) before the call");
       src = b->tap_sync.p;
       rows = b->lastR;
       break;
@@ -898,6 +904,14 @@ int fmd_batch_get_design(fmd_batch* b, int what, float* out, unsigned cap)
   for (size_t i = 0; i < v.size() && i < cap; i++)
     out[i] = v[i];
   return int(v.size());
+}
+
+int fmd_batch_set_debug_taps(fmd_batch* b, int enable)
+{
+  if (!b)
+    return fail(FMD_ERR_ARG, "null batch");
+  b->write_taps = enable != 0;
+  return FMD_OK;
 }
 
 int fmd_batch_set_profiling(fmd_batch* b, int level)

@@ -72,7 +72,6 @@ struct ChannelState
   float* f;         // [F_SLOTS][CP]
   int* i;           // [I_SLOTS][CP]
   uint16_t* r_data; // [4][CP]   block words of the group being assembled
-  float* r_mfring;  // [mf_taps][CP] matched-filter ring
   unsigned CP;
   __host__ __device__ float* F(int slot) const { return f + (size_t)slot * CP; }
   __host__ __device__ int* I(int slot) const { return i + (size_t)slot * CP; }
@@ -259,7 +258,7 @@ constexpr int DS = 32; // samples per LDS chunk
 
 __global__ __launch_bounds__(128) void k_demod_serial(
     const float2* __restrict__ demod, unsigned Mstride, unsigned M, unsigned C, unsigned CP,
-    DemodConsts k, ChannelState st, float* __restrict__ bb, unsigned Hbb, float* __restrict__ raw,
+    DemodConsts k, ChannelState st, float2* __restrict__ br, unsigned Hbb,
     float2* __restrict__ mix, unsigned Hmix, const double* __restrict__ sctab_g, FmdSincosTab sct)
 {
   __shared__ float chunk[2][DS][64];
@@ -344,8 +343,7 @@ __global__ __launch_bounds__(128) void k_demod_serial(
     float p_level = 1000.0f; // FmDecode.cpp:147
     float o_re = st.F(F_OSC_RE)[c], o_im = st.F(F_OSC_IM)[c];
     float vsum = 0.0f, vsumsq = 0.0f;
-    float* __restrict__ bbp = bb + (size_t)Hbb * CP + c;
-    float* __restrict__ rawp = raw + (size_t)Hbb * CP + c;
+    float2* __restrict__ brp = br + (size_t)Hbb * CP + c; // (baseband, 38 kHz * 2 * baseband)
     float2* __restrict__ mixp = mix + (size_t)Hmix * CP + c;
     for (unsigned j = 0; j <= nchunks; j++)
     {
@@ -398,12 +396,10 @@ __global__ __launch_bounds__(128) void k_demod_serial(
           const float zero = 0.0f;
           if (active)
           {
-            *bbp = v;
-            *rawp = tone * (2 * v); // FmDecode.cpp:456
+            *brp = make_float2(v, tone * (2 * v)); // FmDecode.cpp:456
             *mixp = make_float2((v * osc.x) - (zero * osc.y), (v * osc.y) + (zero * osc.x));
           }
-          bbp += CP;
-          rawp += CP;
+          brp += CP;
           mixp += CP;
         }
       }
@@ -453,29 +449,65 @@ struct HbCoef
   float c[52];
 };
 
+constexpr int HB_R = 4; // outputs per thread: each even input row is loaded once for up to 4 outputs
+
 __global__ __launch_bounds__(256) void k_halfband(const float2* __restrict__ in,
                                                   float2* __restrict__ out, unsigned n_out, int L,
                                                   HbCoef hc, unsigned C, unsigned CP, unsigned Hout)
 {
   const unsigned c = blockIdx.x * 64 + threadIdx.x;
-  const unsigned kk = blockIdx.y * blockDim.y + threadIdx.y;
-  if (c >= C || kk >= n_out)
+  // threadIdx.y is the same for all 64 lanes of a wave; saying so keeps tap/table loads scalar
+  const unsigned wy = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
+  const unsigned k0 = (blockIdx.y * blockDim.y + wy) * HB_R;
+  if (c >= C || k0 >= n_out)
     return;
-  const float2* __restrict__ p = in + (size_t)(2 * kk) * CP + c;
-  const int mid = (L - 1) / 2;
-  float2 x = p[0];
-  float ar = x.x * hc.c[0];
-  float ai = x.y * hc.c[0];
-  for (int j = 0; j < L; j += 2)
+  const int nr = (int)min((unsigned)HB_R, n_out - k0);
+  const int half = (L - 1) / 2; // index of the last even tap is 2*half' with half' = (L-1)/2
+  const int mid = half;
+  const float2* __restrict__ p = in + (size_t)(2 * k0) * CP + c;
+  float ar[HB_R], ai[HB_R];
+  // even rows e = 2*k0 + 2*u feed output r with tap j = 2*(u - r), in ascending j per output
+  const int nu = half + nr; // u = 0 .. half + nr - 1
+  for (int u0 = 0; u0 < nu; u0 += 4)
   {
-    x = p[(size_t)j * CP];
-    ar = ar + x.x * hc.c[j];
-    ai = ai + x.y * hc.c[j];
+    float2 xs[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) // four independent loads in flight (index clamped, not branched)
+      xs[q] = p[(size_t)(2 * min(u0 + q, nu - 1)) * CP];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+      const int u = u0 + q;
+      const float2 x = xs[q];
+#pragma unroll
+      for (int r = 0; r < HB_R; r++)
+      {
+        const int jh = u - r;
+        if (u < nu && r < nr && jh >= 0 && jh <= half)
+        {
+          const float cj = hc.c[2 * jh];
+          if (jh == 0)
+          { // :529-530 tap 0 initialises the accumulator and is then added again in the loop
+            ar[r] = x.x * cj;
+            ai[r] = x.y * cj;
+          }
+          ar[r] = ar[r] + x.x * cj;
+          ai[r] = ai[r] + x.y * cj;
+        }
+      }
+    }
   }
-  x = p[(size_t)mid * CP];
-  ar = ar + x.x * hc.c[mid];
-  ai = ai + x.y * hc.c[mid];
-  out[(size_t)(Hout + kk) * CP + c] = make_float2(ar, ai);
+#pragma unroll
+  for (int r = 0; r < HB_R; r++)
+  {
+    if (r < nr)
+    {
+      const float2 x = p[(size_t)(2 * r + mid) * CP];
+      ar[r] = ar[r] + x.x * hc.c[mid];
+      ai[r] = ai[r] + x.y * hc.c[mid];
+      out[(size_t)(Hout + k0 + r) * CP + c] = make_float2(ar[r], ai[r]);
+    }
+  }
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -485,37 +517,61 @@ __global__ __launch_bounds__(256) void k_halfband(const float2* __restrict__ in,
 /*     with a0 = g mod T, starting from the first product (no leading zero).  in has T-1        */
 /*     history rows in front (zeros after init).  I and Q taps are the same table.              */
 /* ------------------------------------------------------------------------------------------ */
-__global__ __launch_bounds__(256) void k_ring_fir(const float2* __restrict__ in,
-                                                  float2* __restrict__ out, unsigned n, int T,
-                                                  const float* __restrict__ taps, unsigned g0,
-                                                  unsigned C, unsigned CP, unsigned Hout)
+constexpr int RF_TI = 32; // outputs per workgroup tile
+
+__device__ __forceinline__ float rf_mul(float k, float x) { return k * x; }
+__device__ __forceinline__ float2 rf_mul(float k, float2 x) { return make_float2(k * x.x, k * x.y); }
+__device__ __forceinline__ void rf_acc(float& a, float k, float x) { a += k * x; }
+__device__ __forceinline__ void rf_acc(float2& a, float k, float2 x)
 {
-  const unsigned c = blockIdx.x * 64 + threadIdx.x;
-  const unsigned i = blockIdx.y * blockDim.y + threadIdx.y;
-  if (c >= C || i >= n)
+  a.x += k * x.x;
+  a.y += k * x.y;
+}
+
+/* Workgroup = 64 channels x RF_TI outputs.  The T-1+RF_TI input rows of the tile are staged once
+ * in LDS ([row][channel]: conflict-free reads), because every input row is needed by T different
+ * outputs and re-reading it from L2 for each made the kernel L2-bandwidth bound.
+ * E = float2 for the complex / two-stream filters, float for the RDS matched filter. */
+template <typename E>
+__global__ __launch_bounds__(256) void k_ring_fir(const E* __restrict__ in, E* __restrict__ out,
+                                                  unsigned n, int T, const float* __restrict__ taps,
+                                                  unsigned g0, unsigned C, unsigned CP, unsigned Hout)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char rtile_raw[];
+  E* rtile = reinterpret_cast<E*>(rtile_raw); // [T - 1 + RF_TI][64]
+  const unsigned lane = threadIdx.x;
+  const unsigned y = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y); // 0..3, wave-uniform
+  const unsigned c0 = blockIdx.x * 64 + lane;
+  const unsigned c = c0 < C ? c0 : C - 1;
+  const unsigned i0 = blockIdx.y * RF_TI;
+  const unsigned nt = min((unsigned)RF_TI, n - i0);
+  const unsigned rows = (unsigned)T - 1 + nt;
+  // buffer row of x[i - a] is (T-1 + i - a); the tile starts at buffer row i0
+  for (unsigned r = y; r < rows; r += 4)
+    rtile[r * 64 + lane] = in[(size_t)(i0 + r) * CP + c];
+  __syncthreads();
+  if (c0 >= C)
     return;
-  // row of x[i - a] is (T-1 + i - a)
-  const float2* __restrict__ p = in + (size_t)(T - 1 + i) * CP + c;
-  int a = (int)((g0 + i) % (unsigned)T);
-  float2 x = p[-(ptrdiff_t)a * CP];
-  float ar = taps[a] * x.x;
-  float ai = taps[a] * x.y;
-  for (int s = 1; s < T; s++)
+  for (unsigned q = y; q < nt; q += 4)
   {
-    a = (a + 1 == T) ? 0 : a + 1;
-    x = p[-(ptrdiff_t)a * CP];
-    ar += taps[a] * x.x;
-    ai += taps[a] * x.y;
+    const unsigned i = i0 + q;
+    const int a0 = (int)((g0 + i) % (unsigned)T);
+    // newest sample (age 0) sits at tile row T-1+q; age a at row T-1+q-a
+    const E* base = rtile + (size_t)((unsigned)T - 1 + q) * 64 + lane;
+    E acc = rf_mul(taps[a0], base[-(ptrdiff_t)a0 * 64]);
+#pragma unroll 4
+    for (int a = a0 + 1; a < T; a++) // ages a0+1 .. T-1
+      rf_acc(acc, taps[a], base[-(ptrdiff_t)a * 64]);
+#pragma unroll 4
+    for (int a = 0; a < a0; a++) // then the ring wraps: ages 0 .. a0-1
+      rf_acc(acc, taps[a], base[-(ptrdiff_t)a * 64]);
+    out[(size_t)(Hout + i) * CP + c] = acc;
   }
-  out[(size_t)(Hout + i) * CP + c] = make_float2(ar, ai);
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* K5: RDS recurrences at the RDS rate, one lane per channel: ProcessRdsPll                      */
-/*     (RDSProcess.cpp:222-270), matched filter cFirFilter::Process(real) with its ring buffer   */
-/*     kept per lane in HBM-backed state (FirFilter.cpp:360-377), squaring + bit-sync resonator  */
-/*     (RDSProcess.cpp:137-142, IirFilter.cpp:78-87), peak slicer (:144-179), ProcessNewRdsBit   */
-/*     (:272-375) and CheckBlock with Meggitt FEC (:377-431).                                    */
+/* K5: RDS recurrences at the RDS rate.  The matched filter between the two serial kernels     */
+/*     (cFirFilter::Process(real), FirFilter.cpp:360-377) runs time-parallel in k_ring_fir.      */
 /* ------------------------------------------------------------------------------------------ */
 __device__ __forceinline__ uint32_t rds_check_block(uint32_t& in_bits, uint32_t offset, bool fec)
 {
@@ -558,153 +614,186 @@ __device__ __forceinline__ uint32_t rds_check_block(uint32_t& in_bits, uint32_t 
   return syn;
 }
 
-__global__ __launch_bounds__(64) void k_rds_serial(const float2* __restrict__ lpf, unsigned R,
-                                                   unsigned C, unsigned CP, RdsConsts k,
-                                                   const float* __restrict__ mf_taps2, // doubled
-                                                   int mf_state0, ChannelState st, uint32_t call_index,
-                                                   RdsGroupRec* __restrict__ queue,
-                                                   unsigned* __restrict__ queue_count,
-                                                   unsigned queue_cap, float* __restrict__ tap_pll,
-                                                   float* __restrict__ tap_mf,
-                                                   float* __restrict__ tap_sync)
+/* K5a: ProcessRdsPll (RDSProcess.cpp:222-270), one lane per channel.  Output = de-rotated
+ *      imaginary part, written behind the T_mf-1 history rows the matched filter needs. */
+__global__ __launch_bounds__(64) void k_rds_pll(const float2* __restrict__ lpf, unsigned R, unsigned C,
+                                                unsigned CP, RdsConsts k, ChannelState st,
+                                                float* __restrict__ rpll, unsigned Hout,
+                                                const double* __restrict__ sctab_g, FmdSincosTab sct)
 {
-  extern __shared__ float ring[]; // [mf_taps][64]
-  const unsigned lane = threadIdx.x;
-  const unsigned c = blockIdx.x * 64 + lane;
+  __shared__ double sctab[2 * FMD_SINCOS_TAB_SIZE];
+  for (unsigned i = threadIdx.x; i < 2 * FMD_SINCOS_TAB_SIZE; i += 64)
+    sctab[i] = sctab_g[i];
+  __syncthreads();
+  const unsigned c = blockIdx.x * 64 + threadIdx.x;
   if (c >= C)
     return;
-  const int T = k.mf_taps;
-  for (int j = 0; j < T; j++)
-    ring[j * 64 + lane] = st.r_mfring[(size_t)j * CP + c];
-
-  const uint32_t offs[8] = {0x3D8, 0x3D4, 0x25C, 0x258, 0x3D8, 0x3D4, 0x3CC, 0x258};
   float phase = st.F(F_R_PHASE)[c], freq = st.F(F_R_FREQ)[c];
+  float2 cur = lpf[c];
+  float* __restrict__ o = rpll + (size_t)Hout * CP + c;
+#pragma unroll 1
+  for (unsigned i = 0; i < R; i++)
+  {
+    const float2 in = cur;
+    cur = lpf[(size_t)((i + 1 < R) ? i + 1 : i) * CP + c]; // one step ahead of its use
+    float sn, cs;
+    fmd_sincos_tab(phase, sctab, sct, &sn, &cs);
+    const float tr = cs * in.x - sn * in.y;
+    const float ti = cs * in.y + sn * in.x;
+    const float err = -fmd_rds_arctan2(ti, tr);
+    freq += (k.pll_beta * err);
+    freq = (freq > k.nco_hl) ? k.nco_hl : ((freq < k.nco_ll) ? k.nco_ll : freq);
+    phase += (freq + k.pll_alpha * err);
+    *o = ti;
+    o += CP;
+  }
+  st.F(F_R_PHASE)[c] = fmodf(phase, (float)FMD_K_2PI); // RDSProcess.cpp:269
+  st.F(F_R_FREQ)[c] = freq;
+}
+
+/* K5b: after the matched filter (k_ring_fir<float>): squaring + bit-sync resonator
+ *      (RDSProcess.cpp:137-142, IirFilter.cpp:78-87), peak slicer (:144-179), ProcessNewRdsBit
+ *      (:272-375) and CheckBlock with Meggitt FEC (:377-431).  One lane per channel.  Sliced
+ *      bits are queued per lane and the block-sync state machine drains the queue once per
+ *      RB_TILE samples, so the wave does not run it on every sample just because some lane has
+ *      a bit. */
+constexpr int RB_TILE = 32;
+
+__global__ __launch_bounds__(64) void k_rds_bits(const float* __restrict__ mf, unsigned R, unsigned C,
+                                                 unsigned CP, RdsConsts k, ChannelState st,
+                                                 uint32_t call_index, RdsGroupRec* __restrict__ queue,
+                                                 unsigned* __restrict__ queue_count, unsigned queue_cap,
+                                                 float* __restrict__ tap_sync, int write_taps)
+{
+  const unsigned c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C)
+    return;
+  const uint32_t offs[8] = {0x3D8, 0x3D4, 0x25C, 0x258, 0x3D8, 0x3D4, 0x3CC, 0x258};
   float w1 = st.F(F_R_W1)[c], w2 = st.F(F_R_W2)[c];
-  float last_sync = st.F(F_R_LAST_SYNC)[c], last_slope = st.F(F_R_LAST_SLOPE)[c], last_data = st.F(F_R_LAST_DATA)[c];
+  float last_sync = st.F(F_R_LAST_SYNC)[c], last_slope = st.F(F_R_LAST_SLOPE)[c],
+        last_data = st.F(F_R_LAST_DATA)[c];
   int last_bit = st.I(I_R_LAST_BIT)[c];
   uint32_t bits = (uint32_t)st.I(I_R_BITS)[c];
-  int block = st.I(I_R_BLOCK)[c], bitpos = st.I(I_R_BITPOS)[c], state = st.I(I_R_STATE)[c], boff = st.I(I_R_BOFF)[c],
-      errors = st.I(I_R_ERRORS)[c];
+  int block = st.I(I_R_BLOCK)[c], bitpos = st.I(I_R_BITPOS)[c], state = st.I(I_R_STATE)[c],
+      boff = st.I(I_R_BOFF)[c], errors = st.I(I_R_ERRORS)[c];
   uint16_t bd[4];
 #pragma unroll
   for (int q = 0; q < 4; q++)
     bd[q] = st.r_data[(size_t)q * CP + c];
   uint32_t seq = (uint32_t)st.I(I_R_SEQ)[c];
-  int mstate = mf_state0;
 
-  for (unsigned i = 0; i < R; i++)
+  for (unsigned i0 = 0; i0 < R; i0 += RB_TILE)
   {
-    const float2 in = lpf[(size_t)i * CP + c];
-    /* PLL de-rotation */
-    float sn, cs;
-    fmd_sincos_nco(phase, &sn, &cs);
-    const float tr = cs * in.x - sn * in.y;
-    const float ti = cs * in.y + sn * in.x;
-    const float err = -fmd_rds_arctan2(ti, tr);
-    freq += (k.pll_beta * err);
-    if (freq > k.nco_hl)
-      freq = k.nco_hl;
-    else if (freq < k.nco_ll)
-      freq = k.nco_ll;
-    phase += (freq + k.pll_alpha * err);
-    tap_pll[(size_t)i * CP + c] = ti;
-
-    /* matched filter through the ring (slot order = the reference's summation order) */
-    ring[mstate * 64 + lane] = ti;
-    const float* h = mf_taps2 + (T - mstate);
-    float d = h[0] * ring[lane];
-    for (int j = 1; j < T; ++j)
-      d += h[j] * ring[j * 64 + lane];
-    if (--mstate < 0)
-      mstate += T;
-    tap_mf[(size_t)i * CP + c] = d;
-
-    /* bit-sync resonator on d*d */
-    const float mag = d * d;
-    const float w0 = mag - k.bs_a1 * w1 - k.bs_a2 * w2;
-    const float sv = k.bs_b0 * w0 + k.bs_b1 * w1 + k.bs_b2 * w2;
-    w2 = w1;
-    w1 = w0;
-    tap_sync[(size_t)i * CP + c] = sv;
-
-    /* slicer at the positive peak of the sync sine */
-    const float slope = sv - last_sync;
-    last_sync = sv;
-    if ((slope < 0.0f) && (last_slope * slope) < 0.0f)
+    const unsigned cnt = min((unsigned)RB_TILE, R - i0);
+    float din[RB_TILE];
+#pragma unroll
+    for (unsigned u = 0; u < RB_TILE; u++) // all loads of the tile in flight before the recurrence
+      din[u] = mf[(size_t)min(i0 + u, R - 1) * CP + c];
+    uint64_t qbits = 0; // bits sliced in this tile, oldest in the MSBs
+    int qcount = 0;
+#pragma unroll
+    for (unsigned u = 0; u < RB_TILE; u++)
     {
-      const int bit = (last_data >= 0) ? 1 : 0;
-      const int nb = bit ^ last_bit;
-      last_bit = bit;
-      /* ---- ProcessNewRdsBit ---- */
-      bits = (bits << 1) | (uint32_t)nb;
-      bool emit = false;
-      if (state == 0)
-      {
-        if (!rds_check_block(bits, offs[0], false))
-        {
-          bitpos = 0;
-          boff = 0;
-          bd[0] = (uint16_t)(bits >> 10);
-          block = 1;
-          state = 1;
-        }
+      if (u >= cnt)
+        break;
+      const float d = din[u];
+      const float mag = d * d;
+      const float w0 = mag - k.bs_a1 * w1 - k.bs_a2 * w2;
+      const float sv = k.bs_b0 * w0 + k.bs_b1 * w1 + k.bs_b2 * w2;
+      w2 = w1;
+      w1 = w0;
+      if (write_taps)
+        tap_sync[(size_t)(i0 + u) * CP + c] = sv;
+      const float slope = sv - last_sync;
+      last_sync = sv;
+      if ((slope < 0.0f) && (last_slope * slope) < 0.0f)
+      { // top of the sync sine: read the previous matched-filter sample, differential decode
+        const int bit = (last_data >= 0) ? 1 : 0;
+        qbits = (qbits << 1) | (uint64_t)(bit ^ last_bit);
+        qcount++;
+        last_bit = bit;
       }
-      else if (++bitpos >= 26)
+      last_data = d;
+      last_slope = slope;
+    }
+
+    while (__any(qcount > 0))
+    {
+      if (qcount > 0)
       {
-        bitpos = 0;
-        if (state == 3)
-        {
-          if (++block > 3)
+        qcount--;
+        const uint32_t nb = (uint32_t)((qbits >> qcount) & 1u);
+        bits = (bits << 1) | nb;
+        bool emit = false;
+        if (state == 0)
+        { // BITSYNC: look for a clean block A at every bit position
+          if (!rds_check_block(bits, offs[0], false))
           {
-            block = 0;
-            state = 2;
+            bitpos = 0;
+            boff = 0;
+            bd[0] = (uint16_t)(bits >> 10);
+            block = 1;
+            state = 1;
           }
         }
-        else
+        else if (++bitpos >= 26)
         {
-          const uint32_t bad = rds_check_block(bits, offs[block + boff], state == 2);
-          if (bad)
-          {
-            if (state == 1)
-              state = 0;
-            else
+          bitpos = 0;
+          if (state == 3)
+          { // GROUPRESYNC: skip to the start of the next group
+            if (++block > 3)
             {
-              errors++;
-              if (errors > 0) // BLOCK_ERROR_LIMIT 0
-                state = 0;
-              else
-              {
-                if (++block > 3)
-                  block = 0;
-                if (block != 0)
-                  state = 3;
-              }
+              block = 0;
+              state = 2;
             }
           }
           else
           {
-            const uint16_t word = (uint16_t)(bits >> 10);
-            if (block == 0) bd[0] = word;
-            else if (block == 1) bd[1] = word;
-            else if (block == 2) bd[2] = word;
-            else bd[3] = word;
-            boff = (block == 1 && (word & 0x0800)) ? 4 : 0;
-            if (state == 1)
+            const uint32_t bad = rds_check_block(bits, offs[block + boff], state == 2);
+            if (bad)
             {
-              if (block >= 3)
-              {
-                block = 0;
-                errors = 0;
-                state = 2;
-                emit = true;
-              }
+              if (state == 1)
+                state = 0;
               else
-                block++;
+              {
+                errors++;
+                if (errors > 0) // BLOCK_ERROR_LIMIT 0
+                  state = 0;
+                else
+                {
+                  if (++block > 3)
+                    block = 0;
+                  if (block != 0)
+                    state = 3;
+                }
+              }
             }
             else
             {
-              if (++block > 3)
-              {
+              const uint16_t word = (uint16_t)(bits >> 10);
+              if (block == 0)
+                bd[0] = word;
+              else if (block == 1)
+                bd[1] = word;
+              else if (block == 2)
+                bd[2] = word;
+              else
+                bd[3] = word;
+              boff = (block == 1 && (word & 0x0800)) ? 4 : 0;
+              if (state == 1)
+              { // BLOCKSYNC: four good blocks in sequence confirm the bit position
+                if (block >= 3)
+                {
+                  block = 0;
+                  errors = 0;
+                  state = 2;
+                  emit = true;
+                }
+                else
+                  block++;
+              }
+              else if (++block > 3)
+              { // GROUPDECODE: a complete group
                 block = 0;
                 errors = 0;
                 emit = true;
@@ -712,34 +801,27 @@ __global__ __launch_bounds__(64) void k_rds_serial(const float2* __restrict__ lp
             }
           }
         }
-      }
-      if (emit)
-      {
-        const unsigned slot = atomicAdd(queue_count, 1u);
-        if (slot < queue_cap)
+        if (emit)
         {
-          RdsGroupRec r;
-          r.channel = c;
-          r.call_index = call_index;
-          r.seq = seq;
-          r.blocks[0] = bd[0];
-          r.blocks[1] = bd[1];
-          r.blocks[2] = bd[2];
-          r.blocks[3] = bd[3];
-          queue[slot] = r;
+          const unsigned slot = atomicAdd(queue_count, 1u);
+          if (slot < queue_cap)
+          {
+            RdsGroupRec r;
+            r.channel = c;
+            r.call_index = call_index;
+            r.seq = seq;
+            r.blocks[0] = bd[0];
+            r.blocks[1] = bd[1];
+            r.blocks[2] = bd[2];
+            r.blocks[3] = bd[3];
+            queue[slot] = r;
+          }
+          seq++;
         }
-        seq++;
       }
     }
-    last_data = d;
-    last_slope = slope;
   }
-  phase = fmodf(phase, (float)FMD_K_2PI); // RDSProcess.cpp:269
 
-  for (int j = 0; j < T; j++)
-    st.r_mfring[(size_t)j * CP + c] = ring[j * 64 + lane];
-  st.F(F_R_PHASE)[c] = phase;
-  st.F(F_R_FREQ)[c] = freq;
   st.F(F_R_W1)[c] = w1;
   st.F(F_R_W2)[c] = w2;
   st.F(F_R_LAST_SYNC)[c] = last_sync;
@@ -780,77 +862,176 @@ __global__ void k_rs_table(const float* __restrict__ coeff, unsigned order, floa
     pidx[i] = pi;
 }
 
-__global__ __launch_bounds__(256) void k_resample(const float* __restrict__ bb,
-                                                  const float* __restrict__ raw, unsigned Hbb,
+constexpr int RS_R = 8; // outputs per thread; their windows overlap by ~(order - 4.5*7) rows
+
+/* Thread = (channel lane, group of RS_R consecutive outputs).  The union of the group's windows is
+ * walked once from the newest row down; row `top - t` feeds output r with tap j = t - off_r
+ * (off_r = top - pidx[r]), so every output still accumulates in ascending j like the reference.
+ * in = (baseband, raw-stereo) pairs, so both resamplers share each load and each tap. */
+__global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br, unsigned Hbb,
                                                   unsigned order, const float* __restrict__ ktab,
                                                   const int* __restrict__ pidx, unsigned A,
                                                   float2* __restrict__ out, unsigned Hout, unsigned C,
                                                   unsigned CP)
 {
   const unsigned c = blockIdx.x * 64 + threadIdx.x;
-  const unsigned i = blockIdx.y * blockDim.y + threadIdx.y;
-  if (c >= C || i >= A)
+  const unsigned wy = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y); // wave-uniform
+  const unsigned i0 = (blockIdx.y * blockDim.y + wy) * RS_R;
+  if (c >= C || i0 >= A)
     return;
-  const int pi = pidx[i];
-  const float* __restrict__ kt = ktab + (size_t)i * (order + 1);
-  const size_t base = (size_t)(Hbb + (unsigned)pi) * CP + c;
-  float ym = 0.0f, ys = 0.0f;
-  for (unsigned j = 0; j <= order; j++)
+  const int nr = (int)min((unsigned)RS_R, A - i0);
+  const unsigned K1 = order + 1;
+  int off[RS_R];
+  const float* kp[RS_R]; // kp[r][t] = tap of output r for window row t
+  const int top = pidx[i0 + nr - 1];
+#pragma unroll
+  for (int r = 0; r < RS_R; r++)
   {
-    const float kj = kt[j];
-    ym += kj * bb[base - (size_t)j * CP];
-    ys += kj * raw[base - (size_t)j * CP];
+    const int rr = r < nr ? r : nr - 1;
+    off[r] = top - pidx[i0 + rr];
+    kp[r] = ktab + (size_t)(i0 + rr) * K1 - off[r];
   }
-  out[(size_t)(Hout + i) * CP + c] = make_float2(ys, ym); // (stereo, mono) = ProcessTwo's (A, B)
+  float2 acc[RS_R];
+#pragma unroll
+  for (int r = 0; r < RS_R; r++)
+    acc[r] = make_float2(0.0f, 0.0f);
+  const float2* __restrict__ p = br + (size_t)(Hbb + (unsigned)top) * CP + c;
+  const int off0 = off[0];          // largest offset (oldest output of the group)
+  const int tend = off0 + (int)order; // last row of the union window
+
+  auto edge_row = [&](int t) {
+    const float2 x = p[-(ptrdiff_t)t * CP];
+#pragma unroll
+    for (int r = 0; r < RS_R; r++)
+    {
+      const int j = t - off[r];
+      if (r < nr && j >= 0 && j <= (int)order)
+      {
+        const float kj = kp[r][t];
+        acc[r].x += kj * x.x;
+        acc[r].y += kj * x.y;
+      }
+    }
+  };
+
+  if (nr == RS_R && off0 <= (int)order)
+  {
+    int t = 0;
+    for (; t < off0; t++) // head: the younger outputs have started, the older not yet
+      edge_row(t);
+    for (; t + 8 <= (int)order + 1; t += 8) // body: every output of the group takes these rows
+    {
+      float2 xs[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        xs[q] = p[-(ptrdiff_t)(t + q) * CP];
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+      {
+#pragma unroll
+        for (int r = 0; r < RS_R; r++)
+        {
+          const float kj = kp[r][t + q];
+          acc[r].x += kj * xs[q].x;
+          acc[r].y += kj * xs[q].y;
+        }
+      }
+    }
+    for (; t <= (int)order; t++)
+    {
+      const float2 x = p[-(ptrdiff_t)t * CP];
+#pragma unroll
+      for (int r = 0; r < RS_R; r++)
+      {
+        const float kj = kp[r][t];
+        acc[r].x += kj * x.x;
+        acc[r].y += kj * x.y;
+      }
+    }
+    for (; t <= tend; t++) // tail
+      edge_row(t);
+  }
+  else
+  {
+    for (int t = 0; t <= tend; t++)
+      edge_row(t);
+  }
+#pragma unroll
+  for (int r = 0; r < RS_R; r++)
+    if (r < nr) // (stereo, mono) = ProcessTwo's (A, B): x came from baseband -> mono
+      out[(size_t)(Hout + i0 + r) * CP + c] = make_float2(acc[r].y, acc[r].x);
 }
 
 /* ------------------------------------------------------------------------------------------ */
 /* K8: audio tail, one lane per channel: ProcessDeemphasisFilter (FmDecode.cpp:348-359),        */
 /*     19 kHz notch cIirFilter::ProcessTwo (IirFilter.cpp:89-105), L/R matrix (:473-499).       */
 /* ------------------------------------------------------------------------------------------ */
+constexpr int AT_STEPS = 16; // audio frames buffered per lane before a coalesced store
+
 __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp, unsigned A,
                                                    unsigned C, unsigned CP, AudioConsts k,
                                                    ChannelState st, float* __restrict__ audio,
                                                    size_t audio_stride)
 {
-  const unsigned c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C)
-    return;
+  // [channel lane][AT_STEPS frames + pad]: one row = 128 B of a channel's interleaved L/R output
+  __shared__ float2 tile[64][AT_STEPS + 2];
+  const unsigned lane = threadIdx.x;
+  const unsigned c0 = blockIdx.x * 64 + lane;
+  const bool active = c0 < C;
+  const unsigned c = active ? c0 : C - 1;
   float de_re = st.F(F_DE_RE)[c], de_im = st.F(F_DE_IM)[c];
   float w1a = st.F(F_N_W1A)[c], w2a = st.F(F_N_W2A)[c], w1b = st.F(F_N_W1B)[c], w2b = st.F(F_N_W2B)[c];
   const int stereo = st.I(I_STEREO)[c];
-  float2* __restrict__ o = reinterpret_cast<float2*>(audio + (size_t)c * audio_stride);
-  for (unsigned i = 0; i < A; ++i)
+  for (unsigned i0 = 0; i0 < A; i0 += AT_STEPS)
   {
-    const float2 v = lp[(size_t)i * CP + c]; // x = stereo, y = mono
-    de_re = (1.0f - k.de_alpha) * de_re + k.de_alpha * v.x;
-    const float s0 = de_re * 2.0f;
-    de_im = (1.0f - k.de_alpha) * de_im + k.de_alpha * v.y;
-    const float m0 = de_im * 2.0f;
-    const float w0a = s0 - k.n_a1 * w1a - k.n_a2 * w2a;
-    const float w0b = m0 - k.n_a1 * w1b - k.n_a2 * w2b;
-    const float s = k.n_b0 * w0a + k.n_b1 * w1a + k.n_b2 * w2a;
-    const float m = k.n_b0 * w0b + k.n_b1 * w1b + k.n_b2 * w2b;
-    w2a = w1a;
-    w1a = w0a;
-    w2b = w1b;
-    w1b = w0b;
-    float2 lr;
-    if (stereo)
-      lr = make_float2((m + s) * 0.5f, (m - s) * 0.5f);
-    else
+    const unsigned cnt = min((unsigned)AT_STEPS, A - i0);
+    float2 vin[AT_STEPS];
+#pragma unroll
+    for (unsigned u = 0; u < AT_STEPS; u++) // all loads of the tile in flight before the recurrence
+      vin[u] = lp[(size_t)min(i0 + u, A - 1) * CP + c];
+#pragma unroll
+    for (unsigned u = 0; u < AT_STEPS; u++)
     {
+      if (u >= cnt)
+        break;
+      const float2 v = vin[u]; // x = stereo, y = mono
+      de_re = (1.0f - k.de_alpha) * de_re + k.de_alpha * v.x;
+      const float s0 = de_re * 2.0f;
+      de_im = (1.0f - k.de_alpha) * de_im + k.de_alpha * v.y;
+      const float m0 = de_im * 2.0f;
+      const float w0a = s0 - k.n_a1 * w1a - k.n_a2 * w2a;
+      const float w0b = m0 - k.n_a1 * w1b - k.n_a2 * w2b;
+      const float s = k.n_b0 * w0a + k.n_b1 * w1a + k.n_b2 * w2a;
+      const float m = k.n_b0 * w0b + k.n_b1 * w1b + k.n_b2 * w2b;
+      w2a = w1a;
+      w1a = w0a;
+      w2b = w1b;
+      w1b = w0b;
       const float mm = m * 0.5f;
-      lr = make_float2(mm, mm);
+      tile[lane][u] = stereo ? make_float2((m + s) * 0.5f, (m - s) * 0.5f) : make_float2(mm, mm);
     }
-    o[i] = lr;
+    __syncthreads(); // single wave: orders the LDS writes before the cross-lane reads
+    // 8 lanes write one channel's cnt frames (8 B each) as consecutive pieces
+    for (unsigned q = 0; q < 8; q++)
+    {
+      const unsigned ch = q * 8 + (lane >> 3);
+      const unsigned cg = blockIdx.x * 64 + ch;
+      float2* __restrict__ o = reinterpret_cast<float2*>(audio + (size_t)cg * audio_stride) + i0;
+      for (unsigned f = (lane & 7u); f < cnt; f += 8)
+        if (cg < C)
+          o[f] = tile[ch][f];
+    }
+    __syncthreads();
   }
-  st.F(F_DE_RE)[c] = de_re;
-  st.F(F_DE_IM)[c] = de_im;
-  st.F(F_N_W1A)[c] = w1a;
-  st.F(F_N_W2A)[c] = w2a;
-  st.F(F_N_W1B)[c] = w1b;
-  st.F(F_N_W2B)[c] = w2b;
+  if (active)
+  {
+    st.F(F_DE_RE)[c] = de_re;
+    st.F(F_DE_IM)[c] = de_im;
+    st.F(F_N_W1A)[c] = w1a;
+    st.F(F_N_W2A)[c] = w2a;
+    st.F(F_N_W1B)[c] = w1b;
+    st.F(F_N_W2B)[c] = w2b;
+  }
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -862,9 +1043,16 @@ __global__ void k_roll(T* __restrict__ buf, unsigned H, unsigned n, unsigned CP)
   const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= CP)
     return;
-  // ascending order is safe for any n >= 1 (destination row r < source row r + n)
-  for (unsigned r = 0; r < H; r++)
-    buf[(size_t)r * CP + c] = buf[(size_t)(r + n) * CP + c];
+  if (n >= H)
+  { // source rows [n, n+H) and destination rows [0, H) are disjoint: one row per blockIdx.y
+    for (unsigned r = blockIdx.y; r < H; r += gridDim.y)
+      buf[(size_t)r * CP + c] = buf[(size_t)(r + n) * CP + c];
+  }
+  else if (blockIdx.y == 0)
+  { // overlapping (tiny block): ascending order is safe (destination row r < source row r + n)
+    for (unsigned r = 0; r < H; r++)
+      buf[(size_t)r * CP + c] = buf[(size_t)(r + n) * CP + c];
+  }
 }
 
 } // namespace fmd

@@ -59,6 +59,7 @@ def test_stage_taps_bit_exact(pkg, oracle, fmsig, fs, D, nblk):
     p = fmsig.default_params(fs, noise_sigma=0.01)
     o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
     b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 1)
+    b.enable_taps()
     for blk in range(nblk):
         iq = fmsig.generate_f32(p, blk * N, N)
         a_ref = o.process_stream(iq)
