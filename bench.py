@@ -18,7 +18,11 @@ import os
 import sys
 import time
 
-import numpy as np
+# The decoder runs three internal streams next to torch's; give HIP enough hardware queues that
+# they do not share one (must be set before the HIP runtime initialises).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -97,32 +101,45 @@ def main():
     batch = pkg.Batch(pkg.make_params(FS, -0.15 * FS, 48000.0, 15000.0, D), C, device=local_rank,
                       record_callbacks=False)
     a_stride = (batch.max_audio_floats(N) + 63) // 64 * 64
-    audio = [torch.zeros((C, a_stride), dtype=torch.float32, device=dev) for _ in range(2)]
+    NBUF = 4  # outputs are consumed two steps after they are produced
+    audio = [torch.zeros((C, a_stride), dtype=torch.float32, device=dev) for _ in range(NBUF)]
     RCAP = C  # RDS records gathered per rank per step (<= 1 group per channel per 27 ms step)
-    rds_dev = [torch.zeros((RCAP, 4), dtype=torch.int32, device=dev) for _ in range(2)]
+    rds_dev = [torch.zeros((RCAP, 4), dtype=torch.int32, device=dev) for _ in range(NBUF)]
     if world > 1 and rank == 0:
-        g_audio = [[torch.empty_like(audio[0]) for _ in range(world)] for _ in range(2)]
-        g_rds = [[torch.empty_like(rds_dev[0]) for _ in range(world)] for _ in range(2)]
+        g_audio = [[torch.empty_like(audio[0]) for _ in range(world)] for _ in range(NBUF)]
+        g_rds = [[torch.empty_like(rds_dev[0]) for _ in range(world)] for _ in range(NBUF)]
     stream = torch.cuda.current_stream().cuda_stream
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    pending = [None, None]
+    pending = [None] * NBUF
     total_groups = 0
 
-    def step(i):
+    batch.set_concurrency(2)  # FIR of step i+1 overlaps the serial stages of step i
+    LAG = 2  # outputs of step i are consumed after step i+2 is submitted: the host never stalls
+    groups_by_call = {}
+    state = {"submitted": -1, "finalized": -1}
+
+    def pull_groups(lag):
         nonlocal total_groups
-        slot = i & 1
-        if pending[slot] is not None:  # gather that still reads this slot's buffers
-            for w in pending[slot]:
-                w.wait()
-            pending[slot] = None
-        nf = batch.process_device(iq[i % ring].data_ptr(), N, N, audio[slot].data_ptr(), a_stride,
-                                  stream)
-        groups = batch.collect_rds(cap=RCAP, stream=stream)  # small D2H, syncs this stream
-        total_groups += len(groups)
+        got = batch.collect_rds_array(cap=4 * RCAP, stream=stream, lag=lag)
+        total_groups += int(got.size)
+        if world > 1 and got.size:
+            for ci in np.unique(got["call_index"]):
+                groups_by_call.setdefault(int(ci), []).append(got[got["call_index"] == ci])
+
+    def finalize(i):
+        """Outputs of step i (call index i+1): its RDS groups are on the host; with N > 1 its
+        audio and RDS records are gathered to rank 0 over RCCL on the side stream."""
+        slot = i % NBUF
         if world > 1:
+            parts = groups_by_call.pop(i + 1, [])
             rec = np.zeros((RCAP, 4), dtype=np.int32)
-            for j, (ch, ci, blk) in enumerate(groups):
-                rec[j] = (ch + 1, ci, blk[0] | (blk[1] << 16), blk[2] | (blk[3] << 16))
+            if parts:
+                g = np.concatenate(parts)[:RCAP]
+                b = g["blocks"].astype(np.int64)
+                rec[:g.size, 0] = g["channel"] + 1
+                rec[:g.size, 1] = g["call_index"]
+                rec[:g.size, 2] = (b[:, 0] | (b[:, 1] << 16)).astype(np.uint32).view(np.int32)
+                rec[:g.size, 3] = (b[:, 2] | (b[:, 3] << 16)).astype(np.uint32).view(np.int32)
             rds_dev[slot].copy_(torch.from_numpy(rec), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
@@ -133,10 +150,31 @@ def main():
                 w2 = dist.gather(rds_dev[slot], g_rds[slot] if rank == 0 else None, dst=0,
                                  async_op=True)
             pending[slot] = [w1, w2]
+        state["finalized"] = i
+
+    def step(i):
+        slot = i % NBUF
+        if pending[slot] is not None:  # an old gather still reads this slot's buffers
+            for w in pending[slot]:
+                w.wait()
+            pending[slot] = None
+        nf = batch.process_device(iq[i % ring].data_ptr(), N, N, audio[slot].data_ptr(), a_stride,
+                                  stream)
+        state["submitted"] = i
+        if i - LAG > state["finalized"]:
+            # orders the torch stream after the calls that are at least LAG old, drains their groups
+            batch.wait(stream=stream, lag=LAG)
+            pull_groups(LAG)
+            while state["finalized"] < i - LAG:
+                finalize(state["finalized"] + 1)
         return nf
 
     def drain():
-        for slot in (0, 1):
+        batch.wait(stream=stream)
+        pull_groups(0)
+        while state["finalized"] < state["submitted"]:
+            finalize(state["finalized"] + 1)
+        for slot in range(NBUF):
             if pending[slot] is not None:
                 for w in pending[slot]:
                     w.wait()

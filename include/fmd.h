@@ -136,6 +136,27 @@ int fmd_batch_process_host(fmd_batch* b, const float* iq, size_t iq_channel_stri
 int fmd_batch_collect_rds(fmd_batch* b, fmd_rds_group* out, unsigned cap, int run_group_decoder,
                           void* stream);
 
+/* Like fmd_batch_collect_rds, but the `lag` (0..2) newest calls are left alone: only calls at
+ * least that old are waited for and their groups drained (use with concurrency 2, where the
+ * newest calls are still running). */
+int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap,
+                                 int run_group_decoder, int lag, void* stream);
+
+/* Internal execution.  A call is four independent kernel chains (FIR -> serial demodulator ->
+ * {RDS branch, audio branch}); mode selects where they run:
+ *   0  all on the caller's stream, in order
+ *   1  on internal streams, the caller's stream is ordered after each call (default; same
+ *      observable semantics as 0)
+ *   2  on internal streams and the caller's stream is NOT ordered after the call: the FIR of
+ *      call k+1 overlaps the serial stages of call k.  The caller must use a different audio
+ *      buffer for consecutive calls, keep d_iq valid, and call fmd_batch_wait (or collect_rds)
+ *      before consuming outputs. */
+int fmd_batch_set_concurrency(fmd_batch* b, int mode);
+/* Orders `stream` after every call submitted so far (outputs complete, inputs released). */
+int fmd_batch_wait(fmd_batch* b, void* stream);
+/* lag = 1 or 2: every call except the newest one / two (whose kernels may still be running). */
+int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream);
+
 int fmd_batch_get_status(fmd_batch* b, unsigned channel, fmd_status* st);
 
 /* Stage taps for parity tests: copies stage output of the last call for one channel to host.

@@ -73,11 +73,15 @@ class FmdRdsGroup(C.Structure):
     _fields_ = [("channel", C.c_uint32), ("call_index", C.c_uint32), ("blocks", C.c_uint16 * 4)]
 
 
+RDS_GROUP_DTYPE = np.dtype([("channel", "<u4"), ("call_index", "<u4"), ("blocks", "<u2", (4,))])
+assert RDS_GROUP_DTYPE.itemsize == C.sizeof(FmdRdsGroup)
+
 EXPORTS = [
     "fmd_create", "fmd_destroy", "fmd_reset", "fmd_process_stream", "fmd_get_status",
     "fmd_batch_create", "fmd_batch_destroy", "fmd_batch_reset", "fmd_batch_channels",
     "fmd_batch_max_audio_floats", "fmd_batch_process_device", "fmd_batch_process_host",
-    "fmd_batch_collect_rds", "fmd_batch_get_status", "fmd_batch_get_tap", "fmd_batch_get_design",
+    "fmd_batch_collect_rds", "fmd_batch_collect_rds_lagged", "fmd_batch_set_concurrency",
+    "fmd_batch_wait", "fmd_batch_wait_lagged", "fmd_batch_get_status", "fmd_batch_get_tap", "fmd_batch_get_design",
     "fmd_batch_set_debug_taps", "fmd_batch_set_profiling", "fmd_batch_get_stage_ms", "fmd_stage_name", "fmd_last_error",
     "fmd_version", "fmd_group_decoder_create", "fmd_group_decoder_destroy",
     "fmd_group_decoder_reset", "fmd_group_decoder_push", "fmd_uecp_stuff_frame",
@@ -122,6 +126,10 @@ def lib():
                                                C.POINTER(u), vp]
         L.fmd_batch_process_host.argtypes = [vp, vp, C.c_size_t, u, vp, C.c_size_t, C.POINTER(u)]
         L.fmd_batch_collect_rds.argtypes = [vp, vp, u, i, vp]
+        L.fmd_batch_collect_rds_lagged.argtypes = [vp, vp, u, i, i, vp]
+        L.fmd_batch_set_concurrency.argtypes = [vp, i]
+        L.fmd_batch_wait.argtypes = [vp, vp]
+        L.fmd_batch_wait_lagged.argtypes = [vp, i, vp]
         L.fmd_batch_get_status.argtypes = [vp, u, C.POINTER(FmdStatus)]
         L.fmd_batch_get_tap.argtypes = [vp, i, u, vp, u]
         L.fmd_batch_get_design.argtypes = [vp, i, vp, u]
@@ -231,10 +239,25 @@ class Batch:
                                               audio_stride, C.byref(nf), stream))
         return nf.value
 
-    def collect_rds(self, cap=65536, run_group_decoder=False, stream=None):
-        buf = (FmdRdsGroup * cap)()
-        n = _check(lib().fmd_batch_collect_rds(self._h, buf, cap, int(run_group_decoder), stream))
-        return [(g.channel, g.call_index, tuple(int(x) for x in g.blocks)) for g in buf[:n]]
+    def collect_rds_array(self, cap=65536, run_group_decoder=False, stream=None, lag=0):
+        """Queued RDS groups as a numpy structured array (channel, call_index, blocks[4])."""
+        if getattr(self, "_rds_buf", None) is None or self._rds_buf.size < cap:
+            self._rds_buf = np.zeros(cap, dtype=RDS_GROUP_DTYPE)
+        n = _check(lib().fmd_batch_collect_rds_lagged(self._h, self._rds_buf.ctypes.data, cap,
+                                                      int(run_group_decoder), lag, stream))
+        return self._rds_buf[:n].copy()
+
+    def collect_rds(self, cap=65536, run_group_decoder=False, stream=None, lag=0):
+        """Queued RDS groups as a list of (channel, call_index, (b0, b1, b2, b3))."""
+        a = self.collect_rds_array(cap, run_group_decoder, stream, lag)
+        return [(int(c), int(k), tuple(int(x) for x in b))
+                for c, k, b in zip(a["channel"], a["call_index"], a["blocks"])]
+
+    def set_concurrency(self, mode):
+        _check(lib().fmd_batch_set_concurrency(self._h, int(mode)))
+
+    def wait(self, stream=None, lag=0):
+        _check(lib().fmd_batch_wait_lagged(self._h, lag, stream))
 
     def status(self, channel=0):
         st = FmdStatus()

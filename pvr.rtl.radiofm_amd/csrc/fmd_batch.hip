@@ -103,7 +103,7 @@ struct fmd_batch
   unsigned lastM = 0, lastA = 0, lastR = 0;
 
   // device memory
-  DevBuf<float2> lut, hist[2], demod, br, mix, rdsraw, rlpf, rs, alp;
+  DevBuf<float2> lut, hist[2], demod[2], br[2], mix[2], rdsraw, rlpf, rs, alp;
   std::vector<DevBuf<float2>> hbbuf; // input buffers of stages 1..n-1 (stage 0 reads mix)
   DevBuf<float> if_coeff, rs_coeff, rds_lpf_taps, mf_taps2, audio_taps, ktab;
   DevBuf<float> rpll, rmf, tap_sync;
@@ -112,8 +112,9 @@ struct fmd_batch
   DevBuf<float> fstate; // all float state arrays, CP each
   DevBuf<int> istate;
   DevBuf<uint16_t> r_data;
-  DevBuf<fmd::RdsGroupRec> queue;
-  DevBuf<unsigned> queue_count;
+  static constexpr int NSLOT = 4; // event sets / RDS queues in rotation (call_index % NSLOT)
+  DevBuf<fmd::RdsGroupRec> queue[NSLOT]; // never drained while a call that appends to it is in flight
+  DevBuf<unsigned> queue_count[NSLOT];
   unsigned queue_cap = 0;
   fmd::ChannelState st{};
   std::vector<fmd::HbCoef> hbcoef;
@@ -128,17 +129,37 @@ struct fmd_batch
   // One event set per call (up to kMaxProfCalls) so nothing has to synchronise inside a timed loop.
   int profiling = 0;
   int write_taps = 0; // stage taps of the RDS recurrences are only written on request
+
+  // Internal streams: the FIR of the next call (s_fir), the serial demodulator of this call
+  // (s_ser) and everything behind it (s_post: RDS chain, then audio chain) are independent
+  // chains tied together, and to the caller's stream, with events.  Three streams on purpose:
+  // HIP multiplexes streams onto a few hardware queues (4 by default) and two chains sharing
+  // a queue block each other.  demod, br and mix are double-buffered by call parity so no
+  // chain waits on a buffer a younger call still reads.
+  //   concurrency 0: everything on the caller's stream (also forced by profiling level 2)
+  //   concurrency 1: internal streams, the caller's stream is ordered after every call (default)
+  //   concurrency 2: as 1, but the caller's stream is only ordered after a call by fmd_batch_wait /
+  //                  fmd_batch_collect_rds; lets call k+1's FIR overlap call k's serial stages
+  int concurrency = 1;
+  hipStream_t s_fir = nullptr, s_ser = nullptr, s_post = nullptr;
+  enum { EV_IN, EV_FIR, EV_SER, EV_BRFREE, EV_MIXFREE, EV_AUD, EV_RDS, EV_N };
+  hipEvent_t cev[NSLOT][EV_N] = {};
+  bool cev_ready = false;
+  uint32_t slot_call[NSLOT] = {0, 0, 0, 0}; // call index that last used the slot (0 = never)
   std::vector<hipEvent_t> ev; // [calls][ST_COUNT + 1]
   unsigned prof_calls = 0;
 
   ~fmd_batch()
   {
     (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
     lut.release();
     hist[0].release();
     hist[1].release();
-    demod.release();
-    mix.release();
+    demod[0].release();
+    demod[1].release();
+    mix[0].release();
+    mix[1].release();
     rdsraw.release();
     rlpf.release();
     rs.release();
@@ -147,7 +168,8 @@ struct fmd_batch
       b.release();
     if_coeff.release();
     rs_coeff.release();
-    br.release();
+    br[0].release();
+    br[1].release();
     rds_lpf_taps.release();
     mf_taps2.release();
     audio_taps.release();
@@ -160,8 +182,20 @@ struct fmd_batch
     fstate.release();
     istate.release();
     r_data.release();
-    queue.release();
-    queue_count.release();
+    for (int q = 0; q < NSLOT; q++)
+    {
+      queue[q].release();
+      queue_count[q].release();
+    }
+    if (cev_ready)
+    {
+      for (auto& row : cev)
+        for (auto& e : row)
+          (void)hipEventDestroy(e);
+      (void)hipStreamDestroy(s_fir);
+      (void)hipStreamDestroy(s_ser);
+      (void)hipStreamDestroy(s_post);
+    }
     h_iq.release();
     h_audio.release();
     for (auto& e : ev)
@@ -339,13 +373,16 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->lut.alloc(size_t(d.table_size) * C);
   bad |= b->hist[0].alloc(size_t(d.if_order) * C);
   bad |= b->hist[1].alloc(size_t(d.if_order) * C);
-  bad |= b->demod.alloc(size_t(b->Mstride) * C);
+  bad |= b->demod[0].alloc(size_t(b->Mstride) * C);
+  bad |= b->demod[1].alloc(size_t(b->Mstride) * C);
   bad |= b->if_coeff.alloc(d.if_coeff.size());
   bad |= b->rs_coeff.alloc(d.rs_coeff.size());
-  bad |= b->br.alloc(size_t(d.rs_order + b->Mmax) * CP);
+  bad |= b->br[0].alloc(size_t(d.rs_order + b->Mmax) * CP);
+  bad |= b->br[1].alloc(size_t(d.rs_order + b->Mmax) * CP);
   if (d.hb.empty())
     return fail(FMD_ERR_ARG, "baseband rate too low for the RDS decimation chain");
-  bad |= b->mix.alloc(size_t(d.hb[0].len - 1 + b->Mmax) * CP);
+  bad |= b->mix[0].alloc(size_t(d.hb[0].len - 1 + b->Mmax) * CP);
+  bad |= b->mix[1].alloc(size_t(d.hb[0].len - 1 + b->Mmax) * CP);
   b->hbbuf.resize(d.hb.size() - 1);
   for (size_t s = 1; s < d.hb.size(); s++)
     bad |= b->hbbuf[s - 1].alloc(size_t(d.hb[s].len - 1 + b->hb_nmax[s]) * CP);
@@ -366,8 +403,11 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->istate.alloc(size_t(fmd::I_SLOTS) * CP);
   bad |= b->r_data.alloc(size_t(4) * CP);
   b->queue_cap = std::max(4096u, 8u * C);
-  bad |= b->queue.alloc(b->queue_cap);
-  bad |= b->queue_count.alloc(1);
+  for (int q = 0; q < fmd_batch::NSLOT; q++)
+  {
+    bad |= b->queue[q].alloc(b->queue_cap);
+    bad |= b->queue_count[q].alloc(1);
+  }
   if (bad)
     return fail(FMD_ERR_DEVICE, std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError()));
 
@@ -393,6 +433,13 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     return fail(FMD_ERR_DEVICE, "state reset failed");
 
   b->gdec.resize(C);
+  HIPCHK(hipStreamCreateWithFlags(&b->s_fir, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&b->s_ser, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&b->s_post, hipStreamNonBlocking));
+  for (auto& row : b->cev)
+    for (auto& e : row)
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  b->cev_ready = true;
   HIPCHK(hipDeviceSynchronize());
   *out = b.release();
   return FMD_OK;
@@ -480,6 +527,25 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
   const unsigned T_alp = unsigned(d.lpf_taps.size());
   const unsigned Hbb = d.rs_order;
   b->call_index++;
+  const int q = int(b->call_index & 1u);  // buffer parity: demod, br, mix
+  const int es = int(b->call_index % fmd_batch::NSLOT); // event set / RDS queue of this call
+  // call k-2 used the same buffers; its events say when they are free again
+  const bool have_prev2 = b->call_index > 2;
+  hipEvent_t* pe2 = b->cev[(b->call_index + fmd_batch::NSLOT - 2) % fmd_batch::NSLOT];
+  const bool serial_mode = b->concurrency == 0 || b->profiling >= 2;
+  hipStream_t sF = serial_mode ? stream : b->s_fir;
+  hipStream_t sS = serial_mode ? stream : b->s_ser;
+  hipStream_t sP = serial_mode ? stream : b->s_post;
+  hipStream_t sA = sP, sR = sP;
+  hipEvent_t* ce = b->cev[es];
+  auto after = [&](hipStream_t s, hipEvent_t e) {
+    if (!serial_mode)
+      (void)hipStreamWaitEvent(s, e, 0);
+  };
+  auto signal = [&](hipEvent_t e, hipStream_t s) {
+    if (!serial_mode)
+      (void)hipEventRecord(e, s);
+  };
 
   hipEvent_t* evset = nullptr;
   if (b->profiling && b->prof_calls < kMaxProfCalls)
@@ -494,13 +560,19 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
     evset = &b->ev[size_t(b->prof_calls) * (ST_COUNT + 1)];
     b->prof_calls++;
   }
+  // level 2: events between all stages (serial mode); level 1: only around the FIR kernel, on
+  // the stream that kernel is launched on
   auto mark = [&](int i) {
     if (evset && (b->profiling >= 2 || i <= 1))
-      (void)hipEventRecord(evset[i], stream);
+      (void)hipEventRecord(evset[i], sF);
   };
-  mark(0);
 
-  /* ---- K1: tuner + IF decimating FIR ---- */
+  /* ---- K1: tuner + IF decimating FIR  (stream F) ---- */
+  signal(ce[fmd_batch::EV_IN], stream);
+  after(sF, ce[fmd_batch::EV_IN]);
+  if (have_prev2)
+    after(sF, pe2[fmd_batch::EV_SER]); // demod[q] was last read by the serial stage two calls ago
+  mark(0);
   {
     constexpr int TILE = 256;
     const unsigned ntiles = (M + TILE - 1) / TILE;
@@ -519,15 +591,25 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kfn, dim3(C * ntiles), dim3(TILE), lds, stream,
+    hipLaunchKernelGGL(kfn, dim3(C * ntiles), dim3(TILE), lds, sF,
                        reinterpret_cast<const float2*>(d_iq), iq_channel_stride, N,
                        b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, d.table_size,
-                       b->lut_idx, b->if_coeff.p, d.if_order, D, pos, M, b->demod.p, b->Mstride,
+                       b->lut_idx, b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride,
                        ntiles, (C % 8 == 0) ? 1u : 0u);
   }
   mark(1);
+  hipLaunchKernelGGL(fmd::k_if_level, dim3(C), dim3(64), 0, sF,
+                     reinterpret_cast<const float2*>(d_iq), iq_channel_stride, N, b->lut.p,
+                     d.table_size, b->lut_idx, b->st);
+  signal(ce[fmd_batch::EV_FIR], sF);
 
-  /* ---- K2: baseband-rate recurrences ---- */
+  /* ---- K2: baseband-rate recurrences  (stream S) ---- */
+  after(sS, ce[fmd_batch::EV_FIR]);
+  if (have_prev2)
+  { // br[q] / mix[q] were last read by the resampler / first half-band two calls ago
+    after(sS, pe2[fmd_batch::EV_BRFREE]);
+    after(sS, pe2[fmd_batch::EV_MIXFREE]);
+  }
   {
     fmd::DemodConsts k{};
     k.pll_alpha = d.pll_alpha;
@@ -546,19 +628,21 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
     k.p_lock_delay = d.p_lock_delay;
     k.osc_cos = d.rds_osc_cos;
     k.osc_sin = d.rds_osc_sin;
-    hipLaunchKernelGGL(fmd::k_if_level, dim3(C), dim3(64), 0, stream,
-                       reinterpret_cast<const float2*>(d_iq), iq_channel_stride, N, b->lut.p,
-                       d.table_size, b->lut_idx, b->st);
-    hipLaunchKernelGGL(fmd::k_demod_serial, dim3(CP / 64), dim3(128), 0, stream, b->demod.p,
-                       b->Mstride, M, C, CP, k, b->st, b->br.p, Hbb, b->mix.p,
+    hipLaunchKernelGGL(fmd::k_demod_serial, dim3(CP / 64), dim3(128), 0, sS, b->demod[q].p,
+                       b->Mstride, M, C, CP, k, b->st, b->br[q].p, Hbb, b->mix[q].p,
                        unsigned(d.hb[0].len - 1), b->sctab.p,
                        FmdSincosTab{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo});
   }
+  signal(ce[fmd_batch::EV_SER], sS);
   mark(2);
 
-  /* ---- K3: half-band chain ---- */
+  const dim3 rt(256);
+  auto rgrid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
+
+  /* ---- RDS branch  (stream R): half-bands, 75-tap LPF, PLL, matched filter, bits ---- */
+  after(sR, ce[fmd_batch::EV_SER]);
   {
-    const float2* in = b->mix.p;
+    const float2* in = b->mix[q].p;
     for (size_t s = 0; s < d.hb.size(); s++)
     {
       const unsigned n_out = (hb_in[s] + 1) / 2;
@@ -566,20 +650,27 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
       float2* outp = last ? b->rdsraw.p : b->hbbuf[s].p;
       const unsigned Hout = last ? (T_lpf - 1) : unsigned(d.hb[s + 1].len - 1);
       hipLaunchKernelGGL(fmd::k_halfband, dim3(CP / 64, (n_out + 4 * fmd::HB_R - 1) / (4 * fmd::HB_R)),
-                         dim3(64, 4), 0, stream, in,
-                         outp, n_out, d.hb[s].len, b->hbcoef[s], C, CP, Hout);
+                         dim3(64, 4), 0, sR, in, outp, n_out, d.hb[s].len, b->hbcoef[s], C, CP, Hout);
+      // keep the last L-1 input rows of this stage for the next call, then its input is free
+      const unsigned Hs = unsigned(d.hb[s].len - 1);
+      if (s == 0)
+      { // tail of mix[q] -> history rows of mix[q^1], which the next call's half-band reads
+        hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->mix[q].p, b->mix[q ^ 1].p, Hs,
+                           hb_in[0], CP);
+        signal(ce[fmd_batch::EV_MIXFREE], sR);
+      }
+      else
+        hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->hbbuf[s - 1].p,
+                           b->hbbuf[s - 1].p, Hs, hb_in[s], CP);
       in = outp;
     }
   }
   mark(3);
-
-  /* ---- K4: RDS 75-tap low-pass ---- */
   hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
-                     size_t(T_lpf - 1 + fmd::RF_TI) * 64 * sizeof(float2), stream, b->rdsraw.p,
+                     size_t(T_lpf - 1 + fmd::RF_TI) * 64 * sizeof(float2), sR, b->rdsraw.p,
                      b->rlpf.p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C, CP, 0u);
+  hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, sR, b->rdsraw.p, b->rdsraw.p, T_lpf - 1, R, CP);
   mark(4);
-
-  /* ---- K5: RDS recurrences and block sync ---- */
   {
     fmd::RdsConsts k{};
     k.pll_alpha = d.rds_pll_alpha;
@@ -593,32 +684,34 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
     k.bs_a2 = d.bitsync.a2;
     k.mf_taps = int(T_mf);
     const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
-    hipLaunchKernelGGL(fmd::k_rds_pll, dim3(CP / 64), dim3(64), 0, stream, b->rlpf.p, R, C, CP, k,
+    hipLaunchKernelGGL(fmd::k_rds_pll, dim3(CP / 64), dim3(64), 0, sR, b->rlpf.p, R, C, CP, k,
                        b->st, b->rpll.p, T_mf - 1, b->sctab.p, sct);
     hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI),
-                       dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), stream,
+                       dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), sR,
                        b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C, CP, 0u);
-    hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, stream, b->rmf.p, R, C, CP, k,
-                       b->st, b->call_index, b->queue.p, b->queue_count.p, b->queue_cap,
+    hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, sR, b->rpll.p, b->rpll.p, T_mf - 1, R, CP);
+    hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, sR, b->rmf.p, R, C, CP, k,
+                       b->st, b->call_index, b->queue[es].p, b->queue_count[es].p, b->queue_cap,
                        b->tap_sync.p, b->write_taps);
   }
+  signal(ce[fmd_batch::EV_RDS], sR);
   mark(5);
 
-  /* ---- K6/K7: fractional resamplers (mono + stereo) ---- */
-  hipLaunchKernelGGL(fmd::k_rs_table, dim3(A), dim3(64), 0, stream, b->rs_coeff.p, d.rs_order, p,
+  /* ---- audio branch  (stream A): resamplers, 15 kHz LPF, de-emphasis / notch / matrix ---- */
+  after(sA, ce[fmd_batch::EV_SER]);
+  hipLaunchKernelGGL(fmd::k_rs_table, dim3(A), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p,
                      pstep, A, b->ktab.p, b->pidx.p);
   hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
-                     dim3(64, 4), 0, stream, b->br.p, Hbb, d.rs_order, b->ktab.p, b->pidx.p, A,
+                     dim3(64, 4), 0, sA, b->br[q].p, Hbb, d.rs_order, b->ktab.p, b->pidx.p, A,
                      b->rs.p, T_alp - 1, C, CP);
+  hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hbb), rt, 0, sA, b->br[q].p, b->br[q ^ 1].p, Hbb, M, CP);
+  signal(ce[fmd_batch::EV_BRFREE], sA);
   mark(6);
-
-  /* ---- audio 15 kHz low-pass on the (stereo, mono) pair ---- */
   hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (A + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
-                     size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), stream, b->rs.p, b->alp.p, A,
+                     size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), sA, b->rs.p, b->alp.p, A,
                      int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
+  hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_alp - 1), rt, 0, sA, b->rs.p, b->rs.p, T_alp - 1, A, CP);
   mark(7);
-
-  /* ---- K8: de-emphasis, notch, L/R ---- */
   {
     fmd::AudioConsts k{};
     k.de_alpha = d.de_alpha;
@@ -627,29 +720,20 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
     k.n_b2 = d.notch.b2;
     k.n_a1 = d.notch.a1;
     k.n_a2 = d.notch.a2;
-    hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, stream, b->alp.p, A, C, CP, k,
+    hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, sA, b->alp.p, A, C, CP, k,
                        b->st, d_audio, audio_channel_stride);
   }
+  signal(ce[fmd_batch::EV_AUD], sA);
   mark(8);
-
-  /* ---- history rolls: keep the last H rows of every windowed buffer for the next call ---- */
-  {
-    const dim3 t(256);
-    auto grid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
-    hipLaunchKernelGGL(fmd::k_roll<float2>, grid(Hbb), t, 0, stream, b->br.p, Hbb, M, CP);
-    const unsigned H0 = unsigned(d.hb[0].len - 1);
-    hipLaunchKernelGGL(fmd::k_roll<float2>, grid(H0), t, 0, stream, b->mix.p, H0, hb_in[0], CP);
-    for (size_t s = 1; s < d.hb.size(); s++)
-    {
-      const unsigned Hs = unsigned(d.hb[s].len - 1);
-      hipLaunchKernelGGL(fmd::k_roll<float2>, grid(Hs), t, 0, stream, b->hbbuf[s - 1].p, Hs, hb_in[s], CP);
-    }
-    hipLaunchKernelGGL(fmd::k_roll<float2>, grid(T_lpf - 1), t, 0, stream, b->rdsraw.p, T_lpf - 1, R, CP);
-    hipLaunchKernelGGL(fmd::k_roll<float>, grid(T_mf - 1), t, 0, stream, b->rpll.p, T_mf - 1, R, CP);
-    hipLaunchKernelGGL(fmd::k_roll<float2>, grid(T_alp - 1), t, 0, stream, b->rs.p, T_alp - 1, A, CP);
-  }
   mark(9);
   HIPCHK(hipGetLastError());
+  b->slot_call[es] = b->call_index;
+  if (!serial_mode && b->concurrency < 2)
+  { // order the caller's stream after everything this call launched
+    (void)hipStreamWaitEvent(stream, ce[fmd_batch::EV_AUD], 0);
+    (void)hipStreamWaitEvent(stream, ce[fmd_batch::EV_RDS], 0);
+    (void)hipStreamWaitEvent(stream, ce[fmd_batch::EV_FIR], 0);
+  }
 
   /* ---- advance the host-tracked positions ---- */
   b->if_pos = pos + M * D - N;                      // DownConvert.cpp:132
@@ -667,24 +751,79 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
   return FMD_OK;
 }
 
-int fmd_batch_collect_rds(fmd_batch* b, fmd_rds_group* out, unsigned cap, int run_group_decoder,
-                          void* stream_)
+/* slots whose call is at least `lag` calls old (lag 0 = every call submitted so far) */
+static bool slot_eligible(const fmd_batch* b, int q, int lag)
 {
-  if (!b)
-    return fail(FMD_ERR_ARG, "null batch");
+  return b->slot_call[q] != 0 && b->slot_call[q] + uint32_t(lag) <= b->call_index;
+}
+
+int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream_)
+{
+  if (!b || lag < 0 || lag > 2)
+    return fail(FMD_ERR_ARG, "fmd_batch_wait: bad argument (lag must be 0, 1 or 2)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
+  for (int q = 0; q < fmd_batch::NSLOT; q++)
+    if (slot_eligible(b, q, lag))
+    {
+      HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_AUD], 0));
+      HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_RDS], 0));
+      HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_FIR], 0));
+    }
+  return FMD_OK;
+}
+
+int fmd_batch_wait(fmd_batch* b, void* stream_)
+{
+  return fmd_batch_wait_lagged(b, 0, stream_);
+}
+
+int fmd_batch_set_concurrency(fmd_batch* b, int mode)
+{
+  if (!b || mode < 0 || mode > 2)
+    return fail(FMD_ERR_ARG, "fmd_batch_set_concurrency: mode must be 0, 1 or 2");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  b->concurrency = mode;
+  return FMD_OK;
+}
+
+static int drain_queue(fmd_batch* b, int q, hipStream_t stream, std::vector<fmd::RdsGroupRec>& recs)
+{
   unsigned n = 0;
-  HIPCHK(hipMemcpyAsync(&n, b->queue_count.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(&n, b->queue_count[q].p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
   HIPCHK(hipStreamSynchronize(stream));
   if (n > b->queue_cap)
     n = b->queue_cap; // overflow: the oldest queue_cap groups are kept
-  std::vector<fmd::RdsGroupRec> recs(n);
   if (n)
-    HIPCHK(hipMemcpyAsync(recs.data(), b->queue.p, size_t(n) * sizeof(fmd::RdsGroupRec),
+  {
+    const size_t old = recs.size();
+    recs.resize(old + n);
+    HIPCHK(hipMemcpyAsync(recs.data() + old, b->queue[q].p, size_t(n) * sizeof(fmd::RdsGroupRec),
                           hipMemcpyDeviceToHost, stream));
-  HIPCHK(hipMemsetAsync(b->queue_count.p, 0, sizeof(unsigned), stream));
-  HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipMemsetAsync(b->queue_count[q].p, 0, sizeof(unsigned), stream));
+    HIPCHK(hipStreamSynchronize(stream));
+  }
+  return FMD_OK;
+}
+
+int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap, int run_group_decoder,
+                                 int lag, void* stream_)
+{
+  if (!b || lag < 0 || lag > 2)
+    return fail(FMD_ERR_ARG, "fmd_batch_collect_rds: bad argument (lag must be 0, 1 or 2)");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIPCHK(hipSetDevice(b->device));
+  std::vector<fmd::RdsGroupRec> recs;
+  for (int q = 0; q < fmd_batch::NSLOT; q++)
+  {
+    if (!slot_eligible(b, q, lag))
+      continue; // never used, or its call may still be appending to this queue
+    HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_RDS], 0));
+    int rc = drain_queue(b, q, stream, recs);
+    if (rc != FMD_OK)
+      return rc;
+  }
   std::sort(recs.begin(), recs.end(), [](const fmd::RdsGroupRec& x, const fmd::RdsGroupRec& y) {
     if (x.call_index != y.call_index)
       return x.call_index < y.call_index;
@@ -706,12 +845,18 @@ int fmd_batch_collect_rds(fmd_batch* b, fmd_rds_group* out, unsigned cap, int ru
     {
       out[k].channel = r.channel;
       out[k].call_index = r.call_index;
-      for (int q = 0; q < 4; q++)
-        out[k].blocks[q] = r.blocks[q];
+      for (int i = 0; i < 4; i++)
+        out[k].blocks[i] = r.blocks[i];
       k++;
     }
   }
-  return int(out ? k : n);
+  return int(out ? k : recs.size());
+}
+
+int fmd_batch_collect_rds(fmd_batch* b, fmd_rds_group* out, unsigned cap, int run_group_decoder,
+                          void* stream_)
+{
+  return fmd_batch_collect_rds_lagged(b, out, cap, run_group_decoder, 0, stream_);
 }
 
 int fmd_batch_process_host(fmd_batch* b, const float* iq, size_t iq_channel_stride, unsigned samples,
@@ -801,7 +946,7 @@ int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsig
     case FMD_TAP_DEMOD:
       if (size_t(2) * b->lastM > cap_floats)
         return fail(FMD_ERR_ARG, "tap buffer too small");
-      HIPCHK(hipMemcpy(out, b->demod.p + size_t(channel) * b->Mstride, size_t(b->lastM) * 8,
+      HIPCHK(hipMemcpy(out, b->demod[b->call_index & 1u].p + size_t(channel) * b->Mstride, size_t(b->lastM) * 8,
                        hipMemcpyDeviceToHost));
       return int(b->lastM);
     /* windowed buffers were rolled at the end of the call: the block's rows are still in place
@@ -812,7 +957,7 @@ int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsig
       rows = b->lastM;
       if (rows > cap_floats)
         return fail(FMD_ERR_ARG, "tap buffer too small");
-      const char* s0 = reinterpret_cast<const char*>(b->br.p) +
+      const char* s0 = reinterpret_cast<const char*>(b->br[b->call_index & 1u].p) +
                        (size_t(b->des.rs_order) * CP + channel) * 8 + (tap == FMD_TAP_PILOT38 ? 4 : 0);
       if (rows)
         HIPCHK(hipMemcpy2D(out, 4, s0, CP * 8, 4, rows, hipMemcpyDeviceToHost));

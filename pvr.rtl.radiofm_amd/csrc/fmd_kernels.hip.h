@@ -263,6 +263,8 @@ __global__ __launch_bounds__(128) void k_demod_serial(
 {
   __shared__ float chunk[2][DS][64];
   __shared__ double sctab[2 * FMD_SINCOS_TAB_SIZE];
+  // latency-bound recurrence: when bandwidth kernels of other calls share the SIMD, issue first
+  __builtin_amdgcn_s_setprio(3);
   for (unsigned i = threadIdx.x; i < 2 * FMD_SINCOS_TAB_SIZE; i += 128)
     sctab[i] = sctab_g[i];
   __syncthreads();
@@ -622,6 +624,7 @@ __global__ __launch_bounds__(64) void k_rds_pll(const float2* __restrict__ lpf, 
                                                 const double* __restrict__ sctab_g, FmdSincosTab sct)
 {
   __shared__ double sctab[2 * FMD_SINCOS_TAB_SIZE];
+  __builtin_amdgcn_s_setprio(3);
   for (unsigned i = threadIdx.x; i < 2 * FMD_SINCOS_TAB_SIZE; i += 64)
     sctab[i] = sctab_g[i];
   __syncthreads();
@@ -665,6 +668,7 @@ __global__ __launch_bounds__(64) void k_rds_bits(const float* __restrict__ mf, u
                                                  unsigned* __restrict__ queue_count, unsigned queue_cap,
                                                  float* __restrict__ tap_sync, int write_taps)
 {
+  __builtin_amdgcn_s_setprio(3);
   const unsigned c = blockIdx.x * 64 + threadIdx.x;
   if (c >= C)
     return;
@@ -975,6 +979,7 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
 {
   // [channel lane][AT_STEPS frames + pad]: one row = 128 B of a channel's interleaved L/R output
   __shared__ float2 tile[64][AT_STEPS + 2];
+  __builtin_amdgcn_s_setprio(3);
   const unsigned lane = threadIdx.x;
   const unsigned c0 = blockIdx.x * 64 + lane;
   const bool active = c0 < C;
@@ -1037,21 +1042,24 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
 /* ------------------------------------------------------------------------------------------ */
 /* history roll: rows [n, n+H) -> [0, H) of a time-major buffer (element size ES floats)        */
 /* ------------------------------------------------------------------------------------------ */
+/* dst rows [0, H) <- src rows [n, n+H): the last H rows of (history + n new rows).  src == dst
+ * for single buffers (then n >= H is required for the row-parallel form), src != dst for the
+ * double-buffered ones. */
 template <typename T>
-__global__ void k_roll(T* __restrict__ buf, unsigned H, unsigned n, unsigned CP)
+__global__ void k_roll(const T* src, T* dst, unsigned H, unsigned n, unsigned CP)
 {
   const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= CP)
     return;
-  if (n >= H)
-  { // source rows [n, n+H) and destination rows [0, H) are disjoint: one row per blockIdx.y
+  if (n >= H || src != dst)
+  { // source and destination rows are disjoint: one row per blockIdx.y
     for (unsigned r = blockIdx.y; r < H; r += gridDim.y)
-      buf[(size_t)r * CP + c] = buf[(size_t)(r + n) * CP + c];
+      dst[(size_t)r * CP + c] = src[(size_t)(r + n) * CP + c];
   }
   else if (blockIdx.y == 0)
   { // overlapping (tiny block): ascending order is safe (destination row r < source row r + n)
     for (unsigned r = 0; r < H; r++)
-      buf[(size_t)r * CP + c] = buf[(size_t)(r + n) * CP + c];
+      dst[(size_t)r * CP + c] = src[(size_t)(r + n) * CP + c];
   }
 }
 

@@ -188,3 +188,43 @@ def test_ragged_block_sizes_and_reset(pkg, oracle, fmsig):
         assert _bits_equal(a, r), (i, n, _rms(a, r))
     with pytest.raises(pkg.FmdError):
         d.ProcessStream(np.zeros(100, np.complex64))  # below FMD_MIN_BLOCK: rejected loudly
+
+
+def test_concurrency_modes_agree(pkg, fmsig):
+    """Internal-stream execution (modes 1 and 2, incl. cross-call overlap) gives exactly the
+    results of the fully serialized mode 0: audio bits and RDS groups, 4 channels, 40 calls."""
+    import torch
+    fs, D, C = 2.4e6, 11, 4
+    ps = [fmsig.default_params(fs, noise_sigma=0.01, seed=7 + c, pi=0x2000 + c, ps="MODE%04d" % c)
+          for c in range(C)]
+    nblk = 40
+    iq = torch.from_numpy(np.stack([np.stack([fmsig.generate_f32(ps[c], b * N, N) for c in range(C)])
+                                    for b in range(nblk)])).cuda()  # [nblk, C, 2N]
+    stream = torch.cuda.current_stream().cuda_stream
+    results = {}
+    for mode in (0, 1, 2):
+        b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C)
+        b.set_concurrency(mode)
+        stride = (b.max_audio_floats(N) + 3) // 4 * 4
+        outs = [torch.zeros((C, stride), dtype=torch.float32, device="cuda") for _ in range(nblk)]
+        groups, nfs = [], []
+        for k in range(nblk):
+            nfs.append(b.process_device(iq[k].data_ptr(), N, N, outs[k].data_ptr(), stride, stream))
+            if mode == 2 and k >= 1:
+                groups += b.collect_rds(stream=stream, lag=1)
+            elif mode != 2:
+                groups += b.collect_rds(stream=stream)
+        b.wait(stream=stream)
+        groups += b.collect_rds(stream=stream)
+        torch.cuda.synchronize()
+        results[mode] = (np.stack([outs[k].cpu().numpy()[:, :nfs[k]].copy() if nfs[k] == nfs[0]
+                                   else np.pad(outs[k].cpu().numpy()[:, :nfs[k]], ((0, 0), (0, nfs[0] + 2 - nfs[k])))[:, :nfs[0]]
+                                   for k in range(nblk)]), nfs, groups)
+        b.close()
+    a0, n0, g0 = results[0]
+    assert len(g0) > 10
+    for mode in (1, 2):
+        a, n, g = results[mode]
+        assert n == n0
+        assert np.array_equal(a.view(np.uint32), a0.view(np.uint32)), mode
+        assert g == g0, mode
