@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--channels", type=int, default=8192, help="channels per GPU")
     ap.add_argument("--ring", type=int, default=10, help="distinct input blocks resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--concurrency", type=int, default=2, choices=[0, 1, 2],
+                    help="fmd_batch_set_concurrency mode (2 = calls overlap, the default)")
     ap.add_argument("--stage-profile", action="store_true",
                     help="after the timed region, run 3 extra steps with per-stage events")
     args = ap.parse_args()
@@ -113,7 +115,7 @@ def main():
     pending = [None] * NBUF
     total_groups = 0
 
-    batch.set_concurrency(2)  # FIR of step i+1 overlaps the serial stages of step i
+    batch.set_concurrency(args.concurrency)  # 2: FIR of step i+1 overlaps the serial stages of step i
     LAG = 2  # outputs of step i are consumed after step i+2 is submitted: the host never stalls
     groups_by_call = {}
     state = {"submitted": -1, "finalized": -1}

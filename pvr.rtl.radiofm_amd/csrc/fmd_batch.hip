@@ -433,9 +433,14 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     return fail(FMD_ERR_DEVICE, "state reset failed");
 
   b->gdec.resize(C);
-  HIPCHK(hipStreamCreateWithFlags(&b->s_fir, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&b->s_ser, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&b->s_post, hipStreamNonBlocking));
+  { // the FIR feeds the pipeline and is the bandwidth-bound kernel: dispatch it first; the
+    // post chain has slack every call and goes last
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi)); // lo = least, hi = greatest priority
+    HIPCHK(hipStreamCreateWithPriority(&b->s_fir, hipStreamNonBlocking, hi));
+    HIPCHK(hipStreamCreateWithPriority(&b->s_ser, hipStreamNonBlocking, hi));
+    HIPCHK(hipStreamCreateWithPriority(&b->s_post, hipStreamNonBlocking, lo));
+  }
   for (auto& row : b->cev)
     for (auto& e : row)
       HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -571,7 +576,14 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
   signal(ce[fmd_batch::EV_IN], stream);
   after(sF, ce[fmd_batch::EV_IN]);
   if (have_prev2)
+  {
     after(sF, pe2[fmd_batch::EV_SER]); // demod[q] was last read by the serial stage two calls ago
+    // Also run behind the post chain of two calls ago.  During one serial stage (the pipeline's
+    // period) the chip has to fit one FIR and one post chain; back to back they each only share
+    // it with the light serial kernel, side by side both ran ~25 % slower (measured).
+    after(sF, pe2[fmd_batch::EV_AUD]);
+    after(sF, pe2[fmd_batch::EV_RDS]);
+  }
   mark(0);
   {
     constexpr int TILE = 256;

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, 
                                                  unsigned ntiles, unsigned xcd_map)
 {
   extern __shared__ __attribute__((aligned(16))) float2 win[];
+  __builtin_amdgcn_s_setprio(1); // ahead of the post-chain kernels it may share a SIMD with
   unsigned c, tile;
   if (xcd_map)
   {
@@ -261,25 +262,28 @@ __global__ __launch_bounds__(128) void k_demod_serial(
     DemodConsts k, ChannelState st, float2* __restrict__ br, unsigned Hbb,
     float2* __restrict__ mix, unsigned Hmix, const double* __restrict__ sctab_g, FmdSincosTab sct)
 {
-  __shared__ float chunk[2][DS][64];
+  __shared__ float chunk[2][DS][64];   // baseband, FM role -> pilot/RDS role
+  __shared__ float2 stage[2][DS][64];  // IF-FIR output, pilot/RDS role -> FM role
   __shared__ double sctab[2 * FMD_SINCOS_TAB_SIZE];
   // latency-bound recurrence: when bandwidth kernels of other calls share the SIMD, issue first
   __builtin_amdgcn_s_setprio(3);
   for (unsigned i = threadIdx.x; i < 2 * FMD_SINCOS_TAB_SIZE; i += 128)
     sctab[i] = sctab_g[i];
-  __syncthreads();
   const unsigned lane = threadIdx.x & 63u;
   const unsigned role = threadIdx.x >> 6;
   const unsigned c0 = blockIdx.x * 64 + lane;
   const bool active = c0 < C;
   const unsigned c = active ? c0 : C - 1; // padded lanes shadow the last channel, stores masked
   const unsigned nchunks = (M + DS - 1) / DS;
+  const float2* __restrict__ row = demod + (size_t)c * Mstride;
+  // chunk 0 of the input: both waves fetch half of it
+  for (unsigned u = role; u < DS; u += 2)
+    stage[0][u][lane] = row[min(u, M - 1)];
+  __syncthreads();
 
   if (role == 0)
   {
     float nco_phase = st.F(F_NCO_PHASE)[c], nco_incr = st.F(F_NCO_INCR)[c], dc = st.F(F_DC_OFF)[c];
-    const float2* __restrict__ row = demod + (size_t)c * Mstride;
-    float2 cur = row[0];
     for (unsigned j = 0; j <= nchunks; j++)
     {
       if (j < nchunks)
@@ -289,10 +293,8 @@ __global__ __launch_bounds__(128) void k_demod_serial(
 #pragma unroll 1
         for (unsigned u = 0; u < cnt; u++)
         {
-          const unsigned m = m0 + u;
-          const float2 nxt = row[(m + 1 < M) ? m + 1 : m]; // fetched one step ahead of its use
-          const float sre = cur.x, sim = cur.y;
-          cur = nxt;
+          const float2 sin_ = stage[j & 1][u][lane]; // staged one chunk ahead by the other wave
+          const float sre = sin_.x, sim = sin_.y;
           /* ---- FM PLL (FmDecode.cpp:371-413) ---- */
           float sn, cs;
           fmd_sincos_tab(nco_phase, sctab, sct, &sn, &cs);
@@ -349,6 +351,16 @@ __global__ __launch_bounds__(128) void k_demod_serial(
     float2* __restrict__ mixp = mix + (size_t)Hmix * CP + c;
     for (unsigned j = 0; j <= nchunks; j++)
     {
+      /* This wave has issue slots to spare, so it also moves the FM wave's input: while that wave
+       * works on chunk j, the IF-FIR samples of chunk j+1 travel HBM -> registers -> LDS here,
+       * a whole chunk ahead of their use, so no memory latency sits on the critical recurrence. */
+      const unsigned pf0 = (j + 1) * DS; // first sample of the chunk being staged
+      const bool staging = (j + 1) < nchunks;
+      if (j == 0 && staging)
+      { // nothing to consume yet: stage chunk 1 in one go
+        for (unsigned u = 0; u < DS; u++)
+          stage[1][u][lane] = row[min(pf0 + u, M - 1)];
+      }
       if (j >= 1)
       {
         const unsigned m0 = (j - 1) * DS;
@@ -356,6 +368,9 @@ __global__ __launch_bounds__(128) void k_demod_serial(
 #pragma unroll 1
         for (unsigned u = 0; u < cnt; u++)
         {
+          float2 pre = make_float2(0.0f, 0.0f);
+          if (staging)
+            pre = row[min(pf0 + u, M - 1)];
           const float v = chunk[(j - 1) & 1][u][lane];
           vsum += v;
           vsumsq += v * v;
@@ -403,7 +418,12 @@ __global__ __launch_bounds__(128) void k_demod_serial(
           }
           brp += CP;
           mixp += CP;
+          if (staging)
+            stage[(j + 1) & 1][u][lane] = pre;
         }
+        if (staging)
+          for (unsigned u = cnt; u < DS; u++) // only when the consumed chunk was the short last one
+            stage[(j + 1) & 1][u][lane] = row[min(pf0 + u, M - 1)];
       }
       __syncthreads();
     }
