@@ -88,6 +88,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     pkg = load_package()
+    import importlib
+    dg = importlib.import_module(pkg.__name__ + ".dist_gather")
     C = args.channels
     K, W = args.steps, args.warmup
     ring = max(1, min(args.ring, K + W))
@@ -134,23 +136,16 @@ def main():
         slot = i % NBUF
         if world > 1:
             parts = groups_by_call.pop(i + 1, [])
-            rec = np.zeros((RCAP, 4), dtype=np.int32)
-            if parts:
-                g = np.concatenate(parts)[:RCAP]
-                b = g["blocks"].astype(np.int64)
-                rec[:g.size, 0] = g["channel"] + 1
-                rec[:g.size, 1] = g["call_index"]
-                rec[:g.size, 2] = (b[:, 0] | (b[:, 1] << 16)).astype(np.uint32).view(np.int32)
-                rec[:g.size, 3] = (b[:, 2] | (b[:, 3] << 16)).astype(np.uint32).view(np.int32)
+            g = np.concatenate(parts) if parts else np.zeros(0, dtype=pkg.RDS_GROUP_DTYPE)
+            rec = dg.pack_rds_records(g, RCAP, channel_offset=rank * C)
             rds_dev[slot].copy_(torch.from_numpy(rec), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev)
-                w1 = dist.gather(audio[slot], g_audio[slot] if rank == 0 else None, dst=0,
-                                 async_op=True)
-                w2 = dist.gather(rds_dev[slot], g_rds[slot] if rank == 0 else None, dst=0,
-                                 async_op=True)
+                w1, w2 = dg.gather_step(audio[slot], rds_dev[slot],
+                                        g_audio[slot] if rank == 0 else None,
+                                        g_rds[slot] if rank == 0 else None, dst=0, async_op=True)
             pending[slot] = [w1, w2]
         state["finalized"] = i
 

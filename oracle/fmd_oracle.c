@@ -1979,6 +1979,11 @@ unsigned fmo_uecp_frame_get(const fmo_decoder* d, unsigned idx, uint8_t* out, un
   return f->len;
 }
 
+void fmo_debug_push_group(fmo_decoder* d, const uint16_t blocks[4])
+{
+  gd_decode(&d->rds.gd, blocks);
+}
+
 const char* fmo_channel_name(const fmo_decoder* d)
 {
   return d->rds.gd.channel_name;

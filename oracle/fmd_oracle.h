@@ -88,6 +88,8 @@ void fmo_rds_group_get(const fmo_decoder* d, unsigned idx, uint16_t blocks[4], u
 /* UECP frames as handed to cRadioReceiver::AddUECPDataFrame (unstuffed). */
 unsigned fmo_uecp_frame_count(const fmo_decoder* d);
 unsigned fmo_uecp_frame_get(const fmo_decoder* d, unsigned idx, uint8_t* out, unsigned cap);
+/* test hook: hand one group straight to the UECP group decoder */
+void fmo_debug_push_group(fmo_decoder* d, const uint16_t blocks[4]);
 /* Last PS name passed to SetChannelName, "" if none. */
 const char* fmo_channel_name(const fmo_decoder* d);
 

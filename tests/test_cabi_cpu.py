@@ -1,0 +1,144 @@
+"""CPU-only checks of the product library: it loads, exports every symbol include/fmd.h declares,
+fails loudly when no GPU is present (no CPU fallback), and its host-only pieces (UECP group
+decoder, byte stuffing) match the oracle and the reference's recorded frames."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import ROOT, load_package
+
+REF_UECP = [  # frames the reference handed to AddUECPDataFrame
+    "00 00 00 05 01 00 01 14 D3 0D 44",
+    "00 00 01 04 07 00 01 0A C1 31",
+    "00 00 02 04 03 00 01 00 64 6A",
+    "00 00 03 04 05 00 01 01 16 72",
+    "00 00 04 04 04 00 01 00 B8 A6",
+    "00 00 05 0B 02 00 01 54 45 53 54 46 4D 30 31 D3 49",
+]
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+def test_every_declared_symbol_is_exported(pkg):
+    hdr = open(os.path.join(ROOT, "include", "fmd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fmd_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    lib = pkg.lib()
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert set(pkg.EXPORTS) <= declared
+
+
+def test_no_gpu_fails_loudly(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.FmdError, match="no HIP device|CPU fallback|hip"):
+        pkg.Batch(pkg.make_params(2.4e6, -0.36e6, 48000.0, 15000.0, 11), 1)
+    with pytest.raises(pkg.FmdError):
+        pkg.FmDecoder(2.4e6, -0.36e6, 48000.0, 15000.0, 11)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product path must not import, link or load anything under oracle/."""
+    pkgdir = os.path.join(ROOT, "pvr.rtl.radiofm_amd")
+    for dirpath, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                code = re.sub(r'""".*?"""', "", text, flags=re.S)
+                code = re.sub(r"/\*.*?\*/", "", code, flags=re.S)
+                code = "\n".join(l for l in code.splitlines()
+                                 if not l.strip().startswith(("#", "//", "*")))
+                assert "fmd_oracle" not in code and "oracle_py" not in code, (f, "references oracle")
+                assert "libfmd_oracle" not in code
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(pkgdir, "libfmd_hip.so")], capture_output=True,
+                         text=True).stdout
+    assert "oracle" not in out
+
+
+def test_group_decoder_matches_reference_frames_and_oracle(pkg, oracle, fmsig):
+    # groups as the oracle's signal path produces them for the SURVEY test signal
+    fs = 2.4e6
+    p = fmsig.default_params(fs)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, 11)
+    for b in range(60):
+        o.process_stream(fmsig.generate_f32(p, b * 65536, 65536))
+    groups = [g for _, g in o.rds_groups()]
+    assert len(groups) >= 12
+    gd = pkg.GroupDecoder()
+    for g in groups:
+        gd.push(g)
+    assert gd.frames == o.uecp_frames()
+    assert [f.hex(" ").upper() for f in gd.frames[:6]] == REF_UECP
+    assert gd.name == "TESTFM01"
+
+
+def _rds_block_b(group, ver_b, pty=5, low5=0):
+    return (group << 12) | (int(ver_b) << 11) | (pty << 5) | low5
+
+
+def test_group_decoder_all_types_match_oracle(pkg, oracle):
+    """Synthetic groups of every decoded type (0A/0B, 1A, 2A/2B, 3A RT+/TFC, 4A, 8A, 10A, ODA
+    carriers, EON) through the product's host decoder and through the oracle's restatement."""
+    import ctypes
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+    groups = []
+    pi = 0xABCD
+    text = b"Hello from the MI355X radiotext test, 64 characters long okay!!"
+    for rep in range(2):
+        for seg in range(4):
+            groups.append((pi, _rds_block_b(0, rep, low5=(seg | 0x08 | (0x04 if seg == 3 else 0))),
+                           0xE0CD, int.from_bytes(b"PSNAME%02d"[:8][2 * seg:2 * seg + 2] if False
+                                                  else (b"STATION%d" % rep)[2 * seg:2 * seg + 2], "big")))
+        groups.append((pi, _rds_block_b(1, 0), 0x80E0, 0x1234 + rep))
+        groups.append((pi, _rds_block_b(3, 0, low5=0x16), 0x0000, 0x4BD7))  # 3A: RT+ on 11A
+        groups.append((pi, _rds_block_b(3, 0, low5=0x18), 0x1234, 0xCD46))  # 3A: TFC on 12A
+        for seg in range(16):
+            ab = rep << 4
+            groups.append((pi, _rds_block_b(2, 0, low5=ab | seg),
+                           int.from_bytes(text[4 * seg:4 * seg + 2], "big"),
+                           int.from_bytes(text[4 * seg + 2:4 * seg + 4], "big")))
+        groups.append((pi, _rds_block_b(2, 0, low5=(rep << 4) | 0), 0x4865, 0x6C6C))
+        groups.append((pi, _rds_block_b(11, 0, low5=3), 0x2222, 0x3333))   # RT+ ODA payload
+        groups.append((pi, _rds_block_b(12, 0, low5=1), 0x4444, 0x5555))   # TFC ODA payload
+        groups.append((pi, _rds_block_b(4, 0, low5=0x01), 0xCF51, 0x2C40))  # clock-time
+        groups.append((pi, _rds_block_b(8, 0, low5=9), 0xAAAA, 0xBBBB))     # TMC
+        groups.append((pi, _rds_block_b(10, 0, low5=rep), 0x4A41, 0x5A5A))  # PTYN
+        groups.append((pi, _rds_block_b(14, 0), 0x1111, 0x2222))            # EON: ignored
+        groups.append((pi, _rds_block_b(2, 1, low5=5), 0x0000, 0x4142))     # 2B
+        groups.append((pi, _rds_block_b(5, 0), 1, 2))                       # TDC: ignored
+    for _ in range(40):  # random groups, same PI so state carries over
+        groups.append((pi, int(rng.integers(0, 65536)), int(rng.integers(0, 65536)),
+                       int(rng.integers(0, 65536))))
+    groups.append((0x1234, _rds_block_b(0, 0), 0, 0x4142))  # PI change resets the decoder
+
+    gd = pkg.GroupDecoder()
+    for g in groups:
+        gd.push(g)
+
+    # the oracle's group decoder is reached through a decoder object; feed it directly
+    L.fmo_debug_push_group.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    o = oracle.OracleDecoder(2.4e6, -0.36e6, 48000.0, 15000.0, 11)
+    for g in groups:
+        arr = (ctypes.c_uint16 * 4)(*g)
+        L.fmo_debug_push_group(o._h, arr)
+    ref = o.uecp_frames()
+    assert len(ref) > 30
+    assert gd.frames == ref
+
+
+def test_uecp_byte_stuffing(pkg):
+    # RadioReceiver.cpp:387-414: 0xFE start, 0xFF stop, 0xFD/0xFE/0xFF -> 0xFD (v&3)-1
+    frame = bytes([0x00, 0xFD, 0x10, 0xFE, 0xFF, 0x7F])
+    assert pkg.stuff_uecp_frame(frame) == bytes([0xFE, 0x00, 0xFD, 0x00, 0x10, 0xFD, 0x01, 0xFD, 0x02,
+                                                 0x7F, 0xFF])

@@ -1,0 +1,88 @@
+"""The other BASELINE configs as parity cases, and the C++ drop-in class used from a program
+that links only libfmd_hip.so (no torch in the process)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import ROOT, load_package
+
+pytestmark = pytest.mark.gpu
+N = 65536
+
+
+def _bits_equal(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_config3_many_channels_from_one_capture(oracle, fmsig):
+    """BASELINE config 3: channels freq-shifted from ONE 2.4 MS/s capture (shared input, read
+    once per tile by every channel).  cFineTuner table_size = 256 (ctor parameter,
+    FmDecode.h:42) so shifts are k * 9.375 kHz; 256 channels, 8 of them checked bit for bit
+    against the oracle with the same shift."""
+    pkg = load_package()
+    fs, D, C, T = 2.4e6, 11, 256, 256
+    stations = [fmsig.default_params(fs, f_offset=f0, amp=0.12, noise_sigma=0.004, seed=50 + i,
+                                     pi=0x5000 + i, ps="CAP%05d" % i, f_left=500.0 + 300 * i)
+                for i, f0 in enumerate((-600e3, -360e3, -150e3, 75e3, 300e3, 600e3))]
+    shifts = np.arange(C, dtype=np.int32) - 128
+    b = pkg.Batch(pkg.make_params(fs, 0.0, 48000.0, 15000.0, D, table_size=T), C, tuning_shifts=shifts)
+    check = [0, 64, 90, 112, 136, 160, 192, 255]  # 64 -> -600 kHz ... 192 -> +600 kHz
+    refs = {c: oracle.OracleDecoder(fs, 0.0, 48000.0, 15000.0, D, table_size=T,
+                                    tuning_shift=int(shifts[c])) for c in check}
+    for blk in range(10):
+        cap = np.zeros(2 * N, dtype=np.float32)
+        for p in stations:
+            cap += fmsig.generate_f32(p, blk * N, N)
+        audio = b.process_host(cap.view(np.complex64), shared=True)
+        for c in check:
+            r = refs[c].process_stream(cap)
+            assert _bits_equal(audio[c], r), (blk, c)
+    # channel 64 (shift -64 * 9375 Hz = -600 kHz) brings the +600 kHz station to 0: it sees a pilot,
+    # channel 0 (tuned 1.2 MHz away from everything) does not
+    assert b.status(64).pilot_level > 0.08 > abs(b.status(0).pilot_level)
+
+
+def test_config5_long_fir_10msps(oracle, fmsig):
+    """BASELINE config 5 geometry: 4096-tap cDownsampleFilter at 10 MS/s, D = 46."""
+    pkg = load_package()
+    fs, D, C = 10e6, 46, 3
+    ps = [fmsig.default_params(fs, noise_sigma=0.01, seed=900 + c, pi=0x7000 + c) for c in range(C)]
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D, if_filter_order=4096), C)
+    refs = [oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D, if_filter_order=4096)
+            for _ in range(C)]
+    b.enable_taps()
+    for blk in range(4):
+        iq = np.stack([fmsig.generate_f32(ps[c], blk * N, N) for c in range(C)])
+        audio = b.process_host(iq.view(np.complex64).reshape(C, N))
+        for c in range(C):
+            r = refs[c].process_stream(iq[c])
+            assert _bits_equal(b.tap("demod", c), refs[c].taps()["demod"]), (blk, c)
+            assert _bits_equal(audio[c], r), (blk, c)
+
+
+def test_cpp_class_drop_in_without_torch(tmp_path, oracle, fmsig):
+    """tests/cpp/receiver_demo.cpp uses cFmDecoder exactly like cRadioReceiver does and links
+    only libfmd_hip.so; its audio and byte-stuffed UECP stream equal the oracle's."""
+    pkg = load_package()
+    exe = os.path.join(ROOT, "tests", "cpp", "receiver_demo")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "pvr.rtl.radiofm_amd", "csrc")])
+    fs, D, nblk = 2.4e6, 11, 40
+    p = fmsig.default_params(fs, noise_sigma=0.01, seed=3)
+    iq = np.concatenate([fmsig.generate_f32(p, b * N, N) for b in range(nblk)])
+    iq_path, a_path, u_path = tmp_path / "iq.f32", tmp_path / "audio.f32", tmp_path / "uecp.bin"
+    iq.tofile(iq_path)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    out = subprocess.run([exe, str(iq_path), str(fs), str(D), str(a_path), str(u_path)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    ref = np.concatenate([o.process_stream(iq[2 * N * b:2 * N * (b + 1)]) for b in range(nblk)])
+    got = np.fromfile(a_path, dtype=np.float32)
+    assert _bits_equal(got, ref)
+    stuffed = b"".join(pkg.stuff_uecp_frame(f) for f in o.uecp_frames())
+    assert u_path.read_bytes() == stuffed and len(stuffed) > 0
+    assert "stereo=1" in out.stdout and "name=TESTFM01" in out.stdout
