@@ -1,8 +1,16 @@
+#!/bin/bash
+# Round profile: run on the GPU box via  gpurun -- 'bash tools/prof_cmd.sh <tag>'
+# 1) plain bench (default flags)  2) rocprofv3 --kernel-trace --stats of the same command
+# 3) PMC passes on k_if_fir (separate runs, counters only)  -> gpurun_out/<tag>_*
+TAG=${1:-r1}
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-python bench.py --steps 6 --warmup 2 --stage-profile --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_ms']); print(d['stage_ms'])"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/prof_stats.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-include-regex "k_if_fir" --output-format csv -d gpurun_out/prof_pmc1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_pmc1.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_if_fir" --output-format csv -d gpurun_out/prof_pmc2 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_pmc2.log 2>&1
-rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-include-regex "k_if_fir" --output-format csv -d gpurun_out/prof_pmc3 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_pmc3.log 2>&1
-ls -R gpurun_out | head -40
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+tail -1 gpurun_out/${TAG}_bench.json
+python bench.py --concurrency 0 --stage-profile --no-cpu-baseline > gpurun_out/${TAG}_bench_serialised.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -- python bench.py --no-cpu-baseline > gpurun_out/${TAG}_stats.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-include-regex "k_if_fir" --output-format csv -d gpurun_out/${TAG}_pmc1 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --concurrency 0 > gpurun_out/${TAG}_pmc1.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_if_fir" --output-format csv -d gpurun_out/${TAG}_pmc2 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --concurrency 0 > gpurun_out/${TAG}_pmc2.log 2>&1
+rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-include-regex "k_if_fir" --output-format csv -d gpurun_out/${TAG}_pmc3 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --concurrency 0 > gpurun_out/${TAG}_pmc3.log 2>&1
+ls gpurun_out | head -30

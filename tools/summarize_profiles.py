@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Copies the judged summaries of a tools/prof_cmd.sh run from gpurun_out/ into profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+os.makedirs(pr, exist_ok=True)
+for name in ("bench", "bench_serialised"):
+    src = os.path.join(go, "%s_%s.json" % (tag, name))
+    if os.path.exists(src):
+        line = open(src).read().strip().splitlines()[-1]
+        json.loads(line)
+        open(os.path.join(pr, "%s_%s.json" % (tag, name)), "w").write(line + "\n")
+st = glob.glob(os.path.join(go, tag + "_stats", "**", "*_kernel_stats.csv"), recursive=True)
+if st:
+    shutil.copy(st[0], os.path.join(pr, tag + "_kernel_stats.csv"))
+out = open(os.path.join(pr, tag + "_pmc_k_if_fir.txt"), "w")
+out.write("rocprofv3 --pmc passes (separate runs, counters only) on k_if_fir<256,6,true>, 8192 channels,\n"
+          "bench.py --concurrency 0; mean per launch.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE\n"
+          "counts 1/2 of a wide coalesced read stream (MI355X_MICROARCH.md, HBM): read bytes = 2*FETCH_SIZE*1024.\n")
+vals = {}
+for d in ("pmc1", "pmc2", "pmc3"):
+    fs = glob.glob(os.path.join(go, "%s_%s" % (tag, d), "**", "*_counter_collection.csv"), recursive=True)
+    if not fs:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        vals[k] = sum(v) / len(v)
+        out.write("%-24s %14.6g  (n=%d)\n" % (k, vals[k], len(v)))
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    rd, wr = 2 * vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024
+    out.write("HBM traffic per launch: read %.4g B + write %.4g B = %.4g B (algorithmic 4.6854e9 B)\n"
+              % (rd, wr, rd + wr))
+    print("traffic per launch:", rd + wr)
+out.close()
+print(open(os.path.join(pr, tag + "_pmc_k_if_fir.txt")).read())
