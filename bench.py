@@ -60,8 +60,8 @@ def cpu_baseline(seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--channels", type=int, default=8192, help="channels per GPU")
     ap.add_argument("--ring", type=int, default=10, help="distinct input blocks resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -239,6 +239,14 @@ def main():
                          "avg_ms": round(fir_ms, 4), "launches_averaged": calls,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch)},
         }
+        # HBM bytes per launch from the PMC counters of the committed profile (same workload only;
+        # PMC needs its own rocprofv3 passes, it cannot be collected inside this run)
+        tpath = os.path.join(ROOT, "profiles", "traffic_k_if_fir.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath))
+            if t.get("channels") == C and t.get("samples_per_call") == N:
+                out["roofline"]["traffic"] = t["bytes_per_launch"]
+                out["roofline"]["traffic_source"] = t["source"]
         if stage_all:
             out["stage_ms"] = {k: round(v, 4) for k, v in stage_all.items()}
         if not args.no_cpu_baseline:

@@ -41,5 +41,11 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     out.write("HBM traffic per launch: read %.4g B + write %.4g B = %.4g B (algorithmic 4.6854e9 B)\n"
               % (rd, wr, rd + wr))
     print("traffic per launch:", rd + wr)
+    json.dump({"kernel": "k_if_fir", "channels": 8192, "samples_per_call": 65536,
+               "bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
+               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                         "read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024",
+               "source": "profiles/%s_pmc_k_if_fir.txt" % tag},
+              open(os.path.join(pr, "traffic_k_if_fir.json"), "w"), indent=1)
 out.close()
 print(open(os.path.join(pr, tag + "_pmc_k_if_fir.txt")).read())
