@@ -82,10 +82,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)"
                          % (args.gpus, world))
+    if os.environ.get("FMD_BENCH_SHARE_GPU") == "1":
+        local_rank = 0  # development aid, see below
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # RCCL ("nccl") on a real multi-GPU node.  FMD_BENCH_BACKEND=gloo + FMD_BENCH_SHARE_GPU=1 is a
+    # development aid: several ranks on ONE GPU with a host-staged gather, to exercise the N > 1
+    # control flow where only one GPU exists.
+    backend = os.environ.get("FMD_BENCH_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     pkg = load_package()
     import importlib
@@ -109,7 +118,7 @@ def main():
     audio = [torch.zeros((C, a_stride), dtype=torch.float32, device=dev) for _ in range(NBUF)]
     RCAP = C  # RDS records gathered per rank per step (<= 1 group per channel per 27 ms step)
     rds_dev = [torch.zeros((RCAP, 4), dtype=torch.int32, device=dev) for _ in range(NBUF)]
-    if world > 1 and rank == 0:
+    if world > 1 and rank == 0 and backend == "nccl":
         g_audio = [[torch.empty_like(audio[0]) for _ in range(world)] for _ in range(NBUF)]
         g_rds = [[torch.empty_like(rds_dev[0]) for _ in range(world)] for _ in range(NBUF)]
     stream = torch.cuda.current_stream().cuda_stream
@@ -143,9 +152,16 @@ def main():
             ev.record()
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev)
-                w1, w2 = dg.gather_step(audio[slot], rds_dev[slot],
-                                        g_audio[slot] if rank == 0 else None,
-                                        g_rds[slot] if rank == 0 else None, dst=0, async_op=True)
+                if backend == "nccl":
+                    w1, w2 = dg.gather_step(audio[slot], rds_dev[slot],
+                                            g_audio[slot] if rank == 0 else None,
+                                            g_rds[slot] if rank == 0 else None, dst=0, async_op=True)
+                else:  # host-staged (development only)
+                    comm_stream.synchronize()
+                    a_h, r_h = audio[slot].cpu(), rds_dev[slot].cpu()
+                    ga = [torch.empty_like(a_h) for _ in range(world)] if rank == 0 else None
+                    gr = [torch.empty_like(r_h) for _ in range(world)] if rank == 0 else None
+                    w1, w2 = dg.gather_step(a_h, r_h, ga, gr, dst=0, async_op=True)
             pending[slot] = [w1, w2]
         state["finalized"] = i
 
@@ -182,6 +198,11 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def reduce_scalar(x, op):
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
     for i in range(W):
         step(i)
     drain()
@@ -197,12 +218,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        tg = torch.tensor([total_groups], dtype=torch.int64, device=dev)
-        dist.all_reduce(tg)
-        total_groups = int(tg.item())
+        dt = reduce_scalar(dt, dist.ReduceOp.MAX)
+        total_groups = int(reduce_scalar(float(total_groups), dist.ReduceOp.SUM))
     stage, calls = batch.stage_ms()
     fir_ms = stage["if_fir"]
 
