@@ -85,6 +85,20 @@ struct RdsGroupRec
   uint16_t blocks[4];
 };
 
+/* Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits
+ * for this wave's outstanding global STORES (1-2 us each time); the role-waves and tile loops
+ * below only exchange data through LDS. */
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+/* Same for a single-wave workgroup: LDS operations of one wave execute in order, so only the
+ * compiler has to be kept from reordering across the exchange. */
+__device__ __forceinline__ void lds_wave_sync()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
   // std::complex<float> product: (ac - bd) + i(ad + bc), four products and two sums, each rounded
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(128) void k_demod_serial(
           chunk[j & 1][u][lane] = (pinc - dc) * k.demod_gain;
         }
       }
-      __syncthreads();
+      lds_barrier();
     }
     if (active)
     {
@@ -425,7 +439,7 @@ __global__ __launch_bounds__(128) void k_demod_serial(
           for (unsigned u = cnt; u < DS; u++) // only when the consumed chunk was the short last one
             stage[(j + 1) & 1][u][lane] = row[min(pf0 + u, M - 1)];
       }
-      __syncthreads();
+      lds_barrier();
     }
     if (active)
     {
@@ -886,7 +900,13 @@ __global__ void k_rs_table(const float* __restrict__ coeff, unsigned order, floa
     pidx[i] = pi;
 }
 
-constexpr int RS_R = 8; // outputs per thread; their windows overlap by ~(order - 4.5*7) rows
+#ifndef FMD_RS_R
+#define FMD_RS_R 4
+#endif
+#ifndef FMD_RS_B
+#define FMD_RS_B 8
+#endif
+constexpr int RS_R = FMD_RS_R; // outputs per thread; their windows overlap by ~(order - 4.5*7) rows
 
 /* Thread = (channel lane, group of RS_R consecutive outputs).  The union of the group's windows is
  * walked once from the newest row down; row `top - t` feeds output r with tap j = t - off_r
@@ -923,34 +943,37 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br,
   const int off0 = off[0];          // largest offset (oldest output of the group)
   const int tend = off0 + (int)order; // last row of the union window
 
-  auto edge_row = [&](int t) {
-    const float2 x = p[-(ptrdiff_t)t * CP];
-#pragma unroll
-    for (int r = 0; r < RS_R; r++)
-    {
-      const int j = t - off[r];
-      if (r < nr && j >= 0 && j <= (int)order)
-      {
-        const float kj = kp[r][t];
-        acc[r].x += kj * x.x;
-        acc[r].y += kj * x.y;
-      }
-    }
-  };
-
   if (nr == RS_R && off0 <= (int)order)
   {
+    // head / tail rows: only some outputs of the group take the row (no `r < nr` test here, so the
+    // compiler has no loop-invariant condition to unswitch the loops on)
+    auto edge_row = [&](int t) {
+      const float2 x = p[-(ptrdiff_t)t * CP];
+#pragma unroll
+      for (int r = 0; r < RS_R; r++)
+      {
+        const int j = t - off[r];
+        if (j >= 0 && j <= (int)order)
+        {
+          const float kj = kp[r][t];
+          acc[r].x += kj * x.x;
+          acc[r].y += kj * x.y;
+        }
+      }
+    };
     int t = 0;
+#pragma unroll 1
     for (; t < off0; t++) // head: the younger outputs have started, the older not yet
       edge_row(t);
-    for (; t + 8 <= (int)order + 1; t += 8) // body: every output of the group takes these rows
+    constexpr int RS_B = FMD_RS_B; // rows per batch: RS_R * RS_B taps live in SGPRs at a time
+    for (; t + RS_B <= (int)order + 1; t += RS_B) // body: every output of the group takes these rows
     {
-      float2 xs[8];
+      float2 xs[RS_B];
 #pragma unroll
-      for (int q = 0; q < 8; q++)
+      for (int q = 0; q < RS_B; q++)
         xs[q] = p[-(ptrdiff_t)(t + q) * CP];
 #pragma unroll
-      for (int q = 0; q < 8; q++)
+      for (int q = 0; q < RS_B; q++)
       {
 #pragma unroll
         for (int r = 0; r < RS_R; r++)
@@ -961,6 +984,7 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br,
         }
       }
     }
+#pragma unroll 1
     for (; t <= (int)order; t++)
     {
       const float2 x = p[-(ptrdiff_t)t * CP];
@@ -972,13 +996,28 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br,
         acc[r].y += kj * x.y;
       }
     }
+#pragma unroll 1
     for (; t <= tend; t++) // tail
       edge_row(t);
   }
   else
-  {
-    for (int t = 0; t <= tend; t++)
-      edge_row(t);
+  { // last, partial group of a call (or a degenerate geometry): one output at a time
+#pragma unroll
+    for (int r = 0; r < RS_R; r++)
+    {
+      if (r < nr)
+      {
+        const float* __restrict__ kt = ktab + (size_t)(i0 + r) * K1;
+        const float2* __restrict__ pr = p - (ptrdiff_t)off[r] * CP; // row of this output's pidx
+#pragma unroll 1
+        for (unsigned j = 0; j <= order; j++)
+        {
+          const float2 x = pr[-(ptrdiff_t)j * CP];
+          acc[r].x += kt[j] * x.x;
+          acc[r].y += kt[j] * x.y;
+        }
+      }
+    }
   }
 #pragma unroll
   for (int r = 0; r < RS_R; r++)
@@ -998,7 +1037,7 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
                                                    size_t audio_stride)
 {
   // [channel lane][AT_STEPS frames + pad]: one row = 128 B of a channel's interleaved L/R output
-  __shared__ float2 tile[64][AT_STEPS + 2];
+  __shared__ float2 tile[64][AT_STEPS + 1];
   __builtin_amdgcn_s_setprio(3);
   const unsigned lane = threadIdx.x;
   const unsigned c0 = blockIdx.x * 64 + lane;
@@ -1007,46 +1046,62 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
   float de_re = st.F(F_DE_RE)[c], de_im = st.F(F_DE_IM)[c];
   float w1a = st.F(F_N_W1A)[c], w2a = st.F(F_N_W2A)[c], w1b = st.F(F_N_W1B)[c], w2b = st.F(F_N_W2B)[c];
   const int stereo = st.I(I_STEREO)[c];
-  for (unsigned i0 = 0; i0 < A; i0 += AT_STEPS)
-  {
-    const unsigned cnt = min((unsigned)AT_STEPS, A - i0);
-    float2 vin[AT_STEPS];
+  const float one_minus_alpha = 1.0f - k.de_alpha;
+
+  auto frame = [&](float2 v) -> float2 { // v.x = stereo, v.y = mono (ProcessTwo's A, B)
+    de_re = one_minus_alpha * de_re + k.de_alpha * v.x;
+    const float s0 = de_re * 2.0f;
+    de_im = one_minus_alpha * de_im + k.de_alpha * v.y;
+    const float m0 = de_im * 2.0f;
+    const float w0a = s0 - k.n_a1 * w1a - k.n_a2 * w2a;
+    const float w0b = m0 - k.n_a1 * w1b - k.n_a2 * w2b;
+    const float s = k.n_b0 * w0a + k.n_b1 * w1a + k.n_b2 * w2a;
+    const float m = k.n_b0 * w0b + k.n_b1 * w1b + k.n_b2 * w2b;
+    w2a = w1a;
+    w1a = w0a;
+    w2b = w1b;
+    w1b = w0b;
+    const float mm = m * 0.5f;
+    return stereo ? make_float2((m + s) * 0.5f, (m - s) * 0.5f) : make_float2(mm, mm);
+  };
+  // 8 lanes write one channel's frames (8 B each) as consecutive pieces: 64-B segments
+  auto flush = [&](unsigned i0, unsigned cnt) {
+    lds_wave_sync(); // single wave: the LDS writes above are ordered before these reads
 #pragma unroll
-    for (unsigned u = 0; u < AT_STEPS; u++) // all loads of the tile in flight before the recurrence
-      vin[u] = lp[(size_t)min(i0 + u, A - 1) * CP + c];
-#pragma unroll
-    for (unsigned u = 0; u < AT_STEPS; u++)
-    {
-      if (u >= cnt)
-        break;
-      const float2 v = vin[u]; // x = stereo, y = mono
-      de_re = (1.0f - k.de_alpha) * de_re + k.de_alpha * v.x;
-      const float s0 = de_re * 2.0f;
-      de_im = (1.0f - k.de_alpha) * de_im + k.de_alpha * v.y;
-      const float m0 = de_im * 2.0f;
-      const float w0a = s0 - k.n_a1 * w1a - k.n_a2 * w2a;
-      const float w0b = m0 - k.n_a1 * w1b - k.n_a2 * w2b;
-      const float s = k.n_b0 * w0a + k.n_b1 * w1a + k.n_b2 * w2a;
-      const float m = k.n_b0 * w0b + k.n_b1 * w1b + k.n_b2 * w2b;
-      w2a = w1a;
-      w1a = w0a;
-      w2b = w1b;
-      w1b = w0b;
-      const float mm = m * 0.5f;
-      tile[lane][u] = stereo ? make_float2((m + s) * 0.5f, (m - s) * 0.5f) : make_float2(mm, mm);
-    }
-    __syncthreads(); // single wave: orders the LDS writes before the cross-lane reads
-    // 8 lanes write one channel's cnt frames (8 B each) as consecutive pieces
     for (unsigned q = 0; q < 8; q++)
     {
       const unsigned ch = q * 8 + (lane >> 3);
       const unsigned cg = blockIdx.x * 64 + ch;
       float2* __restrict__ o = reinterpret_cast<float2*>(audio + (size_t)cg * audio_stride) + i0;
-      for (unsigned f = (lane & 7u); f < cnt; f += 8)
-        if (cg < C)
+#pragma unroll
+      for (unsigned f0 = 0; f0 < AT_STEPS; f0 += 8)
+      {
+        const unsigned f = f0 + (lane & 7u);
+        if (f < cnt && cg < C)
           o[f] = tile[ch][f];
+      }
     }
-    __syncthreads();
+    lds_wave_sync();
+  };
+
+  unsigned i0 = 0;
+  for (; i0 + AT_STEPS <= A; i0 += AT_STEPS)
+  { // full tiles: all loads in flight first, then the recurrence out of registers
+    float2 vin[AT_STEPS];
+#pragma unroll
+    for (unsigned u = 0; u < AT_STEPS; u++)
+      vin[u] = lp[(size_t)(i0 + u) * CP + c];
+#pragma unroll
+    for (unsigned u = 0; u < AT_STEPS; u++)
+      tile[lane][u] = frame(vin[u]);
+    flush(i0, AT_STEPS);
+  }
+  if (i0 < A)
+  {
+    const unsigned cnt = A - i0;
+    for (unsigned u = 0; u < cnt; u++)
+      tile[lane][u] = frame(lp[(size_t)(i0 + u) * CP + c]);
+    flush(i0, cnt);
   }
   if (active)
   {
