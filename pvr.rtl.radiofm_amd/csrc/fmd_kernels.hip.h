@@ -279,10 +279,13 @@ __global__ __launch_bounds__(128) void k_demod_serial(
   __shared__ float chunk[2][DS][64];   // baseband, FM role -> pilot/RDS role
   __shared__ float2 stage[2][DS][64];  // IF-FIR output, pilot/RDS role -> FM role
   __shared__ double sctab[2 * FMD_SINCOS_TAB_SIZE];
+  __shared__ float atab[FMD_ATAN_TAB_FLOATS];
   // latency-bound recurrence: when bandwidth kernels of other calls share the SIMD, issue first
   __builtin_amdgcn_s_setprio(3);
   for (unsigned i = threadIdx.x; i < 2 * FMD_SINCOS_TAB_SIZE; i += 128)
     sctab[i] = sctab_g[i];
+  if (threadIdx.x == 0)
+    fmd_atan_table_fill(atab);
   const unsigned lane = threadIdx.x & 63u;
   const unsigned role = threadIdx.x >> 6;
   const unsigned c0 = blockIdx.x * 64 + lane;
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(128) void k_demod_serial(
           fmd_sincos_tab(nco_phase, sctab, sct, &sn, &cs);
           const float dre = cs * sre - sn * sim; // ComplexType(Cos, Sin) * signal[i]
           const float dim = cs * sim + sn * sre;
-          const float err = -fmd_atan2f_fast(dim, dre);
+          const float err = -fmd_atan2f_tab(dim, dre, atab);
           nco_incr += k.pll_beta * err;
           nco_incr = (nco_incr < k.nco_ll) ? k.nco_ll : nco_incr;
           nco_incr = (nco_incr > k.nco_hl) ? k.nco_hl : nco_incr;
@@ -325,11 +328,11 @@ __global__ __launch_bounds__(128) void k_demod_serial(
              * [-2pi, 0) the loop runs once; the clamps above keep every step inside
              * (-2pi, 4pi), anything else takes the literal slow path. */
             const double pd = (double)nco_phase;
-            const float down = (float)(pd - FMD_K_2PI);
-            const float up = (float)(pd + FMD_K_2PI);
             const bool ge = pd >= FMD_K_2PI;
             const bool lt = nco_phase < 0;
-            const float sel = ge ? down : (lt ? up : nco_phase);
+            const double off = ge ? -FMD_K_2PI : FMD_K_2PI;
+            const float moved = (float)(pd + off); // exact difference / sum, rounded once
+            const float sel = (ge | lt) ? moved : nco_phase;
             if (__builtin_expect((pd >= 2.0 * FMD_K_2PI) | (pd < -FMD_K_2PI), 0))
             {
               if (ge)

@@ -2,22 +2,23 @@
  * fmd_math.h -- transcendental helpers for the HIP kernels, written so that their float
  * results equal what the reference's CPU build produces:
  *
- *  - fmd_atan2f(): the reference calls atan2(float,float) -> glibc atan2f
+ *  - fmd_atan2f() / fmd_atan2f_tab(): the reference calls atan2(float,float) -> glibc atan2f
  *    (FmDecode.cpp:395).  glibc 2.35 (this image; libm is a third-party dependency of the
  *    reference, not vendored) implements atan2f/atanf with the fdlibm float algorithms
  *    (sysdeps/ieee754/flt-32/e_atan2f.c, s_atanf.c; Sun Microsystems 1993).  The published
  *    algorithm is restated here operation for operation in float arithmetic; with
  *    -ffp-contract=off every IEEE add/mul/div rounds like the host's, so the result is
- *    bit-identical (tests/test_device_math.py sweeps it against the host libm).
- *  - fmd_sincos_nco(): the reference uses the x87 fsincos instruction on the float phase
- *    and stores the 64-bit-mantissa result to float (FmDecode.cpp:167,386,
+ *    bit-identical (tests/test_device_math_cpu.py sweeps both forms against the host libm).
+ *  - fmd_sincos_nco() / fmd_sincos_tab(): the reference uses the x87 fsincos instruction on
+ *    the float phase and stores the 64-bit-mantissa result to float (FmDecode.cpp:167,386,
  *    RDSProcess.cpp:245).  That is the correctly rounded float sin/cos except for
  *    double-rounding cases of probability ~2^-40.  Here: evaluate in FP64 (< 1 ulp of
- *    double), round once to float; disagreement probability ~2^-28 per call.
+ *    double), round once to float; disagreement probability ~2^-28 per call (0 observed in
+ *    4x10^8).
  *  - fmd_rds_arctan2(): the reference's own polynomial arctan (RDSProcess.cpp:187-217),
  *    float with double intermediates.
  *
- * Usable from host C++ (for CPU tests of the restatement) and from HIP device code.
+ * Usable from host C (CPU sweep of the restatement) and from HIP device code.
  */
 #ifndef FMD_MATH_H
 #define FMD_MATH_H
@@ -250,70 +251,56 @@ FMD_HD void fmd_sincos_nco(float phase, float* s, float* c)
   *c = (float)co;
 }
 
-/* fdlibm atanf with the five argument ranges folded into one division and selects; same
- * operations in the same order as fmd_atanf() for every finite 2^-29 <= |x| < 2^25 (the
- * callers route anything else to fmd_atanf).  x must be >= 0. */
-FMD_HD float fmd_atanf_pos_fast(float x)
+/* Compact form of the same fdlibm atan2f for the per-sample PLL loop (no data-dependent branch
+ * except the rare-input test).  Per reduced range r (index 0 = no reduction, 1..4 = fdlibm id
+ * 0..3) the table holds a, b, c, d, hi, lo with
+ *   reduced argument = (a*q + b) / (c*q + d)        and   result = hi - ((p - lo) - xr)
+ * which reproduces every fdlibm operation: a*q and c*q are exact or the reference's own products
+ * (1*q, 2*q, 1.5*q, 0*q), adding b / d is the reference's add / subtract, and hi = lo = 0 turns
+ * the final expression into xr - p, the unreduced branch.  A single unsigned range test on the
+ * quotient sends zeros, infinities, NaNs and |y/x| outside [2^-29, 2^25) (which includes every
+ * exponent gap beyond 60) to the literal fmd_atan2f().  Bit-identical to glibc 2.35 atan2f on
+ * 6x10^8 inputs incl. range-edge stress (tests/test_device_math_cpu.py runs a shorter sweep). */
+#define FMD_ATAN_TAB_FLOATS 40 /* 5 ranges x 8 floats (6 used) */
+FMD_HD void fmd_atan_table_fill(float* t)
+{
+  const float v[5][8] = {
+      {1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0, 0},
+      {2.0f, -1.0f, 1.0f, 2.0f, 4.6364760399e-01f, 5.0121582440e-09f, 0, 0},
+      {1.0f, -1.0f, 1.0f, 1.0f, 7.8539812565e-01f, 3.7748947079e-08f, 0, 0},
+      {1.0f, -1.5f, 1.5f, 1.0f, 9.8279368877e-01f, 3.4473217170e-08f, 0, 0},
+      {0.0f, -1.0f, 1.0f, 0.0f, 1.5707962513e+00f, 7.5497894159e-08f, 0, 0}};
+  for (int r = 0; r < 5; r++)
+    for (int k = 0; k < 8; k++)
+      t[r * 8 + k] = v[r][k];
+}
+
+FMD_HD float fmd_atan2f_tab(float y, float x, const float* tab)
 {
   const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
               aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
               aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f,
               aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
-  const uint32_t ix = fmd_f2u(x);
-  const bool r0 = ix < 0x3ee00000u; /* < 0.4375: no reduction */
-  const bool r1 = ix < 0x3f300000u; /* < 0.6875 */
-  const bool r2 = ix < 0x3f980000u; /* < 1.1875 */
-  const bool r3 = ix < 0x401c0000u; /* < 2.4375 */
-  /* all candidate numerators / denominators are formed unconditionally (cheap, finite) so the
-   * choice compiles to selects, not exec-mask branches */
-  const float n1 = 2.0f * x - 1.0f, d1 = 2.0f + x;
-  const float n2 = x - 1.0f, d2 = x + 1.0f;
-  const float n3 = x - 1.5f, d3 = 1.0f + 1.5f * x;
-  float num = -1.0f, den = x, hi = 1.5707962513e+00f, lo = 7.5497894159e-08f;
-  num = r3 ? n3 : num;
-  den = r3 ? d3 : den;
-  hi = r3 ? 9.8279368877e-01f : hi;
-  lo = r3 ? 3.4473217170e-08f : lo;
-  num = r2 ? n2 : num;
-  den = r2 ? d2 : den;
-  hi = r2 ? 7.8539812565e-01f : hi;
-  lo = r2 ? 3.7748947079e-08f : lo;
-  num = r1 ? n1 : num;
-  den = r1 ? d1 : den;
-  hi = r1 ? 4.6364760399e-01f : hi;
-  lo = r1 ? 5.0121582440e-09f : lo;
-  num = r0 ? x : num;
-  den = r0 ? 1.0f : den;
-  const float xr = num / den; /* x/1 is exact for the unreduced range */
+  const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  const float q = fabsf(y / x);
+  const uint32_t iq = fmd_f2u(q);
+  if (iq - 0x31000000u >= 0x4c000000u - 0x31000000u) /* rare: see above */
+    return fmd_atan2f(y, x);
+  const int r = (iq >= 0x3ee00000u) + (iq >= 0x3f300000u) + (iq >= 0x3f980000u) + (iq >= 0x401c0000u);
+  const float* t = tab + 8 * r;
+  const float num = t[0] * q + t[1];
+  const float den = t[2] * q + t[3];
+  const float xr = num / den;
   const float z = xr * xr;
   const float w = z * z;
   const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
   const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
   const float p = xr * (s1 + s2);
-  const float small = xr - p;
-  const float big = hi - ((p - lo) - xr);
-  return r0 ? small : big;
-}
-
-/* fdlibm atan2f, common case branch-free; rare inputs (zeros, infinities, NaNs, huge ratios,
- * tiny or huge |y/x|) go through the literal restatement fmd_atan2f(). */
-FMD_HD float fmd_atan2f_fast(float y, float x)
-{
-  const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
-  const uint32_t hx = fmd_f2u(x), hy = fmd_f2u(y);
-  const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
-  const int32_t k = ((int32_t)iy - (int32_t)ix) >> 23;
-  const float q = fabsf(y / x);
-  const uint32_t iq = fmd_f2u(q);
-  const bool rare = (ix - 1u >= 0x7f7fffffu) | (iy - 1u >= 0x7f7fffffu) | (k > 60) | (k < -60) |
-                    (iq < 0x31000000u) | (iq >= 0x4c000000u);
-  if (rare)
-    return fmd_atan2f(y, x);
-  const float z = fmd_atanf_pos_fast(q);
-  const float t = z - pi_lo;
-  const float neg = fmd_u2f(fmd_f2u(z) ^ 0x80000000u);
-  const bool ysign = (hy >> 31) != 0, xsign = (hx >> 31) != 0;
-  return xsign ? (ysign ? (t - pi) : (pi - t)) : (ysign ? neg : z);
+  const float at = t[4] - ((p - t[5]) - xr); /* atanf(|y/x|) */
+  /* quadrant: x >= 0 -> at, x < 0 -> pi - (at - pi_lo); then the sign of y (m = 1, 3 negate) */
+  const float left = pi - (at - pi_lo);
+  const float base = ((int32_t)fmd_f2u(x) < 0) ? left : at;
+  return fmd_u2f(fmd_f2u(base) ^ (fmd_f2u(y) & 0x80000000u));
 }
 
 /* Table-driven variant of fmd_sincos_nco for the per-sample loops: 1024-entry table of

@@ -24,6 +24,8 @@ int main(int argc, char** argv)
 {
   long n = argc > 1 ? atol(argv[1]) : 10000000L;
   static double tab[2 * FMD_SINCOS_TAB_SIZE];
+  float atab[FMD_ATAN_TAB_FLOATS];
+  fmd_atan_table_fill(atab);
   const long double twopi = 6.283185307179586476925286766559005768L;
   for (int k = 0; k < FMD_SINCOS_TAB_SIZE; k++)
   {
@@ -69,7 +71,7 @@ int main(int argc, char** argv)
         x = ((int32_t)(r >> 32)) / 2147483648.0f * 3e-2f;
     }
     const float ref = atan2f(y, x);
-    const float a = fmd_atan2f(y, x), f = fmd_atan2f_fast(y, x);
+    const float a = fmd_atan2f(y, x), f = fmd_atan2f_tab(y, x, atab);
     if (fmd_f2u(ref) != fmd_f2u(a) && !(ref != ref && a != a))
       bad_a++;
     if (fmd_f2u(ref) != fmd_f2u(f) && !(ref != ref && f != f))
@@ -83,6 +85,6 @@ int main(int argc, char** argv)
     bad_t += (fmd_f2u(s1) != fmd_f2u(s3)) + (fmd_f2u(c1) != fmd_f2u(c3));
     (void)bad_r;
   }
-  printf("n=%ld atan2f=%ld atan2f_fast=%ld sincos_nco=%ld sincos_tab=%ld\n", n, bad_a, bad_f, bad_s, bad_t);
+  printf("n=%ld atan2f=%ld atan2f_tab=%ld sincos_nco=%ld sincos_tab=%ld\n", n, bad_a, bad_f, bad_s, bad_t);
   return 0;
 }
