@@ -65,6 +65,10 @@ def main():
     ap.add_argument("--channels", type=int, default=8192, help="channels per GPU")
     ap.add_argument("--ring", type=int, default=10, help="distinct input blocks resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config5"],
+                    help="config4 (default, the metric's workload): independent channels @2.4 MS/s; "
+                         "config3: 256 channels from ONE shared capture (table_size 256); "
+                         "config5: 4096-tap IF FIR @10 MS/s, D=46, 4096 channels")
     ap.add_argument("--concurrency", type=int, default=2, choices=[0, 1, 2],
                     help="fmd_batch_set_concurrency mode (2 = calls overlap, the default)")
     ap.add_argument("--stage-profile", action="store_true",
@@ -96,6 +100,18 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
+    global FS, D
+    order = 0
+    table = 0
+    shared = False
+    if args.workload == "config5":
+        FS, D, order = 10e6, 46, 4096
+        if args.channels == 8192:
+            args.channels = 4096
+    elif args.workload == "config3":
+        table, shared = 256, True
+        if args.channels == 8192:
+            args.channels = 256
     pkg = load_package()
     import importlib
     dg = importlib.import_module(pkg.__name__ + ".dist_gather")
@@ -104,15 +120,30 @@ def main():
     ring = max(1, min(args.ring, K + W))
 
     # ---- inputs: ring of blocks, [ring][C][N] complex64, generated on the device ----
-    chans = [fmsig_py.channel_params(FS, rank * C + c) for c in range(C)]
-    gen = fmsig_py.DeviceGenerator(chans, dev)
-    iq = torch.empty((ring, C, N, 2), dtype=torch.float32, device=dev)
-    for r in range(ring):
-        gen.generate(iq[r], r * N, N)
+    if shared:
+        # one capture = six stations 200-300 kHz apart, generated per station and summed
+        offs = (-600e3, -360e3, -150e3, 75e3, 300e3, 600e3)
+        st = [fmsig_py.default_params(FS, f_offset=f0, amp=0.12, noise_sigma=0.004, seed=50 + i,
+                                      pi=0x5000 + i, ps="CAP%05d" % i, f_left=500.0 + 300 * i)
+              for i, f0 in enumerate(offs)]
+        gen = fmsig_py.DeviceGenerator(st, dev)
+        tmp = torch.empty((len(st), N, 2), dtype=torch.float32, device=dev)
+        iq = torch.empty((ring, 1, N, 2), dtype=torch.float32, device=dev)
+        for r in range(ring):
+            gen.generate(tmp, r * N, N)
+            iq[r, 0] = tmp.sum(dim=0)
+    else:
+        chans = [fmsig_py.channel_params(FS, rank * C + c) for c in range(C)]
+        gen = fmsig_py.DeviceGenerator(chans, dev)
+        iq = torch.empty((ring, C, N, 2), dtype=torch.float32, device=dev)
+        for r in range(ring):
+            gen.generate(iq[r], r * N, N)
     torch.cuda.synchronize()
 
-    batch = pkg.Batch(pkg.make_params(FS, -0.15 * FS, 48000.0, 15000.0, D), C, device=local_rank,
-                      record_callbacks=False)
+    shifts = (np.arange(C, dtype=np.int32) % table) - table // 2 if shared else None
+    batch = pkg.Batch(pkg.make_params(FS, 0.0 if shared else -0.15 * FS, 48000.0, 15000.0, D,
+                                      table_size=table, if_filter_order=order),
+                      C, tuning_shifts=shifts, device=local_rank, record_callbacks=False)
     a_stride = (batch.max_audio_floats(N) + 63) // 64 * 64
     NBUF = 4  # outputs are consumed two steps after they are produced
     audio = [torch.zeros((C, a_stride), dtype=torch.float32, device=dev) for _ in range(NBUF)]
@@ -171,8 +202,8 @@ def main():
             for w in pending[slot]:
                 w.wait()
             pending[slot] = None
-        nf = batch.process_device(iq[i % ring].data_ptr(), N, N, audio[slot].data_ptr(), a_stride,
-                                  stream)
+        nf = batch.process_device(iq[i % ring].data_ptr(), 0 if shared else N, N,
+                                  audio[slot].data_ptr(), a_stride, stream)
         state["submitted"] = i
         if i - LAG > state["finalized"]:
             # orders the torch stream after the calls that are at least LAG old, drains their groups
@@ -235,18 +266,25 @@ def main():
     if rank == 0:
         samples_per_step = C * N
         value = world * samples_per_step * K / dt / 1e6
-        # algorithmic bytes of the fused tuner+FIR kernel: read 8 B per IQ sample, write 8/D B
-        # (SURVEY.md 8(d)); one launch processes C*N samples.
-        bytes_per_launch = samples_per_step * (8.0 + 8.0 / D)
+        # algorithmic bytes of the fused tuner+FIR kernel: read 8 B per IQ sample (8/C for a capture
+        # shared by C channels), write 8/D B; one launch processes C*N samples.
+        bytes_per_launch = samples_per_step * ((8.0 / C if shared else 8.0) + 8.0 / D)
+        taps = order if order else 8 * D
+        flops_per_launch = samples_per_step * (6.0 + 4.0 * taps / D)
         achieved = bytes_per_launch / (fir_ms * 1e-3) / 1e9
         out = {
             "metric": "IQ MS/s demodulated (whole node) + achieved HBM GB/s on FIR stage",
             "value": round(value, 1), "unit": "MS/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[3] per-GPU shard: %d independent FM "
-                                   "stereo+RDS channels/GPU @2.4 MS/s, 65536 IQ/channel/step, "
-                                   "D=11, 88-tap IF FIR, full ProcessStream path" % C,
+            "config": {"workload": {
+                "config4": "BASELINE configs[3] per-GPU shard: %d independent FM stereo+RDS "
+                           "channels/GPU @2.4 MS/s, 65536 IQ/channel/step, D=11, 88-tap IF FIR, "
+                           "full ProcessStream path" % C,
+                "config3": "BASELINE configs[2]: %d channels freq-shifted from ONE shared 2.4 MS/s "
+                           "capture (table_size 256), full ProcessStream path" % C,
+                "config5": "BASELINE configs[4]: %d channels @10 MS/s, D=46, 4096-tap IF FIR, full "
+                           "ProcessStream path" % C}[args.workload],
                        "channels_per_gpu": C, "samples_per_call": N, "input_ring_blocks": ring,
                        "audio_floats_per_channel_step": nf, "rds_groups_in_timed_region": total_groups,
                        "gather": "rank-0 RCCL gather of audio+RDS per step" if world > 1 else "none (1 GPU)"},
@@ -254,14 +292,15 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "k_if_fir (cFineTuner + cDownsampleFilter complex)",
                          "avg_ms": round(fir_ms, 4), "launches_averaged": calls,
-                         "algorithmic_bytes_per_launch": int(bytes_per_launch)},
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                         "valu_tflops_nofma": round(flops_per_launch / (fir_ms * 1e-3) / 1e12, 2)},
         }
         # HBM bytes per launch from the PMC counters of the committed profile (same workload only;
         # PMC needs its own rocprofv3 passes, it cannot be collected inside this run)
         tpath = os.path.join(ROOT, "profiles", "traffic_k_if_fir.json")
         if os.path.exists(tpath):
             t = json.load(open(tpath))
-            if t.get("channels") == C and t.get("samples_per_call") == N:
+            if args.workload == "config4" and t.get("channels") == C and t.get("samples_per_call") == N:
                 out["roofline"]["traffic"] = t["bytes_per_launch"]
                 out["roofline"]["traffic_source"] = t["source"]
         if stage_all:
