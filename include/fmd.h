@@ -35,6 +35,9 @@ extern "C" {
 /* Below this the reference's half-band stages stop filtering (DownConvert.cpp:519-520) and
  * its level meters divide by zero; the GPU path rejects such calls instead of imitating it. */
 #define FMD_MIN_BLOCK 8192u
+/* A further limit inherited from the reference: samples / downsample (the baseband length of a
+ * call) must stay below 32768 - 51, the size of its half-band delay lines (DownConvert.cpp:267,
+ * :500; it overruns them silently).  Only matters for downsample < 3. */
 
 /* Constructor arguments of cFmDecoder (FmDecode.h:110-116).  table_size / if_filter_order are
  * the two internal constants BASELINE configs 3 and 5 override; 0 selects the reference

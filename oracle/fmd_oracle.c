@@ -1850,6 +1850,12 @@ static void fm_pll(fmo_decoder* d, const cf32* sig, float* out, unsigned n) /* :
 
 unsigned fmo_process_stream(fmo_decoder* d, const float* iq, unsigned samples, float* audio)
 {
+  /* Preconditions the reference leaves unchecked: its work buffers hold 65536 samples
+   * (FmDecode.cpp:277-282) and its half-band delay lines 32768 (DownConvert.cpp:267,500), so a
+   * call whose baseband length exceeds 32768 - taps + 1 overruns the heap there.  Refuse. */
+  if (samples == 0 || samples > FMO_MAX_BLOCK ||
+      (samples + d->downsample - 1) / d->downsample + 51 > HB_BUFSIZE)
+    return 0;
   unsigned n = samples;
   const cf32* in = (const cf32*)iq;
   d->rds.call_index++;

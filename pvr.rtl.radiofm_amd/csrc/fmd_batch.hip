@@ -498,6 +498,10 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
   const unsigned M = pos < N ? (N - pos + D - 1) / D : 0; // DownConvert.cpp:112,123
   if (M == 0)
     return fail(FMD_ERR_SIZE, "block shorter than the decimator phase");
+  // the reference's half-band delay lines hold 32768 samples (DownConvert.cpp:267,500); longer
+  // baseband blocks overrun its heap, so they are outside the contract here too
+  if ((N + D - 1) / D + 51 > 32768)
+    return fail(FMD_ERR_SIZE, "baseband block longer than the reference's half-band buffers (32768)");
   std::vector<unsigned> hb_in(d.hb.size());
   unsigned R = M;
   for (size_t s = 0; s < d.hb.size(); s++)

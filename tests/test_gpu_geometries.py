@@ -1,0 +1,100 @@
+"""Parity over other geometries the constructor accepts: odd / even / unit decimation, a
+non-power-of-two tuner table, 75 us de-emphasis, channel counts that exercise lane padding and
+both block->channel mappings, and the size limits of a call."""
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+N = 65536
+
+
+def _bits_equal(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_unit_decimation_half_blocks(oracle, fmsig):
+    """downsample = 1 (fs = 250 kHz): blocks of 32000 samples, the largest class of call the
+    reference itself can process without overrunning its half-band buffers."""
+    pkg = load_package()
+    fs, D, n = 250e3, 1, 32000
+    p = fmsig.default_params(fs, noise_sigma=0.01, seed=11)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 1)
+    for blk in range(6):
+        iq = fmsig.generate_f32(p, blk * n, n)
+        r = o.process_stream(iq)
+        a = b.process_host(iq.view(np.complex64), shared=True)[0]
+        assert r.size > 0 and _bits_equal(a, r), blk
+
+
+GEOMS = [
+    # fs, D, kwargs for both decoders, blocks
+    (1.2e6, 5, {}, 8),
+    (2.048e6, 9, {}, 8),
+    (1.92e6, 8, {}, 8),
+    (2.4e6, 11, {"table_size": 100}, 6),       # '%' tuner path (table not a power of two)
+    (2.4e6, 11, {"us_version": True}, 6),      # 75 us de-emphasis (FmDecode.cpp:297-298)
+    (2.4e6, 11, {"if_filter_order": 250}, 6),  # even order != 8*D
+]
+
+
+@pytest.mark.parametrize("fs,D,kw,nblk", GEOMS)
+def test_geometry_bit_exact(oracle, fmsig, fs, D, kw, nblk):
+    pkg = load_package()
+    p = fmsig.default_params(fs, noise_sigma=0.01, seed=11)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D, **kw)
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D, **kw), 1)
+    for blk in range(nblk):
+        iq = fmsig.generate_f32(p, blk * N, N)
+        r = o.process_stream(iq)
+        a = b.process_host(iq.view(np.complex64), shared=True)[0]
+        assert _bits_equal(a, r), (blk, a.shape, r.shape)
+    so, sg = o.status(), b.status()
+    assert sg.stereo_detected == so.stereo and sg.rds_state == so.rds_state
+    assert np.float32(sg.pilot_level) == np.float32(so.pilot_level)
+    assert b.sink.frames.get(0, []) == o.uecp_frames()
+
+
+@pytest.mark.parametrize("C", [72, 130])
+def test_channel_counts_with_padding(oracle, fmsig, C):
+    """C = 72 (multiple of 8: XCD-aware mapping, 56 padded lanes) and C = 130 (plain mapping)."""
+    pkg = load_package()
+    fs, D = 2.4e6, 11
+    base = [fmsig.default_params(fs, noise_sigma=0.01, seed=200 + k, f_left=300.0 + 211 * k)
+            for k in range(3)]
+    check = [0, 1, C // 2, C - 1]
+    refs = {c: oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for c in check}
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C)
+    for blk in range(5):
+        src = [fmsig.generate_f32(p, blk * N, N) for p in base]
+        iq = np.stack([src[c % 3] for c in range(C)])
+        a = b.process_host(iq.view(np.complex64).reshape(C, N))
+        for c in check:
+            assert _bits_equal(a[c], refs[c].process_stream(iq[c])), (blk, c)
+
+
+def test_call_size_limits(fmsig):
+    pkg = load_package()
+    fs, D = 2.4e6, 11
+    d = pkg.FmDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    p = fmsig.default_params(fs)
+    assert d.ProcessStream(fmsig.generate_f32(p, 0, 65536).view(np.complex64)).size in (2620, 2622)
+    assert d.ProcessStream(fmsig.generate_f32(p, 65536, 8192).view(np.complex64)).size > 300
+    for bad in (0, 1, 8191, 65537):
+        with pytest.raises(pkg.FmdError):
+            d.ProcessStream(np.zeros(bad, np.complex64))
+    # downsample = 1: a 65536-sample call would overrun the reference's 32768-entry half-band
+    # buffers (DownConvert.cpp:267,500): rejected; half-size calls are fine
+    d1 = pkg.FmDecoder(250e3, -37500.0, 48000.0, 15000.0, 1)
+    with pytest.raises(pkg.FmdError):
+        d1.ProcessStream(np.zeros(65536, np.complex64))
+    p1 = fmsig.default_params(250e3)
+    assert d1.ProcessStream(fmsig.generate_f32(p1, 0, 32000).view(np.complex64)).size > 10000
+    # unsupported configurations fail at construction, loudly
+    with pytest.raises(pkg.FmdError):
+        pkg.FmDecoder(400e3, 0.0, 48000.0, 15000.0, 1)  # baseband 400 kHz needs the 11-tap half-band
+    with pytest.raises(pkg.FmdError):
+        pkg.Batch(pkg.make_params(0.0, 0.0), 1)
