@@ -69,6 +69,10 @@ def main():
                     help="config4 (default, the metric's workload): independent channels @2.4 MS/s; "
                          "config3: 256 channels from ONE shared capture (table_size 256); "
                          "config5: 4096-tap IF FIR @10 MS/s, D=46, 4096 channels")
+    ap.add_argument("--input", default="f32", choices=["f32", "u8"],
+                    help="f32: complex<float> blocks, the ProcessStream argument (BASELINE metric); "
+                         "u8: RTL-SDR byte pairs converted inside the IF kernel (SURVEY 8(f)-2, "
+                         "reported as its own workload: 2 B instead of 8 B read per IQ sample)")
     ap.add_argument("--concurrency", type=int, default=2, choices=[0, 1, 2],
                     help="fmd_batch_set_concurrency mode (2 = calls overlap, the default)")
     ap.add_argument("--stage-profile", action="store_true",
@@ -112,6 +116,10 @@ def main():
         table, shared = 256, True
         if args.channels == 8192:
             args.channels = 256
+    u8 = args.input == "u8"
+    if u8 and shared:
+        raise SystemExit("--input u8 is implemented for the per-channel workloads")
+    in_dtype = torch.uint8 if u8 else torch.float32
     pkg = load_package()
     import importlib
     dg = importlib.import_module(pkg.__name__ + ".dist_gather")
@@ -135,7 +143,7 @@ def main():
     else:
         chans = [fmsig_py.channel_params(FS, rank * C + c) for c in range(C)]
         gen = fmsig_py.DeviceGenerator(chans, dev)
-        iq = torch.empty((ring, C, N, 2), dtype=torch.float32, device=dev)
+        iq = torch.empty((ring, C, N, 2), dtype=in_dtype, device=dev)
         for r in range(ring):
             gen.generate(iq[r], r * N, N)
     torch.cuda.synchronize()
@@ -203,7 +211,7 @@ def main():
                 w.wait()
             pending[slot] = None
         nf = batch.process_device(iq[i % ring].data_ptr(), 0 if shared else N, N,
-                                  audio[slot].data_ptr(), a_stride, stream)
+                                  audio[slot].data_ptr(), a_stride, stream, u8=u8)
         state["submitted"] = i
         if i - LAG > state["finalized"]:
             # orders the torch stream after the calls that are at least LAG old, drains their groups
@@ -268,7 +276,8 @@ def main():
         value = world * samples_per_step * K / dt / 1e6
         # algorithmic bytes of the fused tuner+FIR kernel: read 8 B per IQ sample (8/C for a capture
         # shared by C channels), write 8/D B; one launch processes C*N samples.
-        bytes_per_launch = samples_per_step * ((8.0 / C if shared else 8.0) + 8.0 / D)
+        in_bytes = 2.0 if u8 else 8.0
+        bytes_per_launch = samples_per_step * ((in_bytes / C if shared else in_bytes) + 8.0 / D)
         taps = order if order else 8 * D
         flops_per_launch = samples_per_step * (6.0 + 4.0 * taps / D)
         achieved = bytes_per_launch / (fir_ms * 1e-3) / 1e9
@@ -284,7 +293,10 @@ def main():
                 "config3": "BASELINE configs[2]: %d channels freq-shifted from ONE shared 2.4 MS/s "
                            "capture (table_size 256), full ProcessStream path" % C,
                 "config5": "BASELINE configs[4]: %d channels @10 MS/s, D=46, 4096-tap IF FIR, full "
-                           "ProcessStream path" % C}[args.workload],
+                           "ProcessStream path" % C}[args.workload]
+                + (" -- input as RTL-SDR u8 byte pairs, ReadAsyncCB conversion fused into the IF "
+                   "kernel (SURVEY 8(f)-2; not the BASELINE metric's input format)" if u8 else ""),
+                       "input_format": args.input,
                        "channels_per_gpu": C, "samples_per_call": N, "input_ring_blocks": ring,
                        "audio_floats_per_channel_step": nf, "rds_groups_in_timed_region": total_groups,
                        "gather": "rank-0 RCCL gather of audio+RDS per step" if world > 1 else "none (1 GPU)"},
@@ -300,7 +312,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_k_if_fir.json")
         if os.path.exists(tpath):
             t = json.load(open(tpath))
-            if args.workload == "config4" and t.get("channels") == C and t.get("samples_per_call") == N:
+            if (args.workload == "config4" and not u8 and t.get("channels") == C
+                    and t.get("samples_per_call") == N):
                 out["roofline"]["traffic"] = t["bytes_per_launch"]
                 out["roofline"]["traffic_source"] = t["source"]
         if stage_all:

@@ -99,6 +99,11 @@ int fmd_reset(fmd_decoder* d);
  * audio = caller buffer of samples*2 floats (RadioReceiver.cpp:519-520); returns the number
  * of floats written (2 per audio frame) or a negative error. */
 int fmd_process_stream(fmd_decoder* d, const float* iq, unsigned samples, float* audio);
+/* cRtlSdrSource::ReadAsyncCB (RTL_SDR_Source.cpp:196-213) + ProcessStream in one call: buf =
+ * 2*samples bytes as librtlsdr delivers them (I, Q, I, Q, ...).  Every byte is converted with the
+ * reference's float(b / (255.0 / 2.0) - 1.0) inside the IF kernel, so the result equals
+ * fmd_process_stream on the converted block; the transfer and the HBM read are 4x smaller. */
+int fmd_process_stream_u8(fmd_decoder* d, const uint8_t* buf, unsigned samples, float* audio);
 int fmd_get_status(fmd_decoder* d, fmd_status* st);
 
 /* ---- batch of independent channels on one GPU -------------------------------------- */
@@ -127,11 +132,21 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
                              unsigned samples, float* d_audio, size_t audio_channel_stride,
                              unsigned* out_floats, void* stream);
 
+/* Same with RTL-SDR byte pairs as input (see fmd_process_stream_u8): channel c starts at
+ * d_iq_u8 + 2*c*iq_channel_stride bytes.  Both entry points need the pointer and the channel
+ * stride to be multiples of two IQ samples (16 bytes of float IQ, 4 bytes of byte IQ). */
+int fmd_batch_process_device_u8(fmd_batch* b, const uint8_t* d_iq_u8, size_t iq_channel_stride,
+                                unsigned samples, float* d_audio, size_t audio_channel_stride,
+                                unsigned* out_floats, void* stream);
+
 /* Host-buffer call: copies in, runs fmd_batch_process_device, copies audio out, collects RDS
  * groups and runs the UECP group decoder (callbacks fire here).  Synchronous. */
 int fmd_batch_process_host(fmd_batch* b, const float* iq, size_t iq_channel_stride,
                            unsigned samples, float* audio, size_t audio_channel_stride,
                            unsigned* out_floats);
+int fmd_batch_process_host_u8(fmd_batch* b, const uint8_t* iq_u8, size_t iq_channel_stride,
+                              unsigned samples, float* audio, size_t audio_channel_stride,
+                              unsigned* out_floats);
 
 /* Copies the queued RDS groups (all channels, call order) to `out`, waits for `stream`.
  * Returns the number of groups (<= cap) or a negative error.  When run_group_decoder != 0

@@ -1493,6 +1493,17 @@ float fmo_rds_arctan2(float y, float x)
   return rds_arctan2(y, x);
 }
 
+/* cRtlSdrSource::ReadAsyncCB, RTL_SDR_Source.cpp:207-211: ComplexType(buf[2i] / (255.0/2.0) - 1.0,
+ * buf[2i+1] / (255.0/2.0) - 1.0) -- double arithmetic, narrowed by the complex<float> ctor. */
+void fmo_convert_u8(const uint8_t* buf, unsigned samples, float* iq)
+{
+  for (unsigned i = 0; i < samples; i++)
+  {
+    iq[2 * i] = (float)(buf[2 * i] / (255.0 / 2.0) - 1.0);
+    iq[2 * i + 1] = (float)(buf[2 * i + 1] / (255.0 / 2.0) - 1.0);
+  }
+}
+
 static void rds_pll(rds_proc* r, const cf32* in, float* out, unsigned n) /* :222-270 */
 {
   for (unsigned i = 0; i < n; i++)

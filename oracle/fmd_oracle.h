@@ -80,6 +80,10 @@ unsigned fmo_process_stream(fmo_decoder* d, const float* iq, unsigned samples, f
 void fmo_get_status(const fmo_decoder* d, fmo_status* st);
 void fmo_get_taps(const fmo_decoder* d, fmo_taps* t);
 
+/* The byte -> complex<float> conversion in front of ProcessStream when the source is an RTL-SDR
+ * (cRtlSdrSource::ReadAsyncCB, RTL_SDR_Source.cpp:207-211): buf = 2*samples bytes. */
+void fmo_convert_u8(const uint8_t* buf, unsigned samples, float* iq);
+
 /* RDS group log: every uint16[4] handed to DecodeRDS (RDSProcess.cpp:312,355)
  * with the index of the ProcessStream call it happened in. */
 unsigned fmo_rds_group_count(const fmo_decoder* d);

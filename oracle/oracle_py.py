@@ -102,6 +102,7 @@ def lib():
         L.fmo_atan2f.argtypes = [C.c_float, C.c_float]
         L.fmo_rds_arctan2.restype = C.c_float
         L.fmo_rds_arctan2.argtypes = [C.c_float, C.c_float]
+        L.fmo_convert_u8.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
         L.fmo_sincos_x87.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _LIB = L
     return _LIB
@@ -114,6 +115,14 @@ CONST_NAMES = [
     "rds_rate", "rds_nco_inc", "rds_osc_cos", "rds_osc_sin", "rds_pll_alpha", "rds_pll_beta",
     "rds_nco_hl", "rds_nco_ll", "fs_bb", "rds_mf_len",
 ]
+
+
+def convert_u8(buf):
+    """RTL-SDR bytes -> interleaved float32 IQ exactly like cRtlSdrSource::ReadAsyncCB."""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    out = np.empty(buf.size, dtype=np.float32)
+    lib().fmo_convert_u8(buf.ctypes.data, buf.size // 2, out.ctypes.data)
+    return out
 
 
 class OracleDecoder:
@@ -151,6 +160,10 @@ class OracleDecoder:
         n = iq.size // 2
         k = lib().fmo_process_stream(self._h, iq.ctypes.data, n, self._audio.ctypes.data)
         return self._audio[:k].copy()
+
+    def process_stream_u8(self, buf):
+        """ReadAsyncCB conversion (RTL_SDR_Source.cpp:207-211) followed by ProcessStream."""
+        return self.process_stream(convert_u8(buf))
 
     def status(self):
         st = FmoStatus()

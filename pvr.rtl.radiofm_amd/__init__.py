@@ -77,7 +77,8 @@ RDS_GROUP_DTYPE = np.dtype([("channel", "<u4"), ("call_index", "<u4"), ("blocks"
 assert RDS_GROUP_DTYPE.itemsize == C.sizeof(FmdRdsGroup)
 
 EXPORTS = [
-    "fmd_create", "fmd_destroy", "fmd_reset", "fmd_process_stream", "fmd_get_status",
+    "fmd_create", "fmd_destroy", "fmd_reset", "fmd_process_stream", "fmd_process_stream_u8",
+    "fmd_get_status", "fmd_batch_process_device_u8", "fmd_batch_process_host_u8",
     "fmd_batch_create", "fmd_batch_destroy", "fmd_batch_reset", "fmd_batch_channels",
     "fmd_batch_max_audio_floats", "fmd_batch_process_device", "fmd_batch_process_host",
     "fmd_batch_collect_rds", "fmd_batch_collect_rds_lagged", "fmd_batch_set_concurrency",
@@ -113,6 +114,7 @@ def lib():
         L.fmd_destroy.argtypes = [vp]
         L.fmd_reset.argtypes = [vp]
         L.fmd_process_stream.argtypes = [vp, vp, u, vp]
+        L.fmd_process_stream_u8.argtypes = [vp, vp, u, vp]
         L.fmd_get_status.argtypes = [vp, C.POINTER(FmdStatus)]
         L.fmd_batch_create.argtypes = [C.POINTER(FmdParams), u, vp, i, C.POINTER(FmdCallbacks), vp,
                                        C.POINTER(vp)]
@@ -125,6 +127,8 @@ def lib():
         L.fmd_batch_process_device.argtypes = [vp, vp, C.c_size_t, u, vp, C.c_size_t,
                                                C.POINTER(u), vp]
         L.fmd_batch_process_host.argtypes = [vp, vp, C.c_size_t, u, vp, C.c_size_t, C.POINTER(u)]
+        L.fmd_batch_process_device_u8.argtypes = L.fmd_batch_process_device.argtypes
+        L.fmd_batch_process_host_u8.argtypes = L.fmd_batch_process_host.argtypes
         L.fmd_batch_collect_rds.argtypes = [vp, vp, u, i, vp]
         L.fmd_batch_collect_rds_lagged.argtypes = [vp, vp, u, i, i, vp]
         L.fmd_batch_set_concurrency.argtypes = [vp, i]
@@ -233,10 +237,31 @@ class Batch:
                                             a_stride, C.byref(nf)))
         return audio[:, :nf.value]
 
-    def process_device(self, d_iq_ptr, iq_stride, samples, d_audio_ptr, audio_stride, stream=None):
+    def process_host_u8(self, iq_u8, shared=False):
+        """iq_u8: [C, 2N] uint8 RTL-SDR byte pairs (or [2N] when shared).  Same result as
+        process_host on the converted block (RTL_SDR_Source.cpp:207-211)."""
+        iq_u8 = np.ascontiguousarray(iq_u8, dtype=np.uint8)
+        if shared:
+            n = iq_u8.size // 2
+            stride = 0
+        else:
+            iq_u8 = iq_u8.reshape(self.n_channels, -1)
+            n = iq_u8.shape[1] // 2
+            stride = n
+        a_stride = self.max_audio_floats(n)
+        audio = np.zeros((self.n_channels, a_stride), dtype=np.float32)
         nf = C.c_uint()
-        _check(lib().fmd_batch_process_device(self._h, d_iq_ptr, iq_stride, samples, d_audio_ptr,
-                                              audio_stride, C.byref(nf), stream))
+        _check(lib().fmd_batch_process_host_u8(self._h, iq_u8.ctypes.data, stride, n,
+                                               audio.ctypes.data, a_stride, C.byref(nf)))
+        return audio[:, :nf.value]
+
+    def process_device(self, d_iq_ptr, iq_stride, samples, d_audio_ptr, audio_stride, stream=None,
+                       u8=False):
+        """iq_stride in IQ samples; u8=True: d_iq_ptr holds RTL-SDR byte pairs."""
+        nf = C.c_uint()
+        fn = lib().fmd_batch_process_device_u8 if u8 else lib().fmd_batch_process_device
+        _check(fn(self._h, d_iq_ptr, iq_stride, samples, d_audio_ptr, audio_stride, C.byref(nf),
+                  stream))
         return nf.value
 
     def collect_rds_array(self, cap=65536, run_group_decoder=False, stream=None, lag=0):
@@ -330,6 +355,14 @@ class FmDecoder:
             iq = iq.astype(np.float32).view(np.complex64)
         audio = np.empty(2 * iq.size, dtype=np.float32)  # RadioReceiver.cpp:519-520 sizing
         n = _check(lib().fmd_process_stream(self._h, iq.ctypes.data, iq.size, audio.ctypes.data))
+        return audio[:n]
+
+    def ProcessStreamU8(self, buf):
+        """ReadAsyncCB + ProcessStream (RTL_SDR_Source.cpp:196-213): buf = I,Q byte pairs."""
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        n_iq = buf.size // 2
+        audio = np.empty(2 * n_iq, dtype=np.float32)
+        n = _check(lib().fmd_process_stream_u8(self._h, buf.ctypes.data, n_iq, audio.ctypes.data))
         return audio[:n]
 
     def _status(self):

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -480,14 +481,75 @@ unsigned fmd_batch_max_audio_floats(const fmd_batch* b, unsigned samples)
   return 2 * (unsigned(double(M) / double(b->des.rs_step)) + 4);
 }
 
-int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_stride,
-                             unsigned samples, float* d_audio, size_t audio_channel_stride,
-                             unsigned* out_floats, void* stream_)
+} // extern "C"
+
+namespace
+{
+
+/* The IF FIR kernel is instantiated for a few load depths (two-sample loads in flight per lane);
+ * the launch takes the smallest one that stages a tile's window in a single round trip. */
+template <class IN>
+using FirFn = void (*)(const typename IN::elem*, size_t, unsigned, const float2*, float2*, const float2*,
+                       unsigned, unsigned, const float*, unsigned, unsigned, unsigned, unsigned, float2*,
+                       unsigned, unsigned, unsigned);
+
+template <class IN>
+int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
+                    unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark)
+{
+  constexpr int TILE = 256;
+  const fmd::Design& d = b->des;
+  const unsigned C = b->C, D = d.D, T = d.table_size;
+  const unsigned ntiles = (M + TILE - 1) / TILE;
+  const size_t lds = (size_t(TILE - 1) * D + d.if_order + 4) * sizeof(float2);
+  if (lds > 160 * 1024)
+    return fail(FMD_ERR_ARG, "IF filter window does not fit in LDS");
+  // fast staging: the tuner table is a power of two that divides a tile's sample span, so a lane
+  // needs the same two table entries for every load (all reference configurations: T = 64)
+  const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
+  // loads per lane needed to stage one tile in a single round trip (two samples per load)
+  const unsigned rounds = unsigned(((size_t(TILE - 1) * D + d.if_order + 2) / 2 + TILE - 1) / TILE);
+  FirFn<IN> kfn = &fmd::k_if_fir<IN, TILE, 1, false>;
+  if (pow2)
+    kfn = rounds <= 2 ? &fmd::k_if_fir<IN, TILE, 2, true>
+        : rounds <= 4 ? &fmd::k_if_fir<IN, TILE, 4, true>
+        : rounds <= 6 ? &fmd::k_if_fir<IN, TILE, 6, true>
+                      : &fmd::k_if_fir<IN, TILE, 8, true>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const typename IN::elem* x = static_cast<const typename IN::elem*>(d_iq);
+  mark(0);
+  hipLaunchKernelGGL(kfn, dim3(C * ntiles), dim3(TILE), lds, sF, x, iq_channel_stride, N,
+                     b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, T, b->lut_idx,
+                     b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles,
+                     (C % 8 == 0) ? 1u : 0u);
+  mark(1);
+  hipLaunchKernelGGL(fmd::k_if_level<IN>, dim3(C), dim3(64), 0, sF, x, iq_channel_stride, N, b->lut.p, T,
+                     b->lut_idx, b->st);
+  return FMD_OK;
+}
+
+enum IqFormat
+{
+  IQ_F32 = 0, // complex<float>, the ProcessStream argument (FmDecode.h:135)
+  IQ_U8 = 1   // RTL-SDR byte pairs, converted like ReadAsyncCB (RTL_SDR_Source.cpp:207-211)
+};
+
+int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_channel_stride,
+                        unsigned samples, float* d_audio, size_t audio_channel_stride,
+                        unsigned* out_floats, void* stream_)
 {
   if (!b || !d_iq || !d_audio)
     return fail(FMD_ERR_ARG, "fmd_batch_process_device: null argument");
   if (samples > FMD_MAX_BLOCK || samples < FMD_MIN_BLOCK)
     return fail(FMD_ERR_SIZE, "samples must be within [FMD_MIN_BLOCK, FMD_MAX_BLOCK]");
+  // a lane loads two IQ samples at a time: every channel's stream has to start on a pair boundary
+  {
+    const size_t pair = fmt == IQ_U8 ? 4 : 16;
+    if ((reinterpret_cast<uintptr_t>(d_iq) % pair) || ((iq_channel_stride * (pair / 2)) % pair))
+      return fail(FMD_ERR_ARG, "IQ pointer and channel stride must be multiples of two IQ samples");
+  }
   const fmd::Design& d = b->des;
   const unsigned C = b->C, CP = b->CP, N = samples, D = d.D;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -588,35 +650,14 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
     after(sF, pe2[fmd_batch::EV_AUD]);
     after(sF, pe2[fmd_batch::EV_RDS]);
   }
-  mark(0);
   {
-    constexpr int TILE = 256;
-    const unsigned ntiles = (M + TILE - 1) / TILE;
-    const size_t lds = (size_t(TILE - 1) * D + d.if_order + 4) * sizeof(float2);
-    if (lds > 160 * 1024)
-      return fail(FMD_ERR_ARG, "IF filter window does not fit in LDS");
-    const bool pow2 = (d.table_size & (d.table_size - 1)) == 0 && d.table_size <= 2 * TILE;
-    // loads per lane needed to stage one tile in a single round trip (two samples per load)
-    const unsigned rounds = ((size_t(TILE - 1) * D + d.if_order + 2) / 2 + TILE - 1) / TILE;
-    auto kfn = &fmd::k_if_fir<TILE, 4, false>;
-    if (pow2)
-      kfn = rounds <= 2 ? &fmd::k_if_fir<TILE, 2, true>
-          : rounds <= 4 ? &fmd::k_if_fir<TILE, 4, true>
-          : rounds <= 6 ? &fmd::k_if_fir<TILE, 6, true>
-                        : &fmd::k_if_fir<TILE, 8, true>;
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kfn, dim3(C * ntiles), dim3(TILE), lds, sF,
-                       reinterpret_cast<const float2*>(d_iq), iq_channel_stride, N,
-                       b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, d.table_size,
-                       b->lut_idx, b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride,
-                       ntiles, (C % 8 == 0) ? 1u : 0u);
+    const std::function<void(int)> markfn = mark;
+    const int rc = fmt == IQ_U8
+                       ? launch_if_stage<fmd::InU8>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn)
+                       : launch_if_stage<fmd::InF32>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn);
+    if (rc != FMD_OK)
+      return rc;
   }
-  mark(1);
-  hipLaunchKernelGGL(fmd::k_if_level, dim3(C), dim3(64), 0, sF,
-                     reinterpret_cast<const float2*>(d_iq), iq_channel_stride, N, b->lut.p,
-                     d.table_size, b->lut_idx, b->st);
   signal(ce[fmd_batch::EV_FIR], sF);
 
   /* ---- K2: baseband-rate recurrences  (stream S) ---- */
@@ -767,6 +808,26 @@ int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_
   return FMD_OK;
 }
 
+} // namespace
+
+extern "C" {
+
+int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_stride,
+                             unsigned samples, float* d_audio, size_t audio_channel_stride,
+                             unsigned* out_floats, void* stream)
+{
+  return process_device_impl(b, d_iq, IQ_F32, iq_channel_stride, samples, d_audio, audio_channel_stride,
+                             out_floats, stream);
+}
+
+int fmd_batch_process_device_u8(fmd_batch* b, const uint8_t* d_iq_u8, size_t iq_channel_stride,
+                                unsigned samples, float* d_audio, size_t audio_channel_stride,
+                                unsigned* out_floats, void* stream)
+{
+  return process_device_impl(b, d_iq_u8, IQ_U8, iq_channel_stride, samples, d_audio,
+                             audio_channel_stride, out_floats, stream);
+}
+
 /* slots whose call is at least `lag` calls old (lag 0 = every call submitted so far) */
 static bool slot_eligible(const fmd_batch* b, int q, int lag)
 {
@@ -875,15 +936,19 @@ int fmd_batch_collect_rds(fmd_batch* b, fmd_rds_group* out, unsigned cap, int ru
   return fmd_batch_collect_rds_lagged(b, out, cap, run_group_decoder, 0, stream_);
 }
 
-int fmd_batch_process_host(fmd_batch* b, const float* iq, size_t iq_channel_stride, unsigned samples,
-                           float* audio, size_t audio_channel_stride, unsigned* out_floats)
+static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t iq_channel_stride,
+                             unsigned samples, float* audio, size_t audio_channel_stride,
+                             unsigned* out_floats)
 {
   if (!b || !iq || !audio)
     return fail(FMD_ERR_ARG, "fmd_batch_process_host: null argument");
   HIPCHK(hipSetDevice(b->device));
   const unsigned C = b->C;
-  const size_t dev_iq_stride = iq_channel_stride ? samples : 0;
-  const size_t iq_floats = size_t(2) * samples * (iq_channel_stride ? C : 1);
+  const size_t esz = fmt == IQ_U8 ? 2 : 8; // bytes per IQ sample
+  // device copy: one row per channel, rows padded to a whole pair of samples
+  const size_t dev_row = (size_t(samples) + 1) / 2 * 2 * esz;
+  const size_t dev_iq_stride = iq_channel_stride ? dev_row / esz : 0;
+  const size_t iq_floats = (dev_row * (iq_channel_stride ? C : 1) + 3) / 4;
   const size_t a_stride = (size_t(fmd_batch_max_audio_floats(b, samples)) + 3) & ~size_t(3);
   if (iq_floats > b->h_iq_cap)
   {
@@ -900,14 +965,13 @@ int fmd_batch_process_host(fmd_batch* b, const float* iq, size_t iq_channel_stri
     b->h_audio_cap = a_stride * C;
   }
   if (iq_channel_stride)
-    HIPCHK(hipMemcpy2D(b->h_iq.p, size_t(2) * samples * sizeof(float), iq,
-                       size_t(2) * iq_channel_stride * sizeof(float), size_t(2) * samples * sizeof(float),
-                       C, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy2D(b->h_iq.p, dev_row, iq, iq_channel_stride * esz, size_t(samples) * esz, C,
+                       hipMemcpyHostToDevice));
   else
-    HIPCHK(hipMemcpy(b->h_iq.p, iq, iq_floats * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->h_iq.p, iq, size_t(samples) * esz, hipMemcpyHostToDevice));
   unsigned nf = 0;
-  int rc = fmd_batch_process_device(b, b->h_iq.p, dev_iq_stride, samples, b->h_audio.p, a_stride, &nf,
-                                    nullptr);
+  int rc = process_device_impl(b, b->h_iq.p, fmt, dev_iq_stride, samples, b->h_audio.p, a_stride, &nf,
+                               nullptr);
   if (rc != FMD_OK)
     return rc;
   if (C > 1 && nf > audio_channel_stride)
@@ -920,6 +984,21 @@ int fmd_batch_process_host(fmd_batch* b, const float* iq, size_t iq_channel_stri
   if (out_floats)
     *out_floats = nf;
   return FMD_OK;
+}
+
+int fmd_batch_process_host(fmd_batch* b, const float* iq, size_t iq_channel_stride, unsigned samples,
+                           float* audio, size_t audio_channel_stride, unsigned* out_floats)
+{
+  return process_host_impl(b, iq, IQ_F32, iq_channel_stride, samples, audio, audio_channel_stride,
+                           out_floats);
+}
+
+int fmd_batch_process_host_u8(fmd_batch* b, const uint8_t* iq_u8, size_t iq_channel_stride,
+                              unsigned samples, float* audio, size_t audio_channel_stride,
+                              unsigned* out_floats)
+{
+  return process_host_impl(b, iq_u8, IQ_U8, iq_channel_stride, samples, audio, audio_channel_stride,
+                           out_floats);
 }
 
 int fmd_batch_get_status(fmd_batch* b, unsigned channel, fmd_status* stt)
@@ -1150,6 +1229,15 @@ int fmd_process_stream(fmd_decoder* d, const float* iq, unsigned samples, float*
     return fail(FMD_ERR_ARG, "null decoder");
   unsigned nf = 0;
   int rc = fmd_batch_process_host(d->b, iq, 0, samples, audio, 0, &nf);
+  return rc == FMD_OK ? int(nf) : rc;
+}
+
+int fmd_process_stream_u8(fmd_decoder* d, const uint8_t* buf, unsigned samples, float* audio)
+{
+  if (!d)
+    return fail(FMD_ERR_ARG, "null decoder");
+  unsigned nf = 0;
+  int rc = fmd_batch_process_host_u8(d->b, buf, 0, samples, audio, 0, &nf);
   return rc == FMD_OK ? int(nf) : rc;
 }
 

@@ -107,23 +107,59 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 
 /* ------------------------------------------------------------------------------------------ */
 /* K1: cFineTuner (FmDecode.cpp:66-82) fused into cDownsampleFilter::Process(complex)           */
-/*     (DownConvert.cpp:98-154).  One workgroup = one channel x TILE outputs.  The tuned IQ     */
-/*     window (overlap-save: (TILE-1)*D + order samples) is staged once in LDS; each thread     */
-/*     then accumulates its output over taps j = 1..order in the reference's order.  Taps are   */
-/*     wave-uniform (scalar loads).                                                             */
+/*     (DownConvert.cpp:98-154), optionally with the RTL-SDR byte -> float conversion           */
+/*     (RTL_SDR_Source.cpp:207-211) in front.  One workgroup = one channel x TILE outputs.      */
+/*     The tuned IQ window (overlap-save: (TILE-1)*D + order samples) is staged once in LDS;    */
+/*     each thread then accumulates its output over taps j = 1..order in the reference's order. */
+/*     Taps are wave-uniform (scalar loads).                                                    */
 /* ------------------------------------------------------------------------------------------ */
-/* Staging detail: 16 bytes (two IQ samples) per lane per load, UNROLL loads issued back to back
- * (unconditional, index clamped: a branch would make the compiler wait after every load) so a
- * workgroup has its whole window in flight in one round trip; the tuner table has T | 2*TILE
- * entries (power of two), so the two table entries a lane needs are the same for every load
- * it issues and live in registers.
+/* Input formats.  A lane always loads two IQ samples at a time: 16 bytes of complex<float> or 4
+ * bytes of RTL-SDR (I,Q) byte pairs, so consecutive lanes write consecutive 16-byte LDS slots. */
+struct InF32
+{
+  typedef float2 elem;
+  typedef uint4 pair;
+  static __device__ __forceinline__ float2 one(const elem* x, size_t k) { return x[k]; }
+  static __device__ __forceinline__ void unpack(const pair& v, float2& a, float2& b)
+  {
+    a = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+    b = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));
+  }
+};
+struct InU8
+{
+  typedef uchar2 elem;
+  typedef unsigned pair;
+  static __device__ __forceinline__ float2 one(const elem* x, size_t k)
+  {
+    const uchar2 b = x[k];
+    return make_float2(fmd_u8_to_f32(b.x), fmd_u8_to_f32(b.y));
+  }
+  static __device__ __forceinline__ void unpack(const pair& v, float2& a, float2& b)
+  {
+    a = make_float2(fmd_u8_to_f32(v & 0xffu), fmd_u8_to_f32((v >> 8) & 0xffu));
+    b = make_float2(fmd_u8_to_f32((v >> 16) & 0xffu), fmd_u8_to_f32(v >> 24));
+  }
+};
+
+/* Staging detail: UNROLL two-sample loads per lane issued back to back (unconditional, index
+ * clamped: a branch would make the compiler wait after every load) so a workgroup has its whole
+ * window in flight in one round trip.  The tuner table has T | 2*TILE entries (power of two,
+ * host-checked), so the two table entries a lane needs are the same for every load it issues and
+ * live in registers.
  * Block -> (channel, tile): block ids are dealt round-robin over the 8 XCDs, so with
  * xcd_map != 0 each XCD gets whole channels and walks their tiles in order: consecutive tiles
  * share their `order`-sample halo in that XCD's L2 and every channel is read as one
- * contiguous 512 KiB stream (measured 0.79 ms vs 0.97 ms channel-fastest, 8192 channels). */
-template <int TILE, int UNROLL, bool POW2>
-__global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, size_t chan_stride,
-                                                 unsigned N, const float2* __restrict__ hist_in,
+ * contiguous stream (measured 0.79 ms vs 0.97 ms channel-fastest, 8192 channels).
+ * Tried and dropped (round 1, 8192 channels, kernel alone): workgroups that walk several tiles
+ * with the next tile's loads prefetched into registers during the tap loop (0.86-0.97 ms vs 0.84
+ * on the same box); three outputs per thread sharing their window reads (2.4x less LDS traffic,
+ * but 2 waves per SIMD: 0.94-1.09 ms).  Loads + staging alone take 0.84 ms, the tap loop alone
+ * 0.66 ms: the float path sits at the HBM rate the chip sustains (6.3 TB/s copy, 79 % of spec). */
+template <class IN, int TILE, int UNROLL, bool POW2>
+__global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __restrict__ iq,
+                                                 size_t chan_stride, unsigned N,
+                                                 const float2* __restrict__ hist_in,
                                                  float2* __restrict__ hist_out,
                                                  const float2* __restrict__ lut, unsigned T,
                                                  unsigned lut_idx0, const float* __restrict__ coeff,
@@ -131,6 +167,7 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, 
                                                  float2* __restrict__ out, unsigned Mstride,
                                                  unsigned ntiles, unsigned xcd_map)
 {
+  typedef typename IN::pair pair_t;
   extern __shared__ __attribute__((aligned(16))) float2 win[];
   __builtin_amdgcn_s_setprio(1); // ahead of the post-chain kernels it may share a SIMD with
   unsigned c, tile;
@@ -151,8 +188,8 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, 
   const int p_first = (int)(pos + m0 * D);
   const int k_lo = p_first - (int)order;            // first sample the tile needs
   const int k_hi = p_first + (int)((nout - 1) * D); // one past the last sample it needs
-  const int k_al = k_lo - (k_lo & 1);               // even: even k <-> 16-byte aligned win slot
-  const float2* __restrict__ x = iq + (size_t)c * chan_stride;
+  const int k_al = k_lo & ~1; // floor to a pair boundary: LDS slot of sample k is k - k_al
+  const typename IN::elem* __restrict__ x = iq + (size_t)c * chan_stride;
   const float2* __restrict__ l = lut + (size_t)c * T;
 
   if (k_lo < 0)
@@ -162,43 +199,45 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, 
     for (int i = (int)tid; i < nh; i += TILE)
       win[i + (k_lo - k_al)] = h[(int)order + k_lo + i];
   }
+  if (POW2)
   {
-    const int ks = max(k_al, 0); // even
-    const int npairs = (k_hi - ks + 1) >> 1;
-    if (POW2)
+    // pair i holds samples k_al + 2i, k_al + 2i + 1; pairs [ifirst, npairs) come from this block,
+    // a ragged last sample of an odd-length block is done on its own
+    const unsigned mask = T - 1;
+    const int kfull = min(k_hi, (int)(N & ~1u));
+    const int ifirst = k_al < 0 ? (-k_al) >> 1 : 0;
+    const int npairs = (kfull - k_al + 1) >> 1;
+    const unsigned li = (lut_idx0 + (unsigned)k_al + 2u * tid) & mask;
+    const float2 l0 = l[li], l1 = l[(li + 1) & mask];
+    const pair_t* __restrict__ src = reinterpret_cast<const pair_t*>(x) + (k_al >> 1);
+    float4* dst = reinterpret_cast<float4*>(win);
+    for (int base = 0; base < npairs; base += UNROLL * TILE)
     {
-      const unsigned mask = T - 1;
-      const unsigned li = (lut_idx0 + (unsigned)ks + 2u * tid) & mask;
-      const float2 l0 = l[li], l1 = l[(li + 1) & mask];
-      const float4* __restrict__ src = reinterpret_cast<const float4*>(x + ks);
-      float4* dst = reinterpret_cast<float4*>(win + (ks - k_al));
-      for (int base = 0; base < npairs; base += UNROLL * TILE)
+      pair_t v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++)
+        v[u] = src[max(min(base + u * TILE + (int)tid, npairs - 1), ifirst)];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++)
       {
-        float4 v[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++)
-          v[u] = src[max(min(base + u * TILE + (int)tid, npairs - 1), 0)];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++)
+        const int i = base + u * TILE + (int)tid;
+        if (i >= ifirst && i < npairs)
         {
-          const int i = base + u * TILE + (int)tid;
-          if (i < npairs)
-          {
-            const float2 a = cmul(make_float2(v[u].x, v[u].y), l0);
-            const float2 b = cmul(make_float2(v[u].z, v[u].w), l1);
-            dst[i] = make_float4(a.x, a.y, b.x, b.y);
-          }
+          float2 a, b;
+          IN::unpack(v[u], a, b);
+          a = cmul(a, l0);
+          b = cmul(b, l1);
+          dst[i] = make_float4(a.x, a.y, b.x, b.y);
         }
       }
     }
-    else
-    {
-      for (int i = (int)tid; i < 2 * npairs; i += TILE)
-      {
-        const int k = ks + i;
-        win[k - k_al] = cmul(x[k], l[(lut_idx0 + (unsigned)k) % T]);
-      }
-    }
+    for (int k = max(kfull, 0) + (int)tid; k < k_hi; k += TILE)
+      win[k - k_al] = cmul(IN::one(x, k), l[(lut_idx0 + (unsigned)k) & mask]);
+  }
+  else
+  {
+    for (int k = max(k_al, 0) + (int)tid; k < k_hi; k += TILE)
+      win[k - k_al] = cmul(IN::one(x, k), l[(lut_idx0 + (unsigned)k) % T]);
   }
   __syncthreads();
 
@@ -224,7 +263,7 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, 
     for (unsigned i = tid; i < order; i += TILE)
     {
       const unsigned k = N - order + i;
-      ho[i] = cmul(x[k], l[(lut_idx0 + k) % T]);
+      ho[i] = cmul(IN::one(x, k), l[(lut_idx0 + k) % T]);
     }
   }
 }
@@ -233,18 +272,20 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const float2* __restrict__ iq, 
 /* K2a: RMSLevelApprox (FmDecode.cpp:505-519) + EMA (:427).  One wave per channel: the lanes    */
 /*      form the |tuned sample|^2 terms (coalesced), lane 0 adds them in index order.           */
 /* ------------------------------------------------------------------------------------------ */
-__global__ __launch_bounds__(64) void k_if_level(const float2* __restrict__ iq, size_t chan_stride,
-                                                 unsigned N, const float2* __restrict__ lut,
-                                                 unsigned T, unsigned lut_idx0, ChannelState st)
+template <class IN>
+__global__ __launch_bounds__(64) void k_if_level(const typename IN::elem* __restrict__ iq,
+                                                 size_t chan_stride, unsigned N,
+                                                 const float2* __restrict__ lut, unsigned T,
+                                                 unsigned lut_idx0, ChannelState st)
 {
   __shared__ float term[1024];
   const unsigned c = blockIdx.x;
   const unsigned n = (N + 63) / 64; // <= 1024 for N <= 65536
-  const float2* __restrict__ x = iq + (size_t)c * chan_stride;
+  const typename IN::elem* __restrict__ x = iq + (size_t)c * chan_stride;
   const float2* __restrict__ l = lut + (size_t)c * T;
   for (unsigned i = threadIdx.x; i < n; i += 64)
   {
-    const float2 s = cmul(x[i], l[(lut_idx0 + i) % T]);
+    const float2 s = cmul(IN::one(x, i), l[(lut_idx0 + i) % T]);
     term[i] = s.x * s.x + s.y * s.y;
   }
   __syncthreads();

@@ -18,6 +18,14 @@
  *  - fmd_rds_arctan2(): the reference's own polynomial arctan (RDSProcess.cpp:187-217),
  *    float with double intermediates.
  *
+ *  - fmd_u8_to_f32(): the RTL-SDR byte -> float conversion (RTL_SDR_Source.cpp:207-211),
+ *    float(b / (255.0 / 2.0) - 1.0) in double.  The real value is (2b-255)/255; a float
+ *    rounding boundary is a dyadic rational and (2b-255)/255 stays >= 2^-40 away from every
+ *    one of them, far more than the 2^-53 the two double roundings can move it, so the result
+ *    is the correctly rounded float of 2b/255 - 1.  Computed as b*c_hi - 1 (exact: c_hi has 9
+ *    significant bits) plus b*c_lo with one rounding, c_hi + c_lo = 2/255 to 2^-48; all 256
+ *    inputs are checked in the CPU tests.
+ *
  * Usable from host C (CPU sweep of the restatement) and from HIP device code.
  */
 #ifndef FMD_MATH_H
@@ -56,6 +64,15 @@ FMD_HD float fmd_u2f(uint32_t u)
 }
 
 /* fdlibm s_atanf.c */
+/* RTL_SDR_Source.cpp:207-211, see the header comment.  The fmaf calls are this function's own
+ * evaluation scheme, not contractions of reference arithmetic. */
+FMD_HD float fmd_u8_to_f32(unsigned b)
+{
+  const float f = (float)b;
+  const float s = __builtin_fmaf(f, 0x1.01p-7f, -1.0f); /* exact */
+  return __builtin_fmaf(f, 0x1.010102p-23f, s);
+}
+
 FMD_HD float fmd_atanf(float x)
 {
   const float atanhi0 = 4.6364760399e-01f, atanhi1 = 7.8539812565e-01f,

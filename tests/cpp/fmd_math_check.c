@@ -85,6 +85,14 @@ int main(int argc, char** argv)
     bad_t += (fmd_f2u(s1) != fmd_f2u(s3)) + (fmd_f2u(c1) != fmd_f2u(c3));
     (void)bad_r;
   }
-  printf("n=%ld atan2f=%ld atan2f_tab=%ld sincos_nco=%ld sincos_tab=%ld\n", n, bad_a, bad_f, bad_s, bad_t);
+  /* RTL-SDR byte -> float (RTL_SDR_Source.cpp:207-211): all 256 inputs */
+  long bad_u = 0;
+  for (unsigned b = 0; b < 256; b++)
+  {
+    const float ref = (float)(b / (255.0 / 2.0) - 1.0);
+    bad_u += fmd_f2u(ref) != fmd_f2u(fmd_u8_to_f32(b));
+  }
+  printf("n=%ld atan2f=%ld atan2f_tab=%ld sincos_nco=%ld sincos_tab=%ld u8_to_f32=%ld\n", n, bad_a, bad_f,
+         bad_s, bad_t, bad_u);
   return 0;
 }

@@ -114,6 +114,7 @@ def dlib():
         L = C.CDLL(path)
         L.fmsig_device_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint64,
                                             C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.fmsig_device_generate_u8.argtypes = L.fmsig_device_generate.argtypes
         L.fmsig_chan_size.restype = C.c_uint
         assert L.fmsig_chan_size() == CHAN_DTYPE.itemsize
         _DLIB = L
@@ -148,17 +149,21 @@ class DeviceGenerator:
         self.d_dbits = torch.from_numpy(dbits.reshape(-1).copy()).to(device)
 
     def generate(self, out, start, n):
-        """out: torch float32 cuda tensor viewable as [C, n, 2]; start: absolute sample index."""
+        """out: torch cuda tensor, float32 viewable as [C, n, 2] (converted like the reference) or
+        uint8 viewable as [C, n, 2] (raw RTL-SDR bytes); start: absolute sample index."""
         torch = self.torch
-        assert out.is_cuda and out.dtype == torch.float32 and out.numel() >= self.C * n * 2
+        assert out.is_cuda and out.dtype in (torch.float32, torch.uint8)
+        assert out.numel() >= self.C * n * 2
+        u8 = out.dtype == torch.uint8
+        fn = dlib().fmsig_device_generate_u8 if u8 else dlib().fmsig_device_generate
+        esz = 2 if u8 else 8
         stream = torch.cuda.current_stream().cuda_stream
         # grid.y is limited to 65535 channels per launch
         done = 0
         while done < self.C:
             cnt = min(32768, self.C - done)
-            rc = dlib().fmsig_device_generate(
-                self.d_chans.data_ptr() + done * CHAN_DTYPE.itemsize,
-                self.d_dbits.data_ptr() + done * 832, 832, cnt, start, n,
-                out.data_ptr() + done * n * 8, n, stream)
+            rc = fn(self.d_chans.data_ptr() + done * CHAN_DTYPE.itemsize,
+                    self.d_dbits.data_ptr() + done * 832, 832, cnt, start, n,
+                    out.data_ptr() + done * n * esz, n, stream)
             assert rc == 0
             done += cnt
