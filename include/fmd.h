@@ -177,6 +177,18 @@ int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream);
 
 int fmd_batch_get_status(fmd_batch* b, unsigned channel, fmd_status* st);
 
+/* cRadioReceiver's audio level meter over the audio a call produced (RadioReceiver.cpp:526-528,
+ * SamplesMeanRMS :584-598): float sums over the interleaved samples of the packet, then
+ * level = 0.95 * level + 0.05 * rms.  Computed on the device while the audio is written; `level`
+ * starts at 0 when the batch is created and, like m_AudioLevel, is not touched by Reset. */
+typedef struct fmd_audio_level
+{
+  float mean;  /* audio_mean of the last call */
+  float rms;   /* audio_rms of the last call  */
+  float level; /* m_AudioLevel                */
+} fmd_audio_level;
+int fmd_batch_get_audio_level(fmd_batch* b, unsigned channel, fmd_audio_level* out);
+
 /* Stage taps for parity tests: copies stage output of the last call for one channel to host.
  * Returns element count (complex counts as one) or negative error. */
 enum fmd_tap
@@ -221,6 +233,66 @@ const char* fmd_stage_name(unsigned idx);
 
 const char* fmd_last_error(void);
 const char* fmd_version(void);
+
+/* ---- the stream side of cRadioReceiver around the decoder --------------------------- */
+/* What turns blocks of IQ into Kodi demux packets and the signal-status maths on
+ * top of the decoder's getters (8(f)-4): cRadioReceiver::OpenLiveStream's stream state
+ * (RadioReceiver.cpp:296-349), WriteDataBuffer / EndDataBuffer / SourceGetSamples (:426-460),
+ * AddUECPDataFrame (:387-414), DemuxRead (:462-542) and both GetSignalStatus (:544-582).  The
+ * decoder inside is an fmd_decoder; the rest is host bookkeeping like the reference's.
+ * Not thread-safe by itself except write/end against demux_read (producer / consumer, like the
+ * reference's source thread and demux thread). */
+typedef struct fmd_receiver fmd_receiver;
+
+#define FMD_STREAM_AUDIO 1          /* PID 1, pcm_f32le 2 ch 48 kHz (RadioReceiver.cpp:308-316) */
+#define FMD_STREAM_RDS 2            /* PID 2, rds: byte-stuffed UECP frames (:326-334)          */
+#define FMD_STREAM_CHANGE (-11)     /* DEMUX_SPECIALID_STREAMCHANGE                             */
+#define FMD_STREAM_TIME_BASE 1000000 /* Kodi STREAM_TIME_BASE (microseconds)                    */
+
+/* the DEMUX_PACKET fields DemuxRead fills */
+typedef struct fmd_demux_packet
+{
+  int stream_id;       /* iStreamId                                                  */
+  int size;            /* iSize, bytes                                               */
+  double pts;          /* pts                                                        */
+  double duration;     /* duration (audio packets only, else 0)                      */
+  const uint8_t* data; /* pData: valid until the next call on this receiver          */
+} fmd_demux_packet;
+
+/* OpenLiveStream's decoder + stream state: decoder for (params), m_StreamChange = true,
+ * m_PTSNext = STREAM_TIME_BASE, Reset().  tuner_freq = m_activeTunerFreq (Hz), adapter_name =
+ * the RTL-SDR device name (both only appear in the status text). */
+int fmd_receiver_open(const fmd_params* params, double tuner_freq, const char* adapter_name,
+                      fmd_receiver** out);
+void fmd_receiver_close(fmd_receiver* r);
+/* WriteDataBuffer (:426-436): queues one block (copied).  _u8: cRtlSdrSource::ReadAsyncCB's input,
+ * converted inside the IF kernel when the block is decoded. */
+int fmd_receiver_write_iq(fmd_receiver* r, const float* iq, unsigned samples);
+int fmd_receiver_write_u8(fmd_receiver* r, const uint8_t* buf, unsigned samples);
+void fmd_receiver_end(fmd_receiver* r);                 /* EndDataBuffer (:438-443)        */
+size_t fmd_receiver_queued_samples(fmd_receiver* r);    /* SourceQueuedSamples (:420-424)  */
+void fmd_receiver_set_stream_change(fmd_receiver* r);   /* SetStreamChange (RadioReceiver.h:83) */
+/* DemuxRead (:462-542): 1 = packet filled, 0 = no packet (the reference returns nullptr: end
+ * marked and queue empty), negative = error.  Order per call like the reference: stream-change
+ * packet, else pending RDS bytes, else decode the next IQ block into an audio packet.  Blocks
+ * while the queue is empty and the end is not marked (polling every 20 ms like :448). */
+int fmd_receiver_demux_read(fmd_receiver* r, fmd_demux_packet* pkt);
+/* GetSignalStatus(float&, float&, bool&) (:544-556): 1 = values valid, 0 = no decoder / stream
+ * change pending (the reference returns false). */
+int fmd_receiver_signal_status(fmd_receiver* r, float* interface_level_db, float* audio_level_db,
+                               int* stereo);
+/* GetSignalStatus(int, PVRSignalStatus&) (:558-582) */
+typedef struct fmd_pvr_signal_status
+{
+  char adapter_name[128];
+  char adapter_status[256];
+  char provider_name[64]; /* m_channelName (trimmed PS name) */
+  int signal;             /* SetSignal(2.5 * (interfaceLevel + 40) * 656) */
+  int snr;                /* SetSNR((audioLevel + 100) * 656)             */
+} fmd_pvr_signal_status;
+int fmd_receiver_pvr_signal_status(fmd_receiver* r, fmd_pvr_signal_status* out);
+/* the decoder inside (status getters, not to be destroyed) */
+fmd_decoder* fmd_receiver_decoder(fmd_receiver* r);
 
 /* ---- host-only pieces (no GPU needed) ----------------------------------------------- */
 /* UECP group decoder = cRDSGroupDecoder (RDSGroupDecoder.cpp:166-1001). */

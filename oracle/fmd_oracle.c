@@ -2077,3 +2077,299 @@ unsigned fmo_get_constants(const fmo_decoder* d, double* o, unsigned cap)
     o[i] = v[i];
   return n;
 }
+
+
+/* ============================================================================================ */
+/* cRadioReceiver: the stream members around the decoder (RadioReceiver.cpp, see fmd_oracle.h)   */
+/* ============================================================================================ */
+#include <ctype.h>
+#include <stdio.h>
+
+#define STREAM_TIME_BASE 1000000 /* Kodi timing_constants.h (third-party header, not vendored) */
+#define OUTPUT_SAMPLERATE 48000  /* Definitions.h:15 */
+#define DEMUX_SPECIALID_STREAMCHANGE (-11)
+
+typedef struct rx_block
+{
+  float* iq;
+  unsigned samples;
+  struct rx_block* next;
+} rx_block;
+
+struct fmo_receiver
+{
+  fmo_decoder* dec;      /* m_FMDecoder */
+  double if_rate;        /* m_IfRate */
+  double tuner_freq;     /* m_activeTunerFreq */
+  char adapter_name[128];
+  char channel_name[16]; /* m_channelName */
+  int stream_change;     /* m_StreamChange */
+  float audio_level;     /* m_AudioLevel (RadioReceiver.h:105: float, 0.0f) */
+  float audio_mean, audio_rms;
+  double pts_next;       /* m_PTSNext */
+  uint64_t queued;       /* m_AudioSourceSize */
+  rx_block *head, *tail; /* m_AudioSourceBuffer */
+  int end_marked, buffer_warning;
+  uint8_t* uecp;         /* m_UECPOutputBuffer */
+  size_t uecp_len, uecp_cap;
+  unsigned frames_seen;  /* frames of the decoder log already stuffed */
+  char name_seen[16];
+  uint8_t* packet;
+  size_t packet_cap;
+};
+
+fmo_receiver* fmo_receiver_open(const fmo_params* p, double tuner_freq, const char* adapter_name)
+{
+  fmo_receiver* r = (fmo_receiver*)calloc(1, sizeof(*r));
+  r->dec = fmo_create(p); /* :296-300 */
+  if (!r->dec)
+  {
+    free(r);
+    return NULL;
+  }
+  r->if_rate = p->sample_rate_if;
+  r->tuner_freq = tuner_freq;
+  snprintf(r->adapter_name, sizeof(r->adapter_name), "%s", adapter_name ? adapter_name : "");
+  r->stream_change = 1;               /* :345 */
+  r->pts_next = STREAM_TIME_BASE;     /* :347 */
+  fmo_reset(r->dec);                  /* :349 */
+  return r;
+}
+
+void fmo_receiver_close(fmo_receiver* r)
+{
+  if (!r)
+    return;
+  while (r->head)
+  {
+    rx_block* b = r->head;
+    r->head = b->next;
+    free(b->iq);
+    free(b);
+  }
+  fmo_destroy(r->dec);
+  free(r->uecp);
+  free(r->packet);
+  free(r);
+}
+
+void fmo_receiver_write(fmo_receiver* r, const float* iq, unsigned samples) /* :426-436 */
+{
+  if (!samples)
+    return;
+  rx_block* b = (rx_block*)calloc(1, sizeof(*b));
+  b->iq = (float*)malloc((size_t)samples * 2 * sizeof(float));
+  memcpy(b->iq, iq, (size_t)samples * 2 * sizeof(float));
+  b->samples = samples;
+  r->queued += samples;
+  if (r->tail)
+    r->tail->next = b;
+  else
+    r->head = b;
+  r->tail = b;
+}
+
+void fmo_receiver_write_u8(fmo_receiver* r, const uint8_t* buf, unsigned samples)
+{ /* RTL_SDR_Source.cpp:196-213: convert, then WriteDataBuffer */
+  float* tmp = (float*)malloc((size_t)samples * 2 * sizeof(float));
+  fmo_convert_u8(buf, samples, tmp);
+  fmo_receiver_write(r, tmp, samples);
+  free(tmp);
+}
+
+void fmo_receiver_end(fmo_receiver* r) /* :438-443 */
+{
+  r->end_marked = 1;
+}
+
+uint64_t fmo_receiver_queued_samples(const fmo_receiver* r) /* :420-424 */
+{
+  return r->queued;
+}
+
+void fmo_receiver_set_stream_change(fmo_receiver* r) /* RadioReceiver.h:83 */
+{
+  r->stream_change = 1;
+}
+
+static void rx_push(fmo_receiver* r, uint8_t v)
+{
+  if (r->uecp_len == r->uecp_cap)
+  {
+    r->uecp_cap = r->uecp_cap ? 2 * r->uecp_cap : 1024;
+    r->uecp = (uint8_t*)realloc(r->uecp, r->uecp_cap);
+  }
+  r->uecp[r->uecp_len++] = v;
+}
+
+/* cRadioReceiver::AddUECPDataFrame, :387-414 */
+static int rx_add_uecp_frame(fmo_receiver* r, const uint8_t* frame, unsigned length)
+{
+  if (r->uecp_len > 16384)
+    return 0;
+  rx_push(r, 0xFE);
+  for (unsigned i = 0; i < length; i++)
+  {
+    uint8_t value = frame[i];
+    if (value < 0xFD)
+      rx_push(r, value);
+    else
+    {
+      rx_push(r, 0xFD);
+      rx_push(r, (uint8_t)((value & 3) - 1));
+    }
+  }
+  rx_push(r, 0xFF);
+  return 1;
+}
+
+/* cRadioReceiver::SamplesMeanRMS, :584-598 (float sums, float quotient, float sqrt) */
+static void rx_samples_mean_rms(const float* samples, double* mean, double* rms, unsigned n)
+{
+  float vsum = 0;
+  float vsumsq = 0;
+  for (unsigned i = 0; i < n; ++i)
+  {
+    float v = samples[i];
+    vsum += v;
+    vsumsq += v * v;
+  }
+  *mean = vsum / n;
+  *rms = sqrtf(vsumsq / n);
+}
+
+/* the upward calls of one ProcessStream, replayed in order: frames go through AddUECPDataFrame,
+ * a new PS name through SetChannelName (:600-612: m_channelName = Trim(name)) */
+static void rx_collect_callbacks(fmo_receiver* r)
+{
+  unsigned n = fmo_uecp_frame_count(r->dec);
+  for (; r->frames_seen < n; r->frames_seen++)
+  {
+    uint8_t f[300];
+    unsigned len = fmo_uecp_frame_get(r->dec, r->frames_seen, f, sizeof(f));
+    rx_add_uecp_frame(r, f, len);
+  }
+  const char* name = fmo_channel_name(r->dec);
+  if (name[0] && strcmp(name, r->name_seen) != 0)
+  {
+    snprintf(r->name_seen, sizeof(r->name_seen), "%s", name);
+    const char* a = name;
+    while (*a && isspace((unsigned char)*a))
+      a++;
+    size_t e = strlen(a);
+    while (e && isspace((unsigned char)a[e - 1]))
+      e--;
+    memcpy(r->channel_name, a, e);
+    r->channel_name[e] = 0;
+  }
+}
+
+int fmo_receiver_demux_read(fmo_receiver* r, fmo_packet* pkt) /* :462-542 */
+{
+  memset(pkt, 0, sizeof(*pkt));
+  if (r->stream_change)
+  { /* :471-477 */
+    pkt->stream_id = DEMUX_SPECIALID_STREAMCHANGE;
+    r->stream_change = 0;
+    return 1;
+  }
+  if (r->uecp_len)
+  { /* :482-503 */
+    if (r->packet_cap < r->uecp_len)
+    {
+      r->packet_cap = r->uecp_len;
+      r->packet = (uint8_t*)realloc(r->packet, r->packet_cap);
+    }
+    memcpy(r->packet, r->uecp, r->uecp_len);
+    pkt->data = r->packet;
+    pkt->stream_id = 2;
+    pkt->size = (int)r->uecp_len;
+    pkt->pts = r->pts_next;
+    r->uecp_len = 0;
+    return 1;
+  }
+  if (!r->buffer_warning && (double)r->queued > 10 * r->if_rate) /* :510-514 */
+    r->buffer_warning = 1;
+  if (!r->head)
+    return r->end_marked ? 0 : -1; /* :447-459 */
+  rx_block* b = r->head;
+  r->head = b->next;
+  if (!r->head)
+    r->tail = NULL;
+  r->queued -= b->samples;
+  size_t need = (size_t)b->samples * sizeof(float) * 2; /* :519-520 */
+  if (r->packet_cap < need)
+  {
+    r->packet_cap = need;
+    r->packet = (uint8_t*)realloc(r->packet, r->packet_cap);
+  }
+  unsigned iSize = fmo_process_stream(r->dec, b->iq, b->samples, (float*)r->packet); /* :524-525 */
+  free(b->iq);
+  free(b);
+  rx_collect_callbacks(r);
+
+  double audio_mean, audio_rms;
+  rx_samples_mean_rms((const float*)r->packet, &audio_mean, &audio_rms, iSize); /* :527 */
+  r->audio_mean = (float)audio_mean;
+  r->audio_rms = (float)audio_rms;
+  r->audio_level = (float)(0.95 * r->audio_level + 0.05 * audio_rms); /* :528 */
+
+  double duration = (double)(iSize)*STREAM_TIME_BASE / 2 / OUTPUT_SAMPLERATE; /* :531 */
+  pkt->data = r->packet;
+  pkt->stream_id = 1;
+  pkt->size = (int)(iSize * sizeof(float));
+  pkt->duration = duration;
+  pkt->pts = r->pts_next;
+  r->pts_next = r->pts_next + duration; /* :538 */
+  return 1;
+}
+
+/* GetSignalStatus(float&, float&, bool&), :544-556.  log10 of a float argument resolves to the
+ * float overload under libstdc++; 20 * float is float, + 3.01 is double. */
+int fmo_receiver_signal_status(fmo_receiver* r, float* interface_db, float* audio_db, int* stereo)
+{
+  if (!r->dec || r->stream_change)
+    return 0;
+  fmo_status st;
+  fmo_get_status(r->dec, &st);
+  *interface_db = 20 * log10f(st.if_level);
+  *audio_db = (float)(20 * log10f(r->audio_level) + 3.01);
+  *stereo = st.stereo;
+  return 1;
+}
+
+/* GetSignalStatus(int, PVRSignalStatus&), :558-582.  The format string consumes five of its six
+ * arguments (IF= prints the tuned frequency, BB= the interface level, Audio= the baseband level);
+ * restated as written. */
+int fmo_receiver_pvr_signal_status(fmo_receiver* r, char* adapter_name, unsigned name_cap,
+                                   char* adapter_status, unsigned status_cap, char* provider_name,
+                                   unsigned provider_cap, int* signal, int* snr)
+{
+  if (!r->dec || r->stream_change)
+    return 0;
+  fmo_status st;
+  fmo_get_status(r->dec, &st);
+  float interfaceLevel = 20 * log10f(st.if_level);
+  float audioLevel = (float)(20 * log10f(r->audio_level) + 3.01);
+  snprintf(adapter_status, status_cap, "Freq.=%8.4fMHz - %s - IF=%+5.1fdB  BB=%+5.1fdB  Audio=%+5.1fdB",
+           r->tuner_freq / 1000000, st.stereo ? "Stereo" : "Mono",
+           (r->tuner_freq + st.tuning_offset) * 1.0e-6, interfaceLevel,
+           20 * log10f(st.baseband_level) + 3.01);
+  snprintf(adapter_name, name_cap, "%s", r->adapter_name);
+  snprintf(provider_name, provider_cap, "%s", r->channel_name);
+  *signal = (int)(2.5 * (interfaceLevel + 40) * 656);
+  *snr = (int)((audioLevel + 100) * 656);
+  return 1;
+}
+
+void fmo_receiver_audio_level(const fmo_receiver* r, float* mean, float* rms, float* level)
+{
+  *mean = r->audio_mean;
+  *rms = r->audio_rms;
+  *level = r->audio_level;
+}
+
+fmo_decoder* fmo_receiver_decoder(fmo_receiver* r)
+{
+  return r->dec;
+}

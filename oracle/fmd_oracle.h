@@ -97,6 +97,39 @@ void fmo_debug_push_group(fmo_decoder* d, const uint16_t blocks[4]);
 /* Last PS name passed to SetChannelName, "" if none. */
 const char* fmo_channel_name(const fmo_decoder* d);
 
+/* ---- the stream side of cRadioReceiver around the decoder ----------
+ * Restates OpenLiveStream's stream state (RadioReceiver.cpp:296-349), AddUECPDataFrame
+ * (:387-414), WriteDataBuffer / EndDataBuffer / SourceGetSamples (:420-460), DemuxRead (:462-542),
+ * both GetSignalStatus (:544-582), SamplesMeanRMS (:584-598) and SetChannelName (:600-612, no
+ * settings dialog).  Single-threaded: the producer/consumer waits of the reference are reduced
+ * to "queue empty and end marked -> no packet".  PARITY UNPINNED: SURVEY 8(c) records no reference
+ * output for these members. */
+typedef struct fmo_receiver fmo_receiver;
+typedef struct fmo_packet
+{
+  int stream_id;       /* 1 audio, 2 rds, -11 DEMUX_SPECIALID_STREAMCHANGE */
+  int size;            /* bytes */
+  double pts;
+  double duration;
+  const uint8_t* data; /* valid until the next call on this receiver */
+} fmo_packet;
+fmo_receiver* fmo_receiver_open(const fmo_params* p, double tuner_freq, const char* adapter_name);
+void fmo_receiver_close(fmo_receiver* r);
+void fmo_receiver_write(fmo_receiver* r, const float* iq, unsigned samples); /* WriteDataBuffer */
+void fmo_receiver_write_u8(fmo_receiver* r, const uint8_t* buf, unsigned samples); /* ReadAsyncCB */
+void fmo_receiver_end(fmo_receiver* r);
+uint64_t fmo_receiver_queued_samples(const fmo_receiver* r);
+void fmo_receiver_set_stream_change(fmo_receiver* r);
+/* 1 = packet, 0 = nullptr in the reference; -1 = queue empty but end not marked (the reference
+ * would block here) */
+int fmo_receiver_demux_read(fmo_receiver* r, fmo_packet* pkt);
+int fmo_receiver_signal_status(fmo_receiver* r, float* interface_db, float* audio_db, int* stereo);
+int fmo_receiver_pvr_signal_status(fmo_receiver* r, char* adapter_name, unsigned name_cap,
+                                   char* adapter_status, unsigned status_cap, char* provider_name,
+                                   unsigned provider_cap, int* signal, int* snr);
+void fmo_receiver_audio_level(const fmo_receiver* r, float* mean, float* rms, float* level);
+fmo_decoder* fmo_receiver_decoder(fmo_receiver* r);
+
 /* Design-level accessors (taps and constants), for G1-style comparisons. */
 unsigned fmo_design_lanczos(unsigned filter_order_arg, double cutoff, float* out, unsigned cap);
 unsigned fmo_design_lp_kaiser(float scale, float astop, float fpass, float fstop, float fs,

@@ -56,6 +56,11 @@ class FmoStatus(C.Structure):
     ]
 
 
+class FmoPacket(C.Structure):
+    _fields_ = [("stream_id", C.c_int), ("size", C.c_int), ("pts", C.c_double),
+                ("duration", C.c_double), ("data", C.POINTER(C.c_uint8))]
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
@@ -103,6 +108,22 @@ def lib():
         L.fmo_rds_arctan2.restype = C.c_float
         L.fmo_rds_arctan2.argtypes = [C.c_float, C.c_float]
         L.fmo_convert_u8.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
+        L.fmo_receiver_open.restype = C.c_void_p
+        L.fmo_receiver_open.argtypes = [C.POINTER(FmoParams), C.c_double, C.c_char_p]
+        L.fmo_receiver_close.argtypes = [C.c_void_p]
+        L.fmo_receiver_write.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        L.fmo_receiver_write_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        L.fmo_receiver_end.argtypes = [C.c_void_p]
+        L.fmo_receiver_queued_samples.restype = C.c_uint64
+        L.fmo_receiver_queued_samples.argtypes = [C.c_void_p]
+        L.fmo_receiver_set_stream_change.argtypes = [C.c_void_p]
+        L.fmo_receiver_demux_read.argtypes = [C.c_void_p, C.POINTER(FmoPacket)]
+        L.fmo_receiver_signal_status.argtypes = [C.c_void_p, C.POINTER(C.c_float),
+                                                 C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.fmo_receiver_pvr_signal_status.argtypes = [C.c_void_p, C.c_char_p, C.c_uint, C.c_char_p,
+                                                     C.c_uint, C.c_char_p, C.c_uint,
+                                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.fmo_receiver_audio_level.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 3
         L.fmo_sincos_x87.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _LIB = L
     return _LIB
@@ -237,6 +258,76 @@ class OracleDecoder:
     def constants(self):
         v = self._vec("fmo_get_constants", 64, np.float64)
         return dict(zip(CONST_NAMES, v))
+
+
+class OracleReceiver:
+    """The stream members of cRadioReceiver around the oracle decoder (DemuxRead & co)."""
+
+    def __init__(self, sample_rate_if, tuning_offset, downsample, tuner_freq=100.0e6,
+                 adapter_name="Generic RTL2832U"):
+        p = FmoParams(sample_rate_if, tuning_offset, 48000.0, 15000.0, downsample, 0, 0, 0, 0, 0)
+        self._h = lib().fmo_receiver_open(C.byref(p), tuner_freq, adapter_name.encode())
+        if not self._h:
+            raise RuntimeError("fmo_receiver_open failed")
+
+    def close(self):
+        if self._h:
+            lib().fmo_receiver_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def write_iq(self, iq):
+        iq = np.ascontiguousarray(iq)
+        if iq.dtype == np.complex64:
+            iq = iq.view(np.float32)
+        lib().fmo_receiver_write(self._h, iq.ctypes.data, iq.size // 2)
+
+    def write_u8(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        lib().fmo_receiver_write_u8(self._h, buf.ctypes.data, buf.size // 2)
+
+    def end(self):
+        lib().fmo_receiver_end(self._h)
+
+    def queued_samples(self):
+        return int(lib().fmo_receiver_queued_samples(self._h))
+
+    def set_stream_change(self):
+        lib().fmo_receiver_set_stream_change(self._h)
+
+    def demux_read(self):
+        """(stream_id, pts, duration, payload bytes) or None; raises if the reference would block."""
+        pkt = FmoPacket()
+        rc = lib().fmo_receiver_demux_read(self._h, C.byref(pkt))
+        if rc < 0:
+            raise RuntimeError("queue empty and end not marked: the reference blocks here")
+        if rc == 0:
+            return None
+        data = bytes(C.string_at(pkt.data, pkt.size)) if pkt.size else b""
+        return (pkt.stream_id, pkt.pts, pkt.duration, data)
+
+    def signal_status(self):
+        a, b, s = C.c_float(), C.c_float(), C.c_int()
+        if not lib().fmo_receiver_signal_status(self._h, C.byref(a), C.byref(b), C.byref(s)):
+            return None
+        return (a.value, b.value, bool(s.value))
+
+    def pvr_signal_status(self):
+        name, status, prov = (C.create_string_buffer(128), C.create_string_buffer(256),
+                              C.create_string_buffer(64))
+        sig, snr = C.c_int(), C.c_int()
+        if not lib().fmo_receiver_pvr_signal_status(self._h, name, 128, status, 256, prov, 64,
+                                                    C.byref(sig), C.byref(snr)):
+            return None
+        return {"adapter_name": name.value.decode(), "adapter_status": status.value.decode(),
+                "provider_name": prov.value.decode("latin-1"), "signal": sig.value, "snr": snr.value}
+
+    def audio_level(self):
+        m, r, lv = C.c_float(), C.c_float(), C.c_float()
+        lib().fmo_receiver_audio_level(self._h, C.byref(m), C.byref(r), C.byref(lv))
+        return (m.value, r.value, lv.value)
 
 
 def design_lanczos(order, cutoff):

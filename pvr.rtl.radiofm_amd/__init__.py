@@ -76,7 +76,27 @@ class FmdRdsGroup(C.Structure):
 RDS_GROUP_DTYPE = np.dtype([("channel", "<u4"), ("call_index", "<u4"), ("blocks", "<u2", (4,))])
 assert RDS_GROUP_DTYPE.itemsize == C.sizeof(FmdRdsGroup)
 
+class FmdAudioLevel(C.Structure):
+    _fields_ = [("mean", C.c_float), ("rms", C.c_float), ("level", C.c_float)]
+
+
+class FmdDemuxPacket(C.Structure):
+    _fields_ = [("stream_id", C.c_int), ("size", C.c_int), ("pts", C.c_double),
+                ("duration", C.c_double), ("data", C.POINTER(C.c_uint8))]
+
+
+class FmdPvrSignalStatus(C.Structure):
+    _fields_ = [("adapter_name", C.c_char * 128), ("adapter_status", C.c_char * 256),
+                ("provider_name", C.c_char * 64), ("signal", C.c_int), ("snr", C.c_int)]
+
+
+STREAM_AUDIO, STREAM_RDS, STREAM_CHANGE, STREAM_TIME_BASE = 1, 2, -11, 1000000
+
 EXPORTS = [
+    "fmd_batch_get_audio_level", "fmd_receiver_open", "fmd_receiver_close", "fmd_receiver_write_iq",
+    "fmd_receiver_write_u8", "fmd_receiver_end", "fmd_receiver_queued_samples",
+    "fmd_receiver_set_stream_change", "fmd_receiver_demux_read", "fmd_receiver_signal_status",
+    "fmd_receiver_pvr_signal_status", "fmd_receiver_decoder",
     "fmd_create", "fmd_destroy", "fmd_reset", "fmd_process_stream", "fmd_process_stream_u8",
     "fmd_get_status", "fmd_batch_process_device_u8", "fmd_batch_process_host_u8",
     "fmd_batch_create", "fmd_batch_destroy", "fmd_batch_reset", "fmd_batch_channels",
@@ -136,6 +156,21 @@ def lib():
         L.fmd_batch_wait_lagged.argtypes = [vp, i, vp]
         L.fmd_batch_get_status.argtypes = [vp, u, C.POINTER(FmdStatus)]
         L.fmd_batch_get_tap.argtypes = [vp, i, u, vp, u]
+        L.fmd_batch_get_audio_level.argtypes = [vp, u, C.POINTER(FmdAudioLevel)]
+        L.fmd_receiver_open.argtypes = [C.POINTER(FmdParams), C.c_double, C.c_char_p, C.POINTER(vp)]
+        L.fmd_receiver_close.argtypes = [vp]
+        L.fmd_receiver_write_iq.argtypes = [vp, vp, u]
+        L.fmd_receiver_write_u8.argtypes = [vp, vp, u]
+        L.fmd_receiver_end.argtypes = [vp]
+        L.fmd_receiver_queued_samples.restype = C.c_size_t
+        L.fmd_receiver_queued_samples.argtypes = [vp]
+        L.fmd_receiver_set_stream_change.argtypes = [vp]
+        L.fmd_receiver_demux_read.argtypes = [vp, C.POINTER(FmdDemuxPacket)]
+        L.fmd_receiver_signal_status.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                                 C.POINTER(i)]
+        L.fmd_receiver_pvr_signal_status.argtypes = [vp, C.POINTER(FmdPvrSignalStatus)]
+        L.fmd_receiver_decoder.restype = vp
+        L.fmd_receiver_decoder.argtypes = [vp]
         L.fmd_batch_get_design.argtypes = [vp, i, vp, u]
         L.fmd_batch_set_profiling.argtypes = [vp, i]
         L.fmd_batch_set_debug_taps.argtypes = [vp, i]
@@ -289,6 +324,12 @@ class Batch:
         _check(lib().fmd_batch_get_status(self._h, channel, C.byref(st)))
         return st
 
+    def audio_level(self, channel=0):
+        """(audio_mean, audio_rms, m_AudioLevel) of cRadioReceiver::DemuxRead for one channel."""
+        a = FmdAudioLevel()
+        _check(lib().fmd_batch_get_audio_level(self._h, channel, C.byref(a)))
+        return (a.mean, a.rms, a.level)
+
     def tap(self, name, channel=0):
         cap = 2 * 65536
         buf = np.zeros(cap, dtype=np.float32)
@@ -419,3 +460,65 @@ def stuff_uecp_frame(frame):
     src = (C.c_uint8 * len(frame))(*frame)
     n = lib().fmd_uecp_stuff_frame(src, len(frame), out, len(out))
     return bytes(out[:n])
+
+
+class Receiver:
+    """The stream members of cRadioReceiver around the GPU decoder: WriteDataBuffer,
+    EndDataBuffer, DemuxRead, GetSignalStatus (RadioReceiver.cpp:296-349, 387-582)."""
+
+    def __init__(self, sample_rate_if, tuning_offset, downsample, tuner_freq=100.0e6,
+                 adapter_name="Generic RTL2832U"):
+        p = make_params(sample_rate_if, tuning_offset, 48000.0, 15000.0, downsample)
+        h = C.c_void_p()
+        _check(lib().fmd_receiver_open(C.byref(p), tuner_freq, adapter_name.encode(), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().fmd_receiver_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def write_iq(self, iq):
+        iq = np.ascontiguousarray(iq)
+        if iq.dtype != np.complex64:
+            iq = iq.astype(np.float32).view(np.complex64)
+        _check(lib().fmd_receiver_write_iq(self._h, iq.ctypes.data, iq.size))
+
+    def write_u8(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        _check(lib().fmd_receiver_write_u8(self._h, buf.ctypes.data, buf.size // 2))
+
+    def end(self):
+        lib().fmd_receiver_end(self._h)
+
+    def queued_samples(self):
+        return int(lib().fmd_receiver_queued_samples(self._h))
+
+    def set_stream_change(self):
+        lib().fmd_receiver_set_stream_change(self._h)
+
+    def demux_read(self):
+        """(stream_id, pts, duration, payload bytes) or None (the reference's nullptr)."""
+        pkt = FmdDemuxPacket()
+        rc = _check(lib().fmd_receiver_demux_read(self._h, C.byref(pkt)))
+        if rc == 0:
+            return None
+        data = bytes(C.string_at(pkt.data, pkt.size)) if pkt.size else b""
+        return (pkt.stream_id, pkt.pts, pkt.duration, data)
+
+    def signal_status(self):
+        a, b, s = C.c_float(), C.c_float(), C.c_int()
+        rc = _check(lib().fmd_receiver_signal_status(self._h, C.byref(a), C.byref(b), C.byref(s)))
+        return (a.value, b.value, bool(s.value)) if rc else None
+
+    def pvr_signal_status(self):
+        st = FmdPvrSignalStatus()
+        rc = _check(lib().fmd_receiver_pvr_signal_status(self._h, C.byref(st)))
+        if not rc:
+            return None
+        return {"adapter_name": st.adapter_name.decode(), "adapter_status": st.adapter_status.decode(),
+                "provider_name": st.provider_name.decode("latin-1"), "signal": st.signal,
+                "snr": st.snr}

@@ -18,6 +18,7 @@
 #include "fmd_design.hpp"
 #include "fmd_groups.hpp"
 #include "fmd_kernels.hip.h"
+#include "fmd_receiver.hpp"
 
 namespace
 {
@@ -1026,6 +1027,18 @@ int fmd_batch_get_status(fmd_batch* b, unsigned channel, fmd_status* stt)
   return FMD_OK;
 }
 
+int fmd_batch_get_audio_level(fmd_batch* b, unsigned channel, fmd_audio_level* out)
+{
+  if (!b || !out || channel >= b->C)
+    return fail(FMD_ERR_ARG, "fmd_batch_get_audio_level: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(&out->mean, b->st.F(fmd::F_AUDIO_MEAN) + channel, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&out->rms, b->st.F(fmd::F_AUDIO_RMS) + channel, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&out->level, b->st.F(fmd::F_AUDIO_LEVEL) + channel, 4, hipMemcpyDeviceToHost));
+  return FMD_OK;
+}
+
 int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsigned cap_floats)
 {
   if (!b || !out || channel >= b->C)
@@ -1244,6 +1257,113 @@ int fmd_process_stream_u8(fmd_decoder* d, const uint8_t* buf, unsigned samples, 
 int fmd_get_status(fmd_decoder* d, fmd_status* st)
 {
   return d ? fmd_batch_get_status(d->b, 0, st) : fail(FMD_ERR_ARG, "null decoder");
+}
+
+/* ---- cRadioReceiver's stream side (csrc/fmd_receiver.hpp) ------------------------------------ */
+} // extern "C"
+
+fmd_batch* fmd::Receiver::fmd_decoder_batch(fmd_decoder* d)
+{
+  return d ? d->b : nullptr;
+}
+
+struct fmd_receiver
+{
+  fmd::Receiver r;
+  fmd_receiver(const fmd_params& p, double tuner_freq, const char* name) : r(p, tuner_freq, name) {}
+};
+
+extern "C" {
+
+int fmd_receiver_open(const fmd_params* params, double tuner_freq, const char* adapter_name,
+                      fmd_receiver** out)
+{
+  if (!params || !out)
+    return fail(FMD_ERR_ARG, "fmd_receiver_open: null argument");
+  *out = nullptr;
+  std::unique_ptr<fmd_receiver> r(new fmd_receiver(*params, tuner_freq, adapter_name));
+  const int rc = r->r.Open(*params);
+  if (rc != FMD_OK)
+    return rc;
+  *out = r.release();
+  return FMD_OK;
+}
+
+void fmd_receiver_close(fmd_receiver* r)
+{
+  delete r;
+}
+
+int fmd_receiver_write_iq(fmd_receiver* r, const float* iq, unsigned samples)
+{
+  if (!r || (!iq && samples))
+    return fail(FMD_ERR_ARG, "fmd_receiver_write_iq: null argument");
+  fmd::Receiver::Block blk;
+  blk.samples = samples;
+  blk.bytes.assign(reinterpret_cast<const uint8_t*>(iq),
+                   reinterpret_cast<const uint8_t*>(iq) + size_t(samples) * 8);
+  r->r.WriteDataBuffer(std::move(blk));
+  return FMD_OK;
+}
+
+int fmd_receiver_write_u8(fmd_receiver* r, const uint8_t* buf, unsigned samples)
+{
+  if (!r || (!buf && samples))
+    return fail(FMD_ERR_ARG, "fmd_receiver_write_u8: null argument");
+  fmd::Receiver::Block blk;
+  blk.samples = samples;
+  blk.u8 = true;
+  blk.bytes.assign(buf, buf + size_t(samples) * 2);
+  r->r.WriteDataBuffer(std::move(blk));
+  return FMD_OK;
+}
+
+void fmd_receiver_end(fmd_receiver* r)
+{
+  if (r)
+    r->r.EndDataBuffer();
+}
+
+size_t fmd_receiver_queued_samples(fmd_receiver* r)
+{
+  return r ? r->r.SourceQueuedSamples() : 0;
+}
+
+void fmd_receiver_set_stream_change(fmd_receiver* r)
+{
+  if (r)
+    r->r.SetStreamChange();
+}
+
+int fmd_receiver_demux_read(fmd_receiver* r, fmd_demux_packet* pkt)
+{
+  if (!r || !pkt)
+    return fail(FMD_ERR_ARG, "fmd_receiver_demux_read: null argument");
+  return r->r.DemuxRead(pkt);
+}
+
+int fmd_receiver_signal_status(fmd_receiver* r, float* interface_level_db, float* audio_level_db,
+                               int* stereo)
+{
+  if (!r || !interface_level_db || !audio_level_db || !stereo)
+    return fail(FMD_ERR_ARG, "fmd_receiver_signal_status: null argument");
+  bool st = false;
+  if (!r->r.GetSignalStatus(*interface_level_db, *audio_level_db, st))
+    return 0;
+  *stereo = st ? 1 : 0;
+  return 1;
+}
+
+int fmd_receiver_pvr_signal_status(fmd_receiver* r, fmd_pvr_signal_status* out)
+{
+  if (!r || !out)
+    return fail(FMD_ERR_ARG, "fmd_receiver_pvr_signal_status: null argument");
+  return r->r.GetSignalStatus(*out) ? 1 : 0;
+}
+
+fmd_decoder* fmd_receiver_decoder(fmd_receiver* r)
+{
+  return r ? r->r.Decoder() : nullptr;
 }
 
 /* ---- host-only pieces ----------------------------------------------------------------------- */

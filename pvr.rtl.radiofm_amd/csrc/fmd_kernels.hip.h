@@ -60,6 +60,7 @@ enum FSlot
   F_OSC_RE, F_OSC_IM,                                // RDS oscillator
   F_R_PHASE, F_R_FREQ, F_R_W1, F_R_W2, F_R_LAST_SYNC, F_R_LAST_SLOPE, F_R_LAST_DATA,
   F_DE_RE, F_DE_IM, F_N_W1A, F_N_W2A, F_N_W1B, F_N_W2B, // de-emphasis, notch
+  F_AUDIO_MEAN, F_AUDIO_RMS, F_AUDIO_LEVEL,          // cRadioReceiver's audio level meter
   F_SLOTS
 };
 enum ISlot
@@ -1091,6 +1092,9 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
   float w1a = st.F(F_N_W1A)[c], w2a = st.F(F_N_W2A)[c], w1b = st.F(F_N_W1B)[c], w2b = st.F(F_N_W2B)[c];
   const int stereo = st.I(I_STEREO)[c];
   const float one_minus_alpha = 1.0f - k.de_alpha;
+  // cRadioReceiver::SamplesMeanRMS over the packet (RadioReceiver.cpp:584-598): float sums over
+  // the interleaved samples L0, R0, L1, R1, ... in that order
+  float vsum = 0.0f, vsumsq = 0.0f;
 
   auto frame = [&](float2 v) -> float2 { // v.x = stereo, v.y = mono (ProcessTwo's A, B)
     de_re = one_minus_alpha * de_re + k.de_alpha * v.x;
@@ -1106,7 +1110,12 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
     w2b = w1b;
     w1b = w0b;
     const float mm = m * 0.5f;
-    return stereo ? make_float2((m + s) * 0.5f, (m - s) * 0.5f) : make_float2(mm, mm);
+    const float2 o = stereo ? make_float2((m + s) * 0.5f, (m - s) * 0.5f) : make_float2(mm, mm);
+    vsum += o.x;
+    vsumsq += o.x * o.x;
+    vsum += o.y;
+    vsumsq += o.y * o.y;
+    return o;
   };
   // 8 lanes write one channel's frames (8 B each) as consecutive pieces: 64-B segments
   auto flush = [&](unsigned i0, unsigned cnt) {
@@ -1155,6 +1164,13 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
     st.F(F_N_W2A)[c] = w2a;
     st.F(F_N_W1B)[c] = w1b;
     st.F(F_N_W2B)[c] = w2b;
+    // mean = vsum / n, rms = sqrt(vsumsq / n) in float (n = floats in the packet), then
+    // m_AudioLevel = 0.95 * m_AudioLevel + 0.05 * audio_rms in double (RadioReceiver.cpp:526-528)
+    const float n = (float)(2u * A);
+    const float rms = sqrtf(vsumsq / n);
+    st.F(F_AUDIO_MEAN)[c] = vsum / n;
+    st.F(F_AUDIO_RMS)[c] = rms;
+    st.F(F_AUDIO_LEVEL)[c] = (float)(0.95 * (double)st.F(F_AUDIO_LEVEL)[c] + 0.05 * (double)rms);
   }
 }
 

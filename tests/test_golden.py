@@ -12,7 +12,7 @@ import pytest
 from __graft_entry__ import ROOT, load_package
 
 N = 65536
-FILES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+FILES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "stereo_rds_*.npz")))
 
 
 def sha(a):

@@ -65,6 +65,60 @@ def make(name, fs, D, nblk, noise, keep):
     print(name, os.path.getsize(path), "bytes,", len(g), "groups,", len(frames), "frames")
 
 
+def receiver_session(rx, fmsig, p, nblk, u8=False, ahead=2):
+    """One demux session written like the reference's two threads run: the source keeps `ahead`
+    blocks queued, the demuxer pulls packets until the source ends.  Returns the packet list and
+    the signal status sampled after every audio packet.  Shared by the generator and the tests."""
+    packets, status = [], []
+    written = 0
+
+    def feed():
+        nonlocal written
+        while written < nblk and rx.queued_samples() < ahead * N:
+            buf = fmsig.generate_u8(p, written * N, N)
+            if u8:
+                rx.write_u8(buf)
+            else:
+                rx.write_iq(fmsig.u8_to_f32(buf))
+            written += 1
+        if written == nblk:
+            rx.end()
+
+    while True:
+        feed()
+        pkt = rx.demux_read()
+        if pkt is None:
+            break
+        packets.append(pkt)
+        if pkt[0] == 1:
+            status.append((rx.signal_status(), rx.pvr_signal_status()))
+    return packets, status
+
+
+def make_receiver(name="receiver_2p4M", fs=2.4e6, D=11, nblk=40):
+    p = fmsig_py.default_params(fs, noise_sigma=0.01, seed=11, ps=" GOLD FM")
+    rx = oracle_py.OracleReceiver(fs, -0.15 * fs, D, tuner_freq=99.9e6 + 0.15 * fs)
+    assert rx.signal_status() is None  # stream change pending (RadioReceiver.cpp:548)
+    packets, status = receiver_session(rx, fmsig_py, p, nblk)
+    out = {"fs": fs, "D": D, "nblk": nblk, "seed": 11,
+           "stream_id": np.array([k[0] for k in packets], dtype=np.int32),
+           "pts": np.array([k[1] for k in packets], dtype=np.float64),
+           "duration": np.array([k[2] for k in packets], dtype=np.float64),
+           "size": np.array([len(k[3]) for k in packets], dtype=np.int32),
+           "data_sha256": np.array([hashlib.sha256(k[3]).hexdigest() for k in packets]),
+           "rds_payload": np.array([k[3].hex() for k in packets if k[0] == 2]),
+           "signal": np.array([[s[0][0], s[0][1], float(s[0][2])] for s in status], dtype=np.float32),
+           "pvr_signal_snr": np.array([[s[1]["signal"], s[1]["snr"]] for s in status], dtype=np.int64),
+           "pvr_status_text": np.array([s[1]["adapter_status"] for s in status]),
+           "provider_name": np.array(status[-1][1]["provider_name"]),
+           "audio_level": np.array(rx.audio_level(), dtype=np.float32)}
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, os.path.getsize(path), "bytes,", len(packets), "packets,",
+          int((out["stream_id"] == 2).sum()), "rds packets")
+
+
 if __name__ == "__main__":
     for name, kw in CASES.items():
         make(name, **kw)
+    make_receiver()
