@@ -301,6 +301,19 @@ fmd_group_decoder* fmd_group_decoder_create(const fmd_callbacks* cb, void* user,
 void fmd_group_decoder_destroy(fmd_group_decoder* g);
 void fmd_group_decoder_reset(fmd_group_decoder* g);
 void fmd_group_decoder_push(fmd_group_decoder* g, const uint16_t blocks[4]);
+/* Filter design as the constructors do it on the host (float/double promotions as written):
+ * cDownsampleFilter's Lanczos table (DownConvert.cpp:18-56 through the ctor :78; `order` is the
+ * ctor's filter_order, order + 2 floats are written), cFirFilter::InitLPFilter's Kaiser low-pass
+ * (FirFilter.cpp:44-140; returns the tap count), cIirFilter::Init (IirFilter.cpp:11-60; type
+ * 0 LP, 1 HP, 2 BP, 3 BR; out = b0 b1 b2 a1 a2) and cFineTuner's table (FmDecode.cpp:45-58;
+ * 2*table_size floats).  Return the element count (which may exceed cap: nothing past cap is
+ * written) or -1. */
+int fmd_design_lanczos(unsigned order, double cutoff, float* out, unsigned cap);
+int fmd_design_lp_kaiser(float scale, float astop, float fpass, float fstop, float fs, float* out,
+                         unsigned cap);
+int fmd_design_biquad(int type, float f0, float q, float fs, float out[5]);
+int fmd_design_tuner_lut(unsigned table_size, int freq_shift, float* out, unsigned cap);
+
 /* cRadioReceiver::AddUECPDataFrame byte stuffing (RadioReceiver.cpp:387-414):
  * 0xFE, payload with 0xFD escapes, 0xFF.  Returns bytes written (<= cap) or -1. */
 int fmd_uecp_stuff_frame(const uint8_t* frame, unsigned len, uint8_t* out, unsigned cap);

@@ -2013,6 +2013,14 @@ static unsigned copy_out(const float* src, unsigned n, float* out, unsigned cap)
   return n;
 }
 
+unsigned fmo_design_tuner_lut(unsigned table_size, int freq_shift, float* out, unsigned cap)
+{
+  fine_tuner ft;
+  fine_tuner_init(&ft, table_size, freq_shift);
+  unsigned n = copy_out((const float*)ft.table, 2 * table_size, out, cap);
+  free(ft.table);
+  return n;
+}
 unsigned fmo_get_lut(const fmo_decoder* d, float* out, unsigned cap)
 {
   return copy_out((const float*)d->tuner.table, 2 * d->tuner.size, out, cap);

@@ -135,6 +135,7 @@ unsigned fmo_design_lanczos(unsigned filter_order_arg, double cutoff, float* out
 unsigned fmo_design_lp_kaiser(float scale, float astop, float fpass, float fstop, float fs,
                               float* out, unsigned cap);
 void fmo_design_biquad(int type, float f0, float q, float fs, float out_b0b1b2a1a2[5]);
+unsigned fmo_design_tuner_lut(unsigned table_size, int freq_shift, float* out, unsigned cap);
 unsigned fmo_get_lut(const fmo_decoder* d, float* out, unsigned cap);
 unsigned fmo_get_if_taps(const fmo_decoder* d, float* out, unsigned cap);
 unsigned fmo_get_audio_taps(const fmo_decoder* d, float* out, unsigned cap);

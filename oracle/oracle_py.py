@@ -346,3 +346,10 @@ def design_biquad(ftype, f0, q, fs):
     buf = np.zeros(5, np.float32)
     lib().fmo_design_biquad(ftype, f0, q, fs, buf.ctypes.data)
     return buf
+
+
+def design_tuner_lut(table_size, freq_shift):
+    buf = np.zeros(2 * table_size, np.float32)
+    lib().fmo_design_tuner_lut.argtypes = [C.c_uint, C.c_int, C.c_void_p, C.c_uint]
+    lib().fmo_design_tuner_lut(table_size, freq_shift, buf.ctypes.data, buf.size)
+    return buf

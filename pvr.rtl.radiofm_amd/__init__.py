@@ -93,6 +93,7 @@ class FmdPvrSignalStatus(C.Structure):
 STREAM_AUDIO, STREAM_RDS, STREAM_CHANGE, STREAM_TIME_BASE = 1, 2, -11, 1000000
 
 EXPORTS = [
+    "fmd_design_lanczos", "fmd_design_lp_kaiser", "fmd_design_biquad", "fmd_design_tuner_lut",
     "fmd_batch_get_audio_level", "fmd_receiver_open", "fmd_receiver_close", "fmd_receiver_write_iq",
     "fmd_receiver_write_u8", "fmd_receiver_end", "fmd_receiver_queued_samples",
     "fmd_receiver_set_stream_change", "fmd_receiver_demux_read", "fmd_receiver_signal_status",
@@ -157,6 +158,10 @@ def lib():
         L.fmd_batch_get_status.argtypes = [vp, u, C.POINTER(FmdStatus)]
         L.fmd_batch_get_tap.argtypes = [vp, i, u, vp, u]
         L.fmd_batch_get_audio_level.argtypes = [vp, u, C.POINTER(FmdAudioLevel)]
+        L.fmd_design_lanczos.argtypes = [u, C.c_double, vp, u]
+        L.fmd_design_lp_kaiser.argtypes = [C.c_float] * 5 + [vp, u]
+        L.fmd_design_biquad.argtypes = [i, C.c_float, C.c_float, C.c_float, vp]
+        L.fmd_design_tuner_lut.argtypes = [u, i, vp, u]
         L.fmd_receiver_open.argtypes = [C.POINTER(FmdParams), C.c_double, C.c_char_p, C.POINTER(vp)]
         L.fmd_receiver_close.argtypes = [vp]
         L.fmd_receiver_write_iq.argtypes = [vp, vp, u]
@@ -522,3 +527,32 @@ class Receiver:
         return {"adapter_name": st.adapter_name.decode(), "adapter_status": st.adapter_status.decode(),
                 "provider_name": st.provider_name.decode("latin-1"), "signal": st.signal,
                 "snr": st.snr}
+
+
+# ---- filter design on the host (no GPU needed), same constructors as the reference ----------
+def design_lanczos(order, cutoff):
+    """cDownsampleFilter's Lanczos table (DownConvert.cpp:18-56, :78): order + 2 floats."""
+    buf = np.zeros(order + 2, np.float32)
+    _check(lib().fmd_design_lanczos(order, cutoff, buf.ctypes.data, buf.size))
+    return buf
+
+
+def design_lp_kaiser(scale, astop, fpass, fstop, fs):
+    """cFirFilter::InitLPFilter (FirFilter.cpp:44-140)."""
+    buf = np.zeros(4096, np.float32)
+    n = _check(lib().fmd_design_lp_kaiser(scale, astop, fpass, fstop, fs, buf.ctypes.data, buf.size))
+    return buf[:n].copy()
+
+
+def design_biquad(ftype, f0, q, fs):
+    """cIirFilter::Init (IirFilter.cpp:11-60): b0 b1 b2 a1 a2; ftype 0 LP, 1 HP, 2 BP, 3 BR."""
+    buf = np.zeros(5, np.float32)
+    _check(lib().fmd_design_biquad(ftype, f0, q, fs, buf.ctypes.data))
+    return buf
+
+
+def design_tuner_lut(table_size, freq_shift):
+    """cFineTuner's table (FmDecode.cpp:45-58), interleaved re, im."""
+    buf = np.zeros(2 * table_size, np.float32)
+    _check(lib().fmd_design_tuner_lut(table_size, freq_shift, buf.ctypes.data, buf.size))
+    return buf

@@ -1392,6 +1392,48 @@ void fmd_group_decoder_push(fmd_group_decoder* g, const uint16_t blocks[4])
     g->g.push(blocks);
 }
 
+static int copy_design(const std::vector<float>& v, float* out, unsigned cap)
+{
+  if (!out && cap)
+    return -1;
+  for (size_t i = 0; i < v.size() && i < cap; i++)
+    out[i] = v[i];
+  return int(v.size());
+}
+
+int fmd_design_lanczos(unsigned order, double cutoff, float* out, unsigned cap)
+{
+  if (order < 1)
+    return -1;
+  return copy_design(fmd::make_lanczos(order, cutoff), out, cap);
+}
+
+int fmd_design_lp_kaiser(float scale, float astop, float fpass, float fstop, float fs, float* out,
+                         unsigned cap)
+{
+  return copy_design(fmd::make_kaiser_lp(scale, astop, fpass, fstop, fs), out, cap);
+}
+
+int fmd_design_biquad(int type, float f0, float q, float fs, float out[5])
+{
+  if (!out || type < 0 || type > 3)
+    return -1;
+  const fmd::Biquad b = fmd::make_biquad(fmd::BiquadType(type), f0, q, fs);
+  out[0] = b.b0;
+  out[1] = b.b1;
+  out[2] = b.b2;
+  out[3] = b.a1;
+  out[4] = b.a2;
+  return 5;
+}
+
+int fmd_design_tuner_lut(unsigned table_size, int freq_shift, float* out, unsigned cap)
+{
+  if (!table_size)
+    return -1;
+  return copy_design(fmd::make_tuner_lut(table_size, freq_shift), out, cap);
+}
+
 int fmd_uecp_stuff_frame(const uint8_t* frame, unsigned len, uint8_t* out, unsigned cap)
 {
   // cRadioReceiver::AddUECPDataFrame (RadioReceiver.cpp:387-414)

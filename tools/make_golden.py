@@ -118,7 +118,50 @@ def make_receiver(name="receiver_2p4M", fs=2.4e6, D=11, nblk=40):
           int((out["stream_id"] == 2).sum()), "rds packets")
 
 
+# design-level vectors.  (order, cutoff) pairs, filters and tables the path builds.
+G1_LANCZOS = [(32, 0.15), (88, 0.6 / 11), (250, 0.06), (218, 15000 / 218181.8), (368, 0.6 / 46),
+              (4096, 0.6 / 46)]
+G1_KAISER = {  # name: (scale, astop, fpass, fstop, fs) -- the calls of FmDecode.cpp:286 (29 taps)
+    # and RDSProcess.cpp:97 (75 taps) at the two RDS process rates the half-band chains end at
+    "audio_lpf_48k": (1.0, 60.0, 15000.0, float(np.float32(1.4 * 15000.0)), 48000.0),
+    "rds_lpf_27272": (1.0, 40.0, 2400.0, float(np.float32(1.3 * 2400.0)), float(np.float32(2.4e6 / 11 / 8))),
+    "rds_lpf_31250": (1.0, 40.0, 2400.0, float(np.float32(1.3 * 2400.0)), 31250.0),
+}
+G1_BIQUAD = {  # name: (type, f0, q, fs): 19 kHz notch (FmDecode.cpp:291), bit-sync resonator
+    "notch_19k_48k": (3, 19000.0, 5.0, 48000.0),
+    "bitsync_27272": (2, 1187.5, 500.0, float(np.float32(2.4e6 / 11 / 8))),
+    "bitsync_31250": (2, 1187.5, 500.0, 31250.0),
+}
+G1_LUT = [(64, 10), (64, -7), (64, 0), (64, 31), (256, -128), (256, 99)]
+
+
+def design_vectors(mod):
+    """The G1 set computed by `mod` (oracle_py or the product package: same function names)."""
+    out = {}
+    for order, cutoff in G1_LANCZOS:
+        out["lanczos_%d_%.6f" % (order, cutoff)] = mod.design_lanczos(order, cutoff)
+    for name, a in G1_KAISER.items():
+        out["kaiser_" + name] = mod.design_lp_kaiser(*a)
+    for name, a in G1_BIQUAD.items():
+        out["biquad_" + name] = mod.design_biquad(*a)
+    for size, shift in G1_LUT:
+        out["lut_%d_%d" % (size, shift)] = mod.design_tuner_lut(size, shift)
+    return out
+
+
+def make_design(name="design_g1"):
+    out = design_vectors(oracle_py)
+    for fs, D in ((2.4e6, 11), (1.0e6, 4)):
+        dec = oracle_py.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+        out["rds_mf_%d" % int(fs / D)] = dec.rds_mf_taps()
+        out["rds_hb_%d" % int(fs / D)] = np.array(dec.rds_hb_lengths(), dtype=np.int32)
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 if __name__ == "__main__":
     for name, kw in CASES.items():
         make(name, **kw)
     make_receiver()
+    make_design()
