@@ -231,6 +231,12 @@ int fmd_batch_set_profiling(fmd_batch* b, int level);
 int fmd_batch_get_stage_ms(fmd_batch* b, float* out, unsigned cap);
 const char* fmd_stage_name(unsigned idx);
 
+/* Test aid: evaluates the device build of one math helper of csrc/fmd_math.h on n arguments
+ * (host arrays).  what: 0 atan2f table form (a = y, b = x), 1 atan2f literal fdlibm, 2 sin/cos
+ * table form (a = phase; out0 = sin, out1 = cos), 3 sin/cos series form, 4 mid-range division
+ * a / b, 5 RTL-SDR byte -> float (a = byte value), 6 the RDS PLL's polynomial arctan2. */
+int fmd_debug_math(int what, unsigned n, const float* a, const float* b, float* out0, float* out1);
+
 const char* fmd_last_error(void);
 const char* fmd_version(void);
 

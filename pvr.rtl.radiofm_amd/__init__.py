@@ -93,7 +93,7 @@ class FmdPvrSignalStatus(C.Structure):
 STREAM_AUDIO, STREAM_RDS, STREAM_CHANGE, STREAM_TIME_BASE = 1, 2, -11, 1000000
 
 EXPORTS = [
-    "fmd_design_lanczos", "fmd_design_lp_kaiser", "fmd_design_biquad", "fmd_design_tuner_lut",
+    "fmd_debug_math", "fmd_design_lanczos", "fmd_design_lp_kaiser", "fmd_design_biquad", "fmd_design_tuner_lut",
     "fmd_batch_get_audio_level", "fmd_receiver_open", "fmd_receiver_close", "fmd_receiver_write_iq",
     "fmd_receiver_write_u8", "fmd_receiver_end", "fmd_receiver_queued_samples",
     "fmd_receiver_set_stream_change", "fmd_receiver_demux_read", "fmd_receiver_signal_status",
@@ -158,6 +158,7 @@ def lib():
         L.fmd_batch_get_status.argtypes = [vp, u, C.POINTER(FmdStatus)]
         L.fmd_batch_get_tap.argtypes = [vp, i, u, vp, u]
         L.fmd_batch_get_audio_level.argtypes = [vp, u, C.POINTER(FmdAudioLevel)]
+        L.fmd_debug_math.argtypes = [i, u, vp, vp, vp, vp]
         L.fmd_design_lanczos.argtypes = [u, C.c_double, vp, u]
         L.fmd_design_lp_kaiser.argtypes = [C.c_float] * 5 + [vp, u]
         L.fmd_design_biquad.argtypes = [i, C.c_float, C.c_float, C.c_float, vp]
@@ -556,3 +557,15 @@ def design_tuner_lut(table_size, freq_shift):
     buf = np.zeros(2 * table_size, np.float32)
     _check(lib().fmd_design_tuner_lut(table_size, freq_shift, buf.ctypes.data, buf.size))
     return buf
+
+
+def debug_math(what, a, b=None):
+    """Device build of one csrc/fmd_math.h helper on arrays (see fmd_debug_math)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    o0, o1 = np.empty_like(a), np.empty_like(a)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        bp = b.ctypes.data
+    _check(lib().fmd_debug_math(what, a.size, a.ctypes.data, bp, o0.ctypes.data, o1.ctypes.data))
+    return o0, o1

@@ -1259,6 +1259,45 @@ int fmd_get_status(fmd_decoder* d, fmd_status* st)
   return d ? fmd_batch_get_status(d->b, 0, st) : fail(FMD_ERR_ARG, "null decoder");
 }
 
+/* Test aid, see k_debug_math.  Host arrays in and out; b may be NULL for one-argument functions. */
+int fmd_debug_math(int what, unsigned n, const float* a, const float* b, float* out0, float* out1)
+{
+  if (!a || !out0 || !out1 || n == 0)
+    return fail(FMD_ERR_ARG, "fmd_debug_math: bad argument");
+  fmd::Params p{};
+  p.sample_rate_if = 2.4e6;
+  p.sample_rate_pcm = 48000.0;
+  p.bandwidth_pcm = 15000.0;
+  p.downsample = 11;
+  const fmd::Design d = fmd::make_design(p);
+  DevBuf<float> da, db, d0, d1;
+  DevBuf<double> tab;
+  int bad = da.alloc(n) | db.alloc(n) | d0.alloc(n) | d1.alloc(n) | tab.alloc(d.sincos_tab.size());
+  if (!bad)
+  {
+    bad |= hipMemcpy(da.p, a, size_t(n) * 4, hipMemcpyHostToDevice) != hipSuccess;
+    if (b)
+      bad |= hipMemcpy(db.p, b, size_t(n) * 4, hipMemcpyHostToDevice) != hipSuccess;
+    bad |= hipMemcpy(tab.p, d.sincos_tab.data(), d.sincos_tab.size() * 8, hipMemcpyHostToDevice) !=
+           hipSuccess;
+  }
+  if (!bad)
+  {
+    hipLaunchKernelGGL(fmd::k_debug_math, dim3(std::min(4096u, (n + 63) / 64)), dim3(64), 0, nullptr, what,
+                       n, da.p, db.p, d0.p, d1.p, tab.p,
+                       FmdSincosTab{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo});
+    bad |= hipDeviceSynchronize() != hipSuccess;
+    bad |= hipMemcpy(out0, d0.p, size_t(n) * 4, hipMemcpyDeviceToHost) != hipSuccess;
+    bad |= hipMemcpy(out1, d1.p, size_t(n) * 4, hipMemcpyDeviceToHost) != hipSuccess;
+  }
+  da.release();
+  db.release();
+  d0.release();
+  d1.release();
+  tab.release();
+  return bad ? fail(FMD_ERR_DEVICE, "fmd_debug_math: device error") : FMD_OK;
+}
+
 /* ---- cRadioReceiver's stream side (csrc/fmd_receiver.hpp) ------------------------------------ */
 } // extern "C"
 

@@ -304,8 +304,9 @@ __global__ __launch_bounds__(64) void k_if_level(const typename IN::elem* __rest
 /* K2: everything that is a sample-by-sample recurrence at the baseband rate, one lane per     */
 /*     channel, 64 channels per workgroup.  The workgroup has TWO waves with different roles   */
 /*     (they sit on different SIMDs of the CU, so they issue in parallel):                      */
-/*       wave 0: FM PLL demodulator (FmDecode.cpp:362-415) -> baseband chunk in LDS             */
-/*       wave 1: SamplesMeanRMS (:522-539), cPilotPhaseLock::Process (:143-229) with the        */
+/*       wave 0: FM PLL recurrence (FmDecode.cpp:362-408) -> NCO frequency term chunk in LDS    */
+/*       wave 1: the PLL's output filter (:409-412), SamplesMeanRMS (:522-539),                 */
+/*               cPilotPhaseLock::Process (:143-229) with the                                   */
 /*               2*baseband multiply (:455-456), RDS quadrature-oscillator mix                  */
 /*               (DownConvert.cpp:429-466), and all stores                                      */
 /*     Chunks of DS samples are double-buffered in LDS, one barrier per chunk.  A lone wave     */
@@ -342,7 +343,8 @@ __global__ __launch_bounds__(128) void k_demod_serial(
 
   if (role == 0)
   {
-    float nco_phase = st.F(F_NCO_PHASE)[c], nco_incr = st.F(F_NCO_INCR)[c], dc = st.F(F_DC_OFF)[c];
+    float nco_phase = st.F(F_NCO_PHASE)[c], nco_incr = st.F(F_NCO_INCR)[c];
+    __builtin_amdgcn_s_waitcnt(0); // state in registers: no memory wait is left inside the loop
     for (unsigned j = 0; j <= nchunks; j++)
     {
       if (j < nchunks)
@@ -374,20 +376,22 @@ __global__ __launch_bounds__(128) void k_demod_serial(
             const bool lt = nco_phase < 0;
             const double off = ge ? -FMD_K_2PI : FMD_K_2PI;
             const float moved = (float)(pd + off); // exact difference / sum, rounded once
-            const float sel = (ge | lt) ? moved : nco_phase;
-            if (__builtin_expect((pd >= 2.0 * FMD_K_2PI) | (pd < -FMD_K_2PI), 0))
-            {
-              if (ge)
-                nco_phase = (float)fmod(pd, FMD_K_2PI);
-              while (nco_phase < 0)
-                nco_phase = (float)((double)nco_phase + FMD_K_2PI);
+            const bool far = (pd >= 2.0 * FMD_K_2PI) | (pd < -FMD_K_2PI);
+            float next = (ge | lt) ? moved : nco_phase;
+            if (FMD_ANY_LANE(far))
+            { // never with the clamps above; kept literal
+              if (far)
+              {
+                next = nco_phase;
+                if (ge)
+                  next = (float)fmod(pd, FMD_K_2PI);
+                while (next < 0)
+                  next = (float)((double)next + FMD_K_2PI);
+              }
             }
-            else
-              nco_phase = sel;
+            nco_phase = next;
           }
-          const float pinc = 2 * nco_incr;
-          dc = (float)((1 - 0.0001) * (double)dc + 0.0001 * (double)pinc);
-          chunk[j & 1][u][lane] = (pinc - dc) * k.demod_gain;
+          chunk[j & 1][u][lane] = 2 * nco_incr; // phaseIncr (:409); the output filter runs in wave 1
         }
       }
       lds_barrier();
@@ -396,7 +400,6 @@ __global__ __launch_bounds__(128) void k_demod_serial(
     {
       st.F(F_NCO_PHASE)[c] = nco_phase;
       st.F(F_NCO_INCR)[c] = nco_incr;
-      st.F(F_DC_OFF)[c] = dc;
     }
   }
   else
@@ -405,20 +408,28 @@ __global__ __launch_bounds__(128) void k_demod_serial(
     float p_x1 = st.F(F_P_X1)[c], p_freq = st.F(F_P_FREQ)[c], p_phase = st.F(F_P_PHASE)[c];
     float p_level = 1000.0f; // FmDecode.cpp:147
     float o_re = st.F(F_OSC_RE)[c], o_im = st.F(F_OSC_IM)[c];
+    float dc = st.F(F_DC_OFF)[c];
+    // the state is in registers before the chunk loop starts: inside it, the only loads in flight
+    // are the staged chunk's, and nothing in the sample loop waits for them
+    __builtin_amdgcn_s_waitcnt(0);
     float vsum = 0.0f, vsumsq = 0.0f;
     float2* __restrict__ brp = br + (size_t)Hbb * CP + c; // (baseband, 38 kHz * 2 * baseband)
     float2* __restrict__ mixp = mix + (size_t)Hmix * CP + c;
     for (unsigned j = 0; j <= nchunks; j++)
     {
-      /* This wave has issue slots to spare, so it also moves the FM wave's input: while that wave
-       * works on chunk j, the IF-FIR samples of chunk j+1 travel HBM -> registers -> LDS here,
-       * a whole chunk ahead of their use, so no memory latency sits on the critical recurrence. */
+      /* This wave also moves the FM wave's input: while that wave works on chunk j, the IF-FIR
+       * samples of chunk j+1 travel HBM -> registers -> LDS here, a whole chunk ahead of their
+       * use.  All DS loads of the chunk are issued before the sample loop and land during it (a
+       * load per sample inside the loop would have to return within one iteration, ~0.4 us:
+       * no margin against HBM latency once other kernels use the memory system). */
       const unsigned pf0 = (j + 1) * DS; // first sample of the chunk being staged
       const bool staging = (j + 1) < nchunks;
-      if (j == 0 && staging)
-      { // nothing to consume yet: stage chunk 1 in one go
+      float2 pre[DS];
+      if (staging)
+      {
+#pragma unroll
         for (unsigned u = 0; u < DS; u++)
-          stage[1][u][lane] = row[min(pf0 + u, M - 1)];
+          pre[u] = row[min(pf0 + u, M - 1)];
       }
       if (j >= 1)
       {
@@ -427,10 +438,11 @@ __global__ __launch_bounds__(128) void k_demod_serial(
 #pragma unroll 1
         for (unsigned u = 0; u < cnt; u++)
         {
-          float2 pre = make_float2(0.0f, 0.0f);
-          if (staging)
-            pre = row[min(pf0 + u, M - 1)];
-          const float v = chunk[(j - 1) & 1][u][lane];
+          /* FM PLL output stage (FmDecode.cpp:409-412): low-pass of the NCO frequency term as
+           * DC offset, off the PLL's own recurrence and therefore done here */
+          const float pinc = chunk[(j - 1) & 1][u][lane];
+          dc = (float)((1 - 0.0001) * (double)dc + 0.0001 * (double)pinc);
+          const float v = (pinc - dc) * k.demod_gain;
           vsum += v;
           vsumsq += v * v;
           /* ---- pilot PLL (FmDecode.cpp:151-217) ---- */
@@ -477,12 +489,13 @@ __global__ __launch_bounds__(128) void k_demod_serial(
           }
           brp += CP;
           mixp += CP;
-          if (staging)
-            stage[(j + 1) & 1][u][lane] = pre;
         }
-        if (staging)
-          for (unsigned u = cnt; u < DS; u++) // only when the consumed chunk was the short last one
-            stage[(j + 1) & 1][u][lane] = row[min(pf0 + u, M - 1)];
+      }
+      if (staging)
+      {
+#pragma unroll
+        for (unsigned u = 0; u < DS; u++)
+          stage[(j + 1) & 1][u][lane] = pre[u];
       }
       lds_barrier();
     }
@@ -498,6 +511,7 @@ __global__ __launch_bounds__(128) void k_demod_serial(
       st.F(F_P_LEVEL)[c] = p_level;
       st.F(F_OSC_RE)[c] = o_re;
       st.F(F_OSC_IM)[c] = o_im;
+      st.F(F_DC_OFF)[c] = dc;
       { // lock status (FmDecode.cpp:219-228)
         int cnt = st.I(I_P_LOCK_CNT)[c];
         if (2 * p_level > k.p_minsignal)
@@ -1171,6 +1185,58 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
     st.F(F_AUDIO_MEAN)[c] = vsum / n;
     st.F(F_AUDIO_RMS)[c] = rms;
     st.F(F_AUDIO_LEVEL)[c] = (float)(0.95 * (double)st.F(F_AUDIO_LEVEL)[c] + 0.05 * (double)rms);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Test aid: the device builds of the fmd_math.h helpers on arrays of arguments, so their      */
+/* device-only code (reciprocal-based division, ballot branches, table forms) can be swept      */
+/* against the host libm directly (fmd_debug_math).                                             */
+/* ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(64) void k_debug_math(int what, unsigned n, const float* __restrict__ a,
+                                                   const float* __restrict__ b, float* __restrict__ o0,
+                                                   float* __restrict__ o1,
+                                                   const double* __restrict__ sctab_g, FmdSincosTab sct)
+{
+  __shared__ double sctab[2 * FMD_SINCOS_TAB_SIZE];
+  __shared__ float atab[FMD_ATAN_TAB_FLOATS];
+  for (unsigned i = threadIdx.x; i < 2 * FMD_SINCOS_TAB_SIZE; i += 64)
+    sctab[i] = sctab_g[i];
+  if (threadIdx.x == 0)
+    fmd_atan_table_fill(atab);
+  __syncthreads();
+  for (unsigned i = blockIdx.x * 64 + threadIdx.x; i < (n + 63) / 64 * 64; i += gridDim.x * 64)
+  { // whole waves stay in the loop: the helpers use wave-wide ballots
+    const unsigned k = min(i, n - 1);
+    float r0 = 0.0f, r1 = 0.0f;
+    switch (what)
+    {
+      case 0:
+        r0 = fmd_atan2f_tab(a[k], b[k], atab);
+        break;
+      case 1:
+        r0 = fmd_atan2f(a[k], b[k]);
+        break;
+      case 2:
+        fmd_sincos_tab(a[k], sctab, sct, &r0, &r1);
+        break;
+      case 3:
+        fmd_sincos_nco(a[k], &r0, &r1);
+        break;
+      case 4:
+        r0 = fmd_div_midrange(a[k], b[k]);
+        break;
+      case 5:
+        r0 = fmd_u8_to_f32((unsigned)a[k]);
+        break;
+      default:
+        r0 = fmd_rds_arctan2(a[k], b[k]);
+    }
+    if (i < n)
+    {
+      o0[i] = r0;
+      o1[i] = r1;
+    }
   }
 }
 

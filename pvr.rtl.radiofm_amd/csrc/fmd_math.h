@@ -50,6 +50,35 @@
 #define FMD_K_PI (3.14159265358979323846)
 #define FMD_K_PI2 (FMD_K_PI / 2.0)
 
+/* Rare-input fix-ups in the per-sample loops sit behind a wave-uniform test (one compare and one
+ * scalar branch on the common path) instead of a divergent branch (exec save / restore). */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FMD_ANY_LANE(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
+#else
+#define FMD_ANY_LANE(cond) (cond)
+#endif
+
+/* n / d, correctly rounded, for operands where no step of the quotient refinement leaves the
+ * normal range (here: d in [0.4, 2^26], |n| <= 2^26 or zero).  On the device this is the
+ * compiler's own IEEE division expansion without the range scaling and special-case fix-up
+ * around it (8 instead of 11 instructions); the fmaf calls are that algorithm, not contractions
+ * of reference arithmetic. */
+FMD_HD float fmd_div_midrange(float n, float d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+  const float r1 = __builtin_fmaf(e0, r0, r0);
+  const float q0 = n * r1;
+  const float e1 = __builtin_fmaf(-d, q0, n);
+  const float q1 = __builtin_fmaf(e1, r1, q0);
+  const float e2 = __builtin_fmaf(-d, q1, n);
+  return __builtin_fmaf(e2, r1, q1);
+#else
+  return n / d;
+#endif
+}
+
 FMD_HD uint32_t fmd_f2u(float f)
 {
   uint32_t u;
@@ -301,13 +330,16 @@ FMD_HD float fmd_atan2f_tab(float y, float x, const float* tab)
   const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
   const float q = fabsf(y / x);
   const uint32_t iq = fmd_f2u(q);
-  if (iq - 0x31000000u >= 0x4c000000u - 0x31000000u) /* rare: see above */
-    return fmd_atan2f(y, x);
-  const int r = (iq >= 0x3ee00000u) + (iq >= 0x3f300000u) + (iq >= 0x3f980000u) + (iq >= 0x401c0000u);
+  const bool rare = iq - 0x31000000u >= 0x4c000000u - 0x31000000u; /* see above */
+  /* the common-range evaluation runs for every lane (a rare lane computes a value nobody uses:
+   * its range index is clamped, nothing here can trap) */
+  const uint32_t ic = rare ? 0x3f800000u : iq;
+  const float qc = fmd_u2f(ic);
+  const int r = (ic >= 0x3ee00000u) + (ic >= 0x3f300000u) + (ic >= 0x3f980000u) + (ic >= 0x401c0000u);
   const float* t = tab + 8 * r;
-  const float num = t[0] * q + t[1];
-  const float den = t[2] * q + t[3];
-  const float xr = num / den;
+  const float num = t[0] * qc + t[1];
+  const float den = t[2] * qc + t[3]; /* 1, 2+q, q+1, 1+1.5q or q: within [0.4375, 2^25] */
+  const float xr = fmd_div_midrange(num, den);
   const float z = xr * xr;
   const float w = z * z;
   const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
@@ -317,7 +349,13 @@ FMD_HD float fmd_atan2f_tab(float y, float x, const float* tab)
   /* quadrant: x >= 0 -> at, x < 0 -> pi - (at - pi_lo); then the sign of y (m = 1, 3 negate) */
   const float left = pi - (at - pi_lo);
   const float base = ((int32_t)fmd_f2u(x) < 0) ? left : at;
-  return fmd_u2f(fmd_f2u(base) ^ (fmd_f2u(y) & 0x80000000u));
+  float res = fmd_u2f(fmd_f2u(base) ^ (fmd_f2u(y) & 0x80000000u));
+  if (FMD_ANY_LANE(rare))
+  {
+    if (rare)
+      res = fmd_atan2f(y, x);
+  }
+  return res;
 }
 
 /* Table-driven variant of fmd_sincos_nco for the per-sample loops: 1024-entry table of
