@@ -494,11 +494,10 @@ using FirFn = void (*)(const typename IN::elem*, size_t, unsigned, const float2*
                        unsigned, unsigned, const float*, unsigned, unsigned, unsigned, unsigned, float2*,
                        unsigned, unsigned, unsigned);
 
-template <class IN>
-int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
-                    unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark)
+template <class IN, int TILE>
+int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
+                      unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark)
 {
-  constexpr int TILE = 256;
   const fmd::Design& d = b->des;
   const unsigned C = b->C, D = d.D, T = d.table_size;
   const unsigned ntiles = (M + TILE - 1) / TILE;
@@ -529,6 +528,30 @@ int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, un
   hipLaunchKernelGGL(fmd::k_if_level<IN>, dim3(C), dim3(64), 0, sF, x, iq_channel_stride, N, b->lut.p, T,
                      b->lut_idx, b->st);
   return FMD_OK;
+}
+
+/* Outputs per workgroup.  Small workgroups suffer least from the serial stage: its two role waves
+ * issue with priority on two SIMDs of half the CUs, a bandwidth wave sharing such a SIMD runs at a
+ * fraction of its speed, and a multi-wave workgroup waits for its slowest wave.  One wave per
+ * workgroup (measured, 8192 channels, in the pipeline): 0.89 ms against 0.98 ms for four waves,
+ * alone 0.77 against 0.78.  Long filters keep 256 outputs per workgroup so the `order`-sample
+ * halo is amortised and the window fits LDS a useful number of times. */
+template <class IN>
+int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
+                    unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark)
+{
+  const fmd::Design& d = b->des;
+  const unsigned T = d.table_size;
+  auto fits = [&](unsigned tile) {
+    const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * tile && (size_t(tile) * d.D) % T == 0;
+    const size_t lds = (size_t(tile - 1) * d.D + d.if_order + 4) * sizeof(float2);
+    return pow2 && d.if_order <= 4u * tile * d.D / 8u && lds <= 16 * 1024; // halo <= half the tile span
+  };
+  if (fits(64))
+    return launch_if_stage_t<IN, 64>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
+  if (fits(128))
+    return launch_if_stage_t<IN, 128>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
+  return launch_if_stage_t<IN, 256>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
 }
 
 enum IqFormat

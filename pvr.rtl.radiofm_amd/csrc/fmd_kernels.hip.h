@@ -240,7 +240,10 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
     for (int k = max(k_al, 0) + (int)tid; k < k_hi; k += TILE)
       win[k - k_al] = cmul(IN::one(x, k), l[(lut_idx0 + (unsigned)k) % T]);
   }
-  __syncthreads();
+  if (TILE == 64)
+    lds_wave_sync(); // one wave: its LDS operations execute in order
+  else
+    __syncthreads();
 
   if (tid < nout)
   {
