@@ -76,6 +76,14 @@ public:
     return n > 0 ? static_cast<unsigned int>(n) : 0u;
   }
 
+  /* Not in the reference: cRtlSdrSource::ReadAsyncCB's conversion (RTL_SDR_Source.cpp:206-211)
+   * and ProcessStream in one call -- buf = 2 * samples bytes as librtlsdr delivers them. */
+  unsigned int ProcessStreamU8(const uint8_t* buf, unsigned int samples, float* audio)
+  {
+    const int n = fmd_process_stream_u8(m_dec, buf, samples, audio);
+    return n > 0 ? static_cast<unsigned int>(n) : 0u;
+  }
+
   bool StereoDetected() const { return Status().stereo_detected != 0; }
   RealType GetTuningOffset() const { return Status().tuning_offset; }
   RealType GetInterfaceLevel() const { return Status().interface_level; }

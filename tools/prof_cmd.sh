@@ -10,6 +10,7 @@ python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -1 gpurun_out/${TAG}_bench.json
 python bench.py --concurrency 0 --stage-profile --no-cpu-baseline > gpurun_out/${TAG}_bench_serialised.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -- python bench.py --no-cpu-baseline > gpurun_out/${TAG}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats_ser -- python bench.py --no-cpu-baseline --concurrency 0 > gpurun_out/${TAG}_stats_ser.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-include-regex "k_if_fir" --output-format csv -d gpurun_out/${TAG}_pmc1 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --concurrency 0 > gpurun_out/${TAG}_pmc1.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_if_fir" --output-format csv -d gpurun_out/${TAG}_pmc2 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --concurrency 0 > gpurun_out/${TAG}_pmc2.log 2>&1
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-include-regex "k_if_fir" --output-format csv -d gpurun_out/${TAG}_pmc3 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --concurrency 0 > gpurun_out/${TAG}_pmc3.log 2>&1

@@ -18,11 +18,14 @@ for name in ("bench", "bench_serialised"):
         line = open(src).read().strip().splitlines()[-1]
         json.loads(line)
         open(os.path.join(pr, "%s_%s.json" % (tag, name)), "w").write(line + "\n")
+st2 = glob.glob(os.path.join(go, tag + "_stats_ser", "**", "*_kernel_stats.csv"), recursive=True)
+if st2:
+    shutil.copy(st2[0], os.path.join(pr, tag + "_kernel_stats_serialised.csv"))
 st = glob.glob(os.path.join(go, tag + "_stats", "**", "*_kernel_stats.csv"), recursive=True)
 if st:
     shutil.copy(st[0], os.path.join(pr, tag + "_kernel_stats.csv"))
 out = open(os.path.join(pr, tag + "_pmc_k_if_fir.txt"), "w")
-out.write("rocprofv3 --pmc passes (separate runs, counters only) on k_if_fir<256,6,true>, 8192 channels,\n"
+out.write("rocprofv3 --pmc passes (separate runs, counters only) on k_if_fir (instance named in the kernel-stats csv of the same tag), 8192 channels,\n"
           "bench.py --concurrency 0; mean per launch.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE\n"
           "counts 1/2 of a wide coalesced read stream (MI355X_MICROARCH.md, HBM): read bytes = 2*FETCH_SIZE*1024.\n")
 vals = {}
