@@ -438,12 +438,15 @@ __global__ __launch_bounds__(128) void k_demod_serial(
       {
         const unsigned m0 = (j - 1) * DS;
         const unsigned cnt = min((unsigned)DS, M - m0);
+        float pinc_next = chunk[(j - 1) & 1][0][lane];
 #pragma unroll 1
         for (unsigned u = 0; u < cnt; u++)
         {
           /* FM PLL output stage (FmDecode.cpp:409-412): low-pass of the NCO frequency term as
-           * DC offset, off the PLL's own recurrence and therefore done here */
-          const float pinc = chunk[(j - 1) & 1][u][lane];
+           * DC offset, off the PLL's own recurrence and therefore done here.  The chunk entry is
+           * read one sample ahead so its LDS latency is not at the head of the iteration. */
+          const float pinc = pinc_next;
+          pinc_next = chunk[(j - 1) & 1][min(u + 1, (unsigned)DS - 1)][lane];
           dc = (float)((1 - 0.0001) * (double)dc + 0.0001 * (double)pinc);
           const float v = (pinc - dc) * k.demod_gain;
           vsum += v;

@@ -337,8 +337,15 @@ FMD_HD float fmd_atan2f_tab(float y, float x, const float* tab)
   const float qc = fmd_u2f(ic);
   const int r = (ic >= 0x3ee00000u) + (ic >= 0x3f300000u) + (ic >= 0x3f980000u) + (ic >= 0x401c0000u);
   const float* t = tab + 8 * r;
-  const float num = t[0] * qc + t[1];
-  const float den = t[2] * qc + t[3]; /* 1, 2+q, q+1, 1+1.5q or q: within [0.4375, 2^25] */
+  /* a = d and c = -b in every row (a: 1 2 1 1 0, c: 0 1 1 1.5 1), so the reduction only needs two
+   * small numbers per range; they come out of two packed byte constants (a, 2c) with a shift and a
+   * byte conversion instead of waiting for the table row, which is then only needed for hi / lo at
+   * the very end. */
+  const unsigned sh = 8u * (unsigned)r;
+  const float ca = (float)((0x0001010201ull >> sh) & 0xffu);        /* bytes r=0..4: 1 2 1 1 0 */
+  const float cc = (float)((0x0203020200ull >> sh) & 0xffu) * 0.5f; /* 2c:         0 2 2 3 2 */
+  const float num = ca * qc + (-cc);
+  const float den = cc * qc + ca; /* 1, 2+q, q+1, 1+1.5q or q: within [0.4375, 2^25] */
   const float xr = fmd_div_midrange(num, den);
   const float z = xr * xr;
   const float w = z * z;

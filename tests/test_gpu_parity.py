@@ -134,6 +134,36 @@ def test_rds_groups_bit_exact_and_call_aligned(pkg, oracle, fmsig):
     assert len(got) > 10
 
 
+@pytest.mark.parametrize("fs,D,a_rds,noise,seed", [(2.4e6, 11, 0.012, 0.05, 5), (2.4e6, 11, 0.011, 0.04, 10),
+                                                   (1.0e6, 4, 0.012, 0.05, 6)])
+def test_weak_rds_sync_loss_and_error_correction(pkg, oracle, fmsig, fs, D, a_rds, noise, seed):
+    """RDS subcarrier near the decoding threshold: blocks arrive with bit errors, the syndrome
+    decoder corrects bursts (CheckBlock, RDSProcess.cpp:363-431), block sync is lost and found
+    again (ProcessNewRdsBit states, :272-361).  The group stream, the state after every call and
+    the audio must still be the oracle's, bit for bit."""
+    p = fmsig.default_params(fs, noise_sigma=noise, a_rds=a_rds, seed=seed)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 1, record_callbacks=False)
+    import torch
+    st = torch.cuda.current_stream().cuda_stream
+    a_dev = torch.zeros(b.max_audio_floats(N), dtype=torch.float32, device="cuda")
+    got, states_o, states_g = [], [], []
+    for blk in range(150):
+        iq = fmsig.generate_f32(p, blk * N, N)
+        a_ref = o.process_stream(iq)
+        x = torch.from_numpy(iq).cuda()
+        nf = b.process_device(x.data_ptr(), 0, N, a_dev.data_ptr(), a_dev.numel(), st)
+        got += [(ci, blocks) for _ch, ci, blocks in b.collect_rds(stream=st)]
+        assert _bits_equal(a_dev[:nf].cpu().numpy(), a_ref), blk
+        states_o.append(o.status().rds_state)
+        states_g.append(b.status().rds_state)
+    assert states_g == states_o
+    assert len(set(states_o)) >= 3  # bit sync, block sync and group decode were all visited
+    assert sum(1 for i in range(1, 150) if states_o[i] < states_o[i - 1]) >= 2  # sync was lost
+    assert got == o.rds_groups() and len(got) >= 10
+    b.close()
+
+
 def test_batch_channels_independent(pkg, oracle, fmsig):
     """Several different stations in one batch: each channel equals its own oracle run."""
     fs, D = 2.4e6, 11
