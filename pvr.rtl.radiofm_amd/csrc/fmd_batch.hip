@@ -494,14 +494,16 @@ using FirFn = void (*)(const typename IN::elem*, size_t, unsigned, const float2*
                        unsigned, unsigned, const float*, unsigned, unsigned, unsigned, unsigned, float2*,
                        unsigned, unsigned, unsigned);
 
-template <class IN, int TILE>
+template <class IN, int TILE, int E>
 int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
                       unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark)
 {
   const fmd::Design& d = b->des;
   const unsigned C = b->C, D = d.D, T = d.table_size;
   const unsigned ntiles = (M + TILE - 1) / TILE;
-  const size_t lds = (size_t(TILE - 1) * D + d.if_order + 4) * sizeof(float2);
+  // 2^E regions of ((TILE-1)*D + order + slack) >> E slots each (see k_if_fir)
+  const size_t region = ((size_t(TILE - 1) * D + d.if_order + 2u * (1u << E) + 2u) >> E) + 1u;
+  const size_t lds = (region << E) * sizeof(float2);
   if (lds > 160 * 1024)
     return fail(FMD_ERR_ARG, "IF filter window does not fit in LDS");
   // fast staging: the tuner table is a power of two that divides a tile's sample span, so a lane
@@ -509,12 +511,12 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
   // loads per lane needed to stage one tile in a single round trip (two samples per load)
   const unsigned rounds = unsigned(((size_t(TILE - 1) * D + d.if_order + 2) / 2 + TILE - 1) / TILE);
-  FirFn<IN> kfn = &fmd::k_if_fir<IN, TILE, 1, false>;
+  FirFn<IN> kfn = &fmd::k_if_fir<IN, TILE, 1, false, E>;
   if (pow2)
-    kfn = rounds <= 2 ? &fmd::k_if_fir<IN, TILE, 2, true>
-        : rounds <= 4 ? &fmd::k_if_fir<IN, TILE, 4, true>
-        : rounds <= 6 ? &fmd::k_if_fir<IN, TILE, 6, true>
-                      : &fmd::k_if_fir<IN, TILE, 8, true>;
+    kfn = rounds <= 2 ? &fmd::k_if_fir<IN, TILE, 2, true, E>
+        : rounds <= 4 ? &fmd::k_if_fir<IN, TILE, 4, true, E>
+        : rounds <= 6 ? &fmd::k_if_fir<IN, TILE, 6, true, E>
+                      : &fmd::k_if_fir<IN, TILE, 8, true, E>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -528,6 +530,21 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   hipLaunchKernelGGL(fmd::k_if_level<IN>, dim3(C), dim3(64), 0, sF, x, iq_channel_stride, N, b->lut.p, T,
                      b->lut_idx, b->st);
   return FMD_OK;
+}
+
+/* Window layout by the power-of-two factor of D (k_if_fir): D odd -> plain, D = 2 * odd and
+ * 4 * odd -> de-interleaved into 2 / 4 regions; higher powers of two keep 4 regions (their
+ * lane stride stays even: fewer conflicts, not none). */
+template <class IN, int TILE>
+int launch_if_stage_e(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
+                      unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark)
+{
+  const unsigned D = b->des.D;
+  if (D % 2 != 0)
+    return launch_if_stage_t<IN, TILE, 0>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
+  if (D % 4 != 0)
+    return launch_if_stage_t<IN, TILE, 1>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
+  return launch_if_stage_t<IN, TILE, 2>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
 }
 
 /* Outputs per workgroup.  Small workgroups suffer least from the serial stage: its two role waves
@@ -548,10 +565,10 @@ int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, un
     return pow2 && d.if_order <= 4u * tile * d.D / 8u && lds <= 16 * 1024; // halo <= half the tile span
   };
   if (fits(64))
-    return launch_if_stage_t<IN, 64>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
+    return launch_if_stage_e<IN, 64>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
   if (fits(128))
-    return launch_if_stage_t<IN, 128>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
-  return launch_if_stage_t<IN, 256>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
+    return launch_if_stage_e<IN, 128>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
+  return launch_if_stage_e<IN, 256>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
 }
 
 enum IqFormat

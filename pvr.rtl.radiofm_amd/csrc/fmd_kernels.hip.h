@@ -157,7 +157,14 @@ struct InU8
  * on the same box); three outputs per thread sharing their window reads (2.4x less LDS traffic,
  * but 2 waves per SIMD: 0.94-1.09 ms).  Loads + staging alone take 0.84 ms, the tap loop alone
  * 0.66 ms: the float path sits at the HBM rate the chip sustains (6.3 TB/s copy, 79 % of spec). */
-template <class IN, int TILE, int UNROLL, bool POW2>
+/* Window layout, E = log2 of the power-of-two factor of D (template): the lanes of a wave read
+ * samples D apart, so with an even D a plain window puts them on a fraction of the LDS banks
+ * (D = 46: a half-wave reaches 32 of 64 banks, 2-way conflict; D = 4: 4-way).  The window is
+ * therefore stored de-interleaved: slot i (sample k_al + i) lives in region i mod 2^E at position
+ * i >> E.  All lanes read the same region at a given tap (their offsets lane*D are multiples of
+ * 2^E), and inside a region the lane stride is D >> E, which is odd: conflict-free.  Consecutive
+ * taps walk the regions round robin, each region contiguously.  E = 0 is the plain window. */
+template <class IN, int TILE, int UNROLL, bool POW2, int E = 0>
 __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __restrict__ iq,
                                                  size_t chan_stride, unsigned N,
                                                  const float2* __restrict__ hist_in,
@@ -169,8 +176,14 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
                                                  unsigned ntiles, unsigned xcd_map)
 {
   typedef typename IN::pair pair_t;
+  constexpr int G = 1 << E; // regions of the de-interleaved window
   extern __shared__ __attribute__((aligned(16))) float2 win[];
   __builtin_amdgcn_s_setprio(1); // ahead of the post-chain kernels it may share a SIMD with
+  // region size in slots: the window spans (TILE-1)*D + order samples plus alignment slack
+  const unsigned H = (((unsigned)(TILE - 1) * D + order + 2u * G + 2u) >> E) + 1u;
+  auto slot = [&](int i) -> unsigned { // LDS index of window slot i
+    return E == 0 ? (unsigned)i : ((unsigned)i & (unsigned)(G - 1)) * H + ((unsigned)i >> E);
+  };
   unsigned c, tile;
   if (xcd_map)
   {
@@ -189,7 +202,8 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
   const int p_first = (int)(pos + m0 * D);
   const int k_lo = p_first - (int)order;            // first sample the tile needs
   const int k_hi = p_first + (int)((nout - 1) * D); // one past the last sample it needs
-  const int k_al = k_lo & ~1; // floor to a pair boundary: LDS slot of sample k is k - k_al
+  // floor to a pair boundary (and to a region-0 slot): window slot of sample k is k - k_al
+  const int k_al = k_lo & ~((G > 2 ? G : 2) - 1);
   const typename IN::elem* __restrict__ x = iq + (size_t)c * chan_stride;
   const float2* __restrict__ l = lut + (size_t)c * T;
 
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
     const float2* __restrict__ h = hist_in + (size_t)c * order;
     const int nh = min(-k_lo, k_hi - k_lo);
     for (int i = (int)tid; i < nh; i += TILE)
-      win[i + (k_lo - k_al)] = h[(int)order + k_lo + i];
+      win[slot(i + (k_lo - k_al))] = h[(int)order + k_lo + i];
   }
   if (POW2)
   {
@@ -228,17 +242,23 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
           IN::unpack(v[u], a, b);
           a = cmul(a, l0);
           b = cmul(b, l1);
-          dst[i] = make_float4(a.x, a.y, b.x, b.y);
+          if (E == 0)
+            dst[i] = make_float4(a.x, a.y, b.x, b.y);
+          else
+          { // the two samples of a pair belong to neighbouring regions
+            win[slot(2 * i)] = a;
+            win[slot(2 * i + 1)] = b;
+          }
         }
       }
     }
     for (int k = max(kfull, 0) + (int)tid; k < k_hi; k += TILE)
-      win[k - k_al] = cmul(IN::one(x, k), l[(lut_idx0 + (unsigned)k) & mask]);
+      win[slot(k - k_al)] = cmul(IN::one(x, k), l[(lut_idx0 + (unsigned)k) & mask]);
   }
   else
   {
     for (int k = max(k_al, 0) + (int)tid; k < k_hi; k += TILE)
-      win[k - k_al] = cmul(IN::one(x, k), l[(lut_idx0 + (unsigned)k) % T]);
+      win[slot(k - k_al)] = cmul(IN::one(x, k), l[(lut_idx0 + (unsigned)k) % T]);
   }
   if (TILE == 64)
     lds_wave_sync(); // one wave: its LDS operations execute in order
@@ -247,15 +267,60 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
 
   if (tid < nout)
   {
-    const float2* w = win + (k_lo - k_al) + tid * D + order; // w[-j] = x[p - j]
     float2 acc = make_float2(0.0f, 0.0f);
-#pragma unroll 8
-    for (unsigned j = 1; j <= order; j++)
+    if (E == 0)
     {
-      const float k = coeff[j];
-      const float2 s = w[-(int)j];
-      acc.x += s.x * k;
-      acc.y += s.y * k;
+      const float2* w = win + (k_lo - k_al) + tid * D + order; // w[-j] = x[p - j]
+#pragma unroll 8
+      for (unsigned j = 1; j <= order; j++)
+      {
+        const float k = coeff[j];
+        const float2 s = w[-(int)j];
+        acc.x += s.x * k;
+        acc.y += s.y * k;
+      }
+    }
+    else
+    {
+      // tap j reads window slot U0 - j + tid*D = region (U0 - j) mod G, position ((U0 - j) >> E) +
+      // tid * (D >> E): a wave-uniform part plus a per-lane offset
+      const unsigned U0 = (unsigned)(k_lo - k_al) + order;
+      const float2* lanebase = win + tid * (D >> E);
+      unsigned j = 1;
+      for (; j <= order && ((U0 - j + 1u) & (unsigned)(G - 1)) != 0u; j++)
+      { // until a tap sits in the last region: from there on whole rounds over the regions
+        const unsigned u = U0 - j;
+        const float2 s = lanebase[(u & (unsigned)(G - 1)) * H + (u >> E)];
+        const float k = coeff[j];
+        acc.x += s.x * k;
+        acc.y += s.y * k;
+      }
+      // whole rounds: tap j + g sits in region G-1-g at position ((U0 - j) >> E), one lower per round
+      const float* __restrict__ kp = coeff + j;
+      const float2* p = lanebase + ((U0 - j) >> E);
+      const unsigned nrounds = (order + 1u - j) >> E;
+      constexpr int ROUNDS = 8 >> E; // 8 taps per unrolled body, as in the plain loop
+#pragma unroll ROUNDS
+      for (unsigned r = 0; r < nrounds; r++)
+      {
+#pragma unroll
+        for (int g = 0; g < G; g++)
+        {
+          const float2 s = p[(ptrdiff_t)((unsigned)(G - 1 - g) * H) - (ptrdiff_t)r];
+          const float k = kp[r * G + g];
+          acc.x += s.x * k;
+          acc.y += s.y * k;
+        }
+      }
+      j += nrounds << E;
+      for (; j <= order; j++)
+      {
+        const unsigned u = U0 - j;
+        const float2 s = lanebase[(u & (unsigned)(G - 1)) * H + (u >> E)];
+        const float k = coeff[j];
+        acc.x += s.x * k;
+        acc.y += s.y * k;
+      }
     }
     out[(size_t)c * Mstride + m0 + tid] = acc;
   }
