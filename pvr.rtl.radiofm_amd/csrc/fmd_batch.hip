@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -133,7 +134,8 @@ struct fmd_batch
   int write_taps = 0; // stage taps of the RDS recurrences are only written on request
 
   // Internal streams: the FIR of the next call (s_fir), the serial demodulator of this call
-  // (s_ser) and everything behind it (s_post: RDS chain, then audio chain) are independent
+  // (s_ser) and everything behind it (s_post: RDS chain, then audio chain; large batches put the
+  // RDS chain on s_rds, see fmd_batch_create) are independent
   // chains tied together, and to the caller's stream, with events.  Three streams on purpose:
   // HIP multiplexes streams onto a few hardware queues (4 by default) and two chains sharing
   // a queue block each other.  demod, br and mix are double-buffered by call parity so no
@@ -143,7 +145,8 @@ struct fmd_batch
   //   concurrency 2: as 1, but the caller's stream is only ordered after a call by fmd_batch_wait /
   //                  fmd_batch_collect_rds; lets call k+1's FIR overlap call k's serial stages
   int concurrency = 1;
-  hipStream_t s_fir = nullptr, s_ser = nullptr, s_post = nullptr;
+  hipStream_t s_fir = nullptr, s_ser = nullptr, s_post = nullptr, s_rds = nullptr;
+  bool split_post = false;
   enum { EV_IN, EV_FIR, EV_SER, EV_BRFREE, EV_MIXFREE, EV_AUD, EV_RDS, EV_N };
   hipEvent_t cev[NSLOT][EV_N] = {};
   bool cev_ready = false;
@@ -197,6 +200,8 @@ struct fmd_batch
       (void)hipStreamDestroy(s_fir);
       (void)hipStreamDestroy(s_ser);
       (void)hipStreamDestroy(s_post);
+      if (s_rds)
+        (void)hipStreamDestroy(s_rds);
     }
     h_iq.release();
     h_audio.release();
@@ -442,6 +447,16 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     HIPCHK(hipStreamCreateWithPriority(&b->s_fir, hipStreamNonBlocking, hi));
     HIPCHK(hipStreamCreateWithPriority(&b->s_ser, hipStreamNonBlocking, hi));
     HIPCHK(hipStreamCreateWithPriority(&b->s_post, hipStreamNonBlocking, lo));
+    // RDS chain and audio chain behind the serial stage are independent.  With more channels than
+    // the chip holds serial-stage workgroups (256 CUs x 64 channels) the batch is throughput-bound
+    // and they run side by side on two streams (+10 % at 24 576, +12 % at 32 768 channels); below
+    // that the extra concurrent kernels only stretch the latency-bound serial stage (-4 % at
+    // 8192), so they share one stream.  FMD_SPLIT_POST=0/1 overrides.
+    b->split_post = b->CP > 16384;
+    if (const char* e = getenv("FMD_SPLIT_POST"))
+      b->split_post = atoi(e) != 0;
+    if (b->split_post)
+      HIPCHK(hipStreamCreateWithPriority(&b->s_rds, hipStreamNonBlocking, lo));
   }
   for (auto& row : b->cev)
     for (auto& e : row)
@@ -648,7 +663,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   hipStream_t sF = serial_mode ? stream : b->s_fir;
   hipStream_t sS = serial_mode ? stream : b->s_ser;
   hipStream_t sP = serial_mode ? stream : b->s_post;
-  hipStream_t sA = sP, sR = sP;
+  hipStream_t sA = sP, sR = (!serial_mode && b->split_post) ? b->s_rds : sP;
   hipEvent_t* ce = b->cev[es];
   auto after = [&](hipStream_t s, hipEvent_t e) {
     if (!serial_mode)
