@@ -382,7 +382,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->hist[1].alloc(size_t(d.if_order) * C);
   bad |= b->demod[0].alloc(size_t(b->Mstride) * C);
   bad |= b->demod[1].alloc(size_t(b->Mstride) * C);
-  bad |= b->if_coeff.alloc(d.if_coeff.size());
+  bad |= b->if_coeff.alloc(d.if_coeff.size() + 64); // zero padding: fir_long_e1_asm's dummy load
   bad |= b->rs_coeff.alloc(d.rs_coeff.size());
   bad |= b->br[0].alloc(size_t(d.rs_order + b->Mmax) * CP);
   bad |= b->br[1].alloc(size_t(d.rs_order + b->Mmax) * CP);
@@ -518,6 +518,9 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   const unsigned ntiles = (M + TILE - 1) / TILE;
   // 2^E regions of ((TILE-1)*D + order + slack) >> E slots each (see k_if_fir)
   const size_t region = ((size_t(TILE - 1) * D + d.if_order + 2u * (1u << E) + 2u) >> E) + 1u;
+  // long filter in the two-region window: one workgroup per CU, hand-scheduled tap loop
+  // (k_if_fir LONGASM)
+  const bool longasm = TILE == 256 && E == 1 && d.if_order >= 512;
   const size_t lds = (region << E) * sizeof(float2);
   if (lds > 160 * 1024)
     return fail(FMD_ERR_ARG, "IF filter window does not fit in LDS");
@@ -532,6 +535,8 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
         : rounds <= 4 ? &fmd::k_if_fir<IN, TILE, 4, true, E>
         : rounds <= 6 ? &fmd::k_if_fir<IN, TILE, 6, true, E>
                       : &fmd::k_if_fir<IN, TILE, 8, true, E>;
+  if (pow2 && longasm)
+    kfn = &fmd::k_if_fir<IN, TILE, 8, true, E, TILE == 256 && E == 1>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

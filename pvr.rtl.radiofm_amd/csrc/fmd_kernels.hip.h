@@ -106,6 +106,151 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+/* Hand-scheduled tap loop for long filters in the two-region window (E = 1), where one wave per
+ * SIMD has to hide every LDS / scalar-cache round trip itself: batches of 16 taps in two register
+ * sets, the 8 + 8 sample reads and the 16-tap scalar load of the next batch issued before the
+ * arithmetic of the current one, one full wait per batch that only finds completed operations.
+ * Products run two ahead of the sum; the sum itself stays one chain in tap order.  acc2 is the
+ * running (re, im) sum; a1 / a0 are the LDS byte addresses of the lowest of the 8 positions of the
+ * current batch in region 1 / region 0 (region 1 holds the first tap of every pair); klo / khi is
+ * the address of the batch's first tap; cnt counts pairs of batches (32 taps each, >= 1).  The last
+ * batch load is a dummy: it reads 16 taps past the table (the buffer is padded) and 8 positions
+ * below the window (LDS reads outside the allocation return zero).  Measured (4096 taps, D = 46):
+ * 3.5 ms per launch against 5.8 ms for the compiler-scheduled loop; the LDS array delivers
+ * ~110 B/clk/CU here, i.e. the loop is LDS-bandwidth-bound (a variant with the tap table in LDS
+ * too: 4.1 ms).  Body generated by tools/gen_fir_long_asm.py. */
+typedef float fmd_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fir_long_e1_asm(fmd_f2v& acc2, unsigned& a1, unsigned& a0, unsigned klo,
+                                                unsigned khi, unsigned& cnt)
+{
+  asm volatile(
+      "s_mov_b32 s72, %4\n\t"
+      "s_mov_b32 s73, %5\n\t"
+      "s_load_dwordx16 s[40:55], s[72:73], 0x0\n\t"
+      "ds_read2_b64 v[64:67], %1 offset0:7 offset1:6\n\t"
+      "ds_read2_b64 v[68:71], %1 offset0:5 offset1:4\n\t"
+      "ds_read2_b64 v[72:75], %1 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[76:79], %1 offset0:1\n\t"
+      "ds_read2_b64 v[80:83], %2 offset0:7 offset1:6\n\t"
+      "ds_read2_b64 v[84:87], %2 offset0:5 offset1:4\n\t"
+      "ds_read2_b64 v[88:91], %2 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[92:95], %2 offset0:1\n\t"
+      "v_subrev_u32 %1, 64, %1\n\t"
+      "v_subrev_u32 %2, 64, %2\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "1:\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[56:71], s[72:73], 0x0\n\t"
+      "ds_read2_b64 v[96:99], %1 offset0:7 offset1:6\n\t"
+      "ds_read2_b64 v[100:103], %1 offset0:5 offset1:4\n\t"
+      "ds_read2_b64 v[104:107], %1 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[108:111], %1 offset0:1\n\t"
+      "ds_read2_b64 v[112:115], %2 offset0:7 offset1:6\n\t"
+      "ds_read2_b64 v[116:119], %2 offset0:5 offset1:4\n\t"
+      "ds_read2_b64 v[120:123], %2 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[124:127], %2 offset0:1\n\t"
+      "v_subrev_u32 %1, 64, %1\n\t"
+      "v_subrev_u32 %2, 64, %2\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "v_pk_mul_f32 v[128:129], v[64:65], s[40:41] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 v[130:131], v[80:81], s[40:41] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[66:67], s[42:43] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[82:83], s[42:43] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[68:69], s[44:45] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[84:85], s[44:45] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[70:71], s[46:47] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[86:87], s[46:47] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[72:73], s[48:49] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[88:89], s[48:49] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[74:75], s[50:51] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[90:91], s[50:51] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[76:77], s[52:53] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[92:93], s[52:53] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[78:79], s[54:55] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[94:95], s[54:55] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[40:55], s[72:73], 0x0\n\t"
+      "ds_read2_b64 v[64:67], %1 offset0:7 offset1:6\n\t"
+      "ds_read2_b64 v[68:71], %1 offset0:5 offset1:4\n\t"
+      "ds_read2_b64 v[72:75], %1 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[76:79], %1 offset0:1\n\t"
+      "ds_read2_b64 v[80:83], %2 offset0:7 offset1:6\n\t"
+      "ds_read2_b64 v[84:87], %2 offset0:5 offset1:4\n\t"
+      "ds_read2_b64 v[88:91], %2 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[92:95], %2 offset0:1\n\t"
+      "v_subrev_u32 %1, 64, %1\n\t"
+      "v_subrev_u32 %2, 64, %2\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "v_pk_mul_f32 v[128:129], v[96:97], s[56:57] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 v[130:131], v[112:113], s[56:57] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[98:99], s[58:59] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[114:115], s[58:59] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[100:101], s[60:61] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[116:117], s[60:61] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[102:103], s[62:63] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[118:119], s[62:63] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[104:105], s[64:65] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[120:121], s[64:65] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[106:107], s[66:67] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[122:123], s[66:67] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[108:109], s[68:69] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[124:125], s[68:69] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[110:111], s[70:71] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[126:127], s[70:71] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "s_sub_u32 %3, %3, 1\n\t"
+      "s_cmp_lg_u32 %3, 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      : "+v"(acc2), "+v"(a1), "+v"(a0), "+s"(cnt)
+      : "s"(klo), "s"(khi)
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76",
+        "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89",
+        "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101",
+        "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
+        "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+        "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134",
+        "v135", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+        "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",
+        "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "scc", "memory");
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* K1: cFineTuner (FmDecode.cpp:66-82) fused into cDownsampleFilter::Process(complex)           */
 /*     (DownConvert.cpp:98-154), optionally with the RTL-SDR byte -> float conversion           */
@@ -164,7 +309,7 @@ struct InU8
  * i >> E.  All lanes read the same region at a given tap (their offsets lane*D are multiples of
  * 2^E), and inside a region the lane stride is D >> E, which is odd: conflict-free.  Consecutive
  * taps walk the regions round robin, each region contiguously.  E = 0 is the plain window. */
-template <class IN, int TILE, int UNROLL, bool POW2, int E = 0>
+template <class IN, int TILE, int UNROLL, bool POW2, int E = 0, bool LONGASM = false>
 __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __restrict__ iq,
                                                  size_t chan_stride, unsigned N,
                                                  const float2* __restrict__ hist_in,
@@ -294,6 +439,21 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
         const float k = coeff[j];
         acc.x += s.x * k;
         acc.y += s.y * k;
+      }
+      if (LONGASM && E == 1 && order + 1u - j >= 32u)
+      { // see fir_long_e1_asm; whatever is left after whole pairs of batches continues below
+        unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)((order + 1u - j) >> 5));
+        const unsigned taps = cnt << 5;
+        const float2* p1 = lanebase + H + ((U0 - j) >> 1) - 7; // lowest of the batch's 8 positions
+        unsigned a1 = (unsigned)(size_t)p1, a0 = (unsigned)(size_t)(p1 - H);
+        const size_t ka = (size_t)(coeff + j);
+        const unsigned klo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ka);
+        const unsigned khi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ka >> 32));
+        fmd_f2v acc2 = {acc.x, acc.y};
+        fir_long_e1_asm(acc2, a1, a0, klo, khi, cnt);
+        acc.x = acc2.x;
+        acc.y = acc2.y;
+        j += taps;
       }
       // whole rounds: tap j + g sits in region G-1-g at position ((U0 - j) >> E), one lower per round
       const float* __restrict__ kp = coeff + j;

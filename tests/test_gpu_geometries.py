@@ -98,3 +98,35 @@ def test_call_size_limits(fmsig):
         pkg.FmDecoder(400e3, 0.0, 48000.0, 15000.0, 1)  # baseband 400 kHz needs the 11-tap half-band
     with pytest.raises(pkg.FmdError):
         pkg.Batch(pkg.make_params(0.0, 0.0), 1)
+
+
+@pytest.mark.parametrize("fs,D,order,n", [(1.4e6, 6, 1000, 65536), (1.4e6, 6, 520, 33333),
+                                         (2.2e6, 10, 2047, 65536), (10e6, 46, 4096, 40000),
+                                         (1.0e6, 4, 600, 65536), (2.4e6, 11, 1000, 65536)])
+def test_long_filters_and_even_decimation(oracle, fmsig, fs, D, order, n):
+    """Long IF filters through every window layout of k_if_fir: D = 2*odd (two-region window, the
+    hand-scheduled tap loop with its head / tail taps around whole 32-tap pairs of batches, first
+    tile out of the history, partial last tile), D = 4*odd (four regions) and odd D (plain).
+    Float and byte input; FIR output and audio bit for bit."""
+    pkg = load_package()
+    p = fmsig.default_params(fs, noise_sigma=0.01, seed=31)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D, if_filter_order=order)
+    o8 = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D, if_filter_order=order)
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D, if_filter_order=order), 3)
+    b8 = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D, if_filter_order=order), 1)
+    b.enable_taps()
+    b8.enable_taps()
+    for blk in range(3):
+        u8 = fmsig.generate_u8(p, blk * n, n)
+        iq = oracle.convert_u8(u8)
+        ref = o.process_stream(iq)
+        a = b.process_host(np.stack([iq, iq, iq]).view(np.complex64))
+        for c in (0, 2):
+            assert _bits_equal(b.tap("demod", c).view(np.float32), o.taps()["demod"].view(np.float32)), (blk, c)
+            assert _bits_equal(a[c], ref), (blk, c)
+        ref8 = o8.process_stream_u8(u8)
+        a8 = b8.process_host_u8(u8, shared=True)
+        assert _bits_equal(b8.tap("demod").view(np.float32), o8.taps()["demod"].view(np.float32)), blk
+        assert _bits_equal(a8[0], ref8), blk
+    b.close()
+    b8.close()
