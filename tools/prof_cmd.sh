@@ -9,6 +9,11 @@ mkdir -p gpurun_out
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -1 gpurun_out/${TAG}_bench.json
 python bench.py --concurrency 0 --stage-profile --no-cpu-baseline > gpurun_out/${TAG}_bench_serialised.json 2>/dev/null
+# the other BASELINE configurations and the byte-input workload (parity-test cases, not the bench line)
+python bench.py --workload config5 --no-cpu-baseline --stage-profile > gpurun_out/${TAG}_bench_config5.json 2>/dev/null
+python bench.py --workload config3 --no-cpu-baseline --stage-profile > gpurun_out/${TAG}_bench_config3.json 2>/dev/null
+python bench.py --input u8 --no-cpu-baseline --stage-profile > gpurun_out/${TAG}_bench_u8.json 2>/dev/null
+python bench.py --channels 32768 --ring 4 --no-cpu-baseline > gpurun_out/${TAG}_bench_32768ch.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -- python bench.py --no-cpu-baseline > gpurun_out/${TAG}_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats_ser -- python bench.py --no-cpu-baseline --concurrency 0 > gpurun_out/${TAG}_stats_ser.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-include-regex "k_if_fir" --output-format csv -d gpurun_out/${TAG}_pmc1 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --concurrency 0 > gpurun_out/${TAG}_pmc1.log 2>&1
