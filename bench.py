@@ -188,6 +188,8 @@ def main():
         g_rds = [[torch.empty_like(rds_dev[0]) for _ in range(world)] for _ in range(NBUF)]
     stream = torch.cuda.current_stream().cuda_stream
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    if world > 1:
+        dg.gather_preflight(dev if backend == "nccl" else "cpu")
     pending = [None] * NBUF
     total_groups = 0
 

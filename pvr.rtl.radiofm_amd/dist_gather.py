@@ -45,3 +45,22 @@ def gather_step(audio, rds_rec, gather_audio=None, gather_rds=None, dst=0, async
     w1 = dist.gather(audio, gather_audio if rank == dst else None, dst=dst, async_op=async_op)
     w2 = dist.gather(rds_rec, gather_rds if rank == dst else None, dst=dst, async_op=async_op)
     return (w1, w2) if async_op else None
+
+
+def gather_preflight(device):
+    """One tiny gather to rank 0 and a check of what arrived, before any buffer is sized for the
+    real thing: raises on every rank if the backend cannot gather (so a launch fails at once and
+    with a message instead of inside the timed region)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    x = torch.full((8,), float(rank + 1), dtype=torch.float32, device=device)
+    out = [torch.zeros_like(x) for _ in range(world)] if rank == 0 else None
+    dist.gather(x, out, dst=0)
+    ok = torch.ones(1, dtype=torch.float32, device=device)
+    if rank == 0:
+        good = all(bool((out[r] == float(r + 1)).all()) for r in range(world))
+        ok.fill_(1.0 if good else 0.0)
+    dist.broadcast(ok, src=0)
+    if float(ok.item()) != 1.0:
+        raise RuntimeError("gather pre-flight: rank 0 did not receive every rank's tensor")

@@ -36,6 +36,7 @@ WORKER = textwrap.dedent("""
     dg = importlib.import_module(pkg.__name__ + ".dist_gather")
     dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=2)
     rank = dist.get_rank()
+    dg.gather_preflight("cpu")
     C, stride, cap = 6, 16, 8
     audio = torch.arange(C * stride, dtype=torch.float32).reshape(C, stride) + 1000.0 * rank
     g = np.zeros(2 + rank, dtype=pkg.RDS_GROUP_DTYPE)
