@@ -86,3 +86,52 @@ def test_cpp_class_drop_in_without_torch(tmp_path, oracle, fmsig):
     stuffed = b"".join(pkg.stuff_uecp_frame(f) for f in o.uecp_frames())
     assert u_path.read_bytes() == stuffed and len(stuffed) > 0
     assert "stereo=1" in out.stdout and "name=TESTFM01" in out.stdout
+
+
+def test_config4_full_shard_properties(oracle, fmsig):
+    """BASELINE configs[3] at its full per-GPU size: 8192 channels x 65536 IQ per call, device-
+    generated input, calls overlapped exactly like bench.py (concurrency 2, outputs consumed two
+    calls late).  Too big to run every channel through the oracle, so: (1) 8 channels incl. the
+    first and the last are checked against the oracle bit for bit on the very bytes the device
+    generator produced; (2) size-independent property over the whole batch: channels c and
+    c + 4096 are given the same station, so their audio and RDS groups must be identical."""
+    import torch
+    pkg = load_package()
+    fs, D, C, nblk, LAG = 2.4e6, 11, 8192, 8, 2
+    chans = [fmsig.channel_params(fs, c % 4096) for c in range(C)]
+    gen = fmsig.DeviceGenerator(chans, "cuda")
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
+    b.set_concurrency(2)
+    a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
+    iq = [torch.empty((C, N, 2), dtype=torch.float32, device="cuda") for _ in range(nblk)]
+    audio = [torch.zeros((C, a_stride), dtype=torch.float32, device="cuda") for _ in range(nblk)]
+    for k in range(nblk):
+        gen.generate(iq[k], k * N, N)
+    st = torch.cuda.current_stream().cuda_stream
+    nf, groups = [], []
+    for k in range(nblk):
+        nf.append(b.process_device(iq[k].data_ptr(), N, N, audio[k].data_ptr(), a_stride, st))
+        if k >= LAG:
+            b.wait(stream=st, lag=LAG)
+            groups.append(b.collect_rds_array(cap=4 * C, stream=st, lag=LAG))
+    b.wait(stream=st)
+    groups.append(b.collect_rds_array(cap=4 * C, stream=st))
+    torch.cuda.synchronize()
+    check = [0, 1, 63, 64, 4095, 4096, 8190, 8191]
+    refs = {c: oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for c in check}
+    for k in range(nblk):
+        a = audio[k][:, :nf[k]].cpu().numpy()
+        for c in check:
+            r = refs[c].process_stream(iq[k][c].cpu().numpy().reshape(-1))
+            assert _bits_equal(a[c], r), (k, c)
+        assert np.array_equal(a[:4096].view(np.uint32), a[4096:].view(np.uint32)), k
+    g = np.concatenate(groups)
+    lo, hi = g[g["channel"] < 4096], g[g["channel"] >= 4096]
+    key = lambda x, off: sorted((int(c) - off, int(k), tuple(int(v) for v in bl))
+                                for c, k, bl in zip(x["channel"], x["call_index"], x["blocks"]))
+    assert key(lo, 0) == key(hi, 4096)
+    for c in check:
+        mine = sorted((int(k), tuple(int(v) for v in bl)) for ch, k, bl in
+                      zip(g["channel"], g["call_index"], g["blocks"]) if ch == c)
+        assert mine == sorted((k, tuple(bl)) for k, bl in refs[c].rds_groups()), c
+    b.close()
