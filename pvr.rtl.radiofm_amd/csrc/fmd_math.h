@@ -299,7 +299,8 @@ FMD_HD void fmd_sincos_nco(float phase, float* s, float* c)
 
 /* Compact form of the same fdlibm atan2f for the per-sample PLL loop (no data-dependent branch
  * except the rare-input test).  Per reduced range r (index 0 = no reduction, 1..4 = fdlibm id
- * 0..3) the table holds a, b, c, d, hi, lo with
+ * 0..3) the table holds a, b, c, d, hi, lo (the function takes hi and lo from it; a..d document
+ * the rows, the function derives them from two packed constants, see there) with
  *   reduced argument = (a*q + b) / (c*q + d)        and   result = hi - ((p - lo) - xr)
  * which reproduces every fdlibm operation: a*q and c*q are exact or the reference's own products
  * (1*q, 2*q, 1.5*q, 0*q), adding b / d is the reference's add / subtract, and hi = lo = 0 turns
