@@ -346,7 +346,7 @@ def main():
                 out["roofline"]["traffic_source"] = t["source"]
         if stage_all:
             out["stage_ms"] = {k: round(v, 4) for k, v in stage_all.items()}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
