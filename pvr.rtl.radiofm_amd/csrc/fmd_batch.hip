@@ -147,6 +147,7 @@ struct fmd_batch
   int concurrency = 1;
   hipStream_t s_fir = nullptr, s_ser = nullptr, s_post = nullptr, s_rds = nullptr;
   bool split_post = false;
+  bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
   enum { EV_IN, EV_FIR, EV_SER, EV_BRFREE, EV_MIXFREE, EV_AUD, EV_RDS, EV_N };
   hipEvent_t cev[NSLOT][EV_N] = {};
   bool cev_ready = false;
@@ -453,6 +454,12 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     // that the extra concurrent kernels only stretch the latency-bound serial stage (-4 % at
     // 8192), so they share one stream.  FMD_SPLIT_POST=0/1 overrides.
     b->split_post = b->CP > 16384;
+    // The serial stage owns whole CUs while that costs at most a quarter of the chip (<= 8192
+    // channels = 64 CUs; +4.4 % at 8192 channels) and the batch is big enough for the bandwidth
+    // kernels to notice their neighbours at all.  FMD_SERIAL_EXCLUSIVE=0/1 overrides.
+    b->serial_exclusive = b->CP <= 8192 && b->CP >= 1024;
+    if (const char* e = getenv("FMD_SERIAL_EXCLUSIVE"))
+      b->serial_exclusive = atoi(e) != 0;
     if (const char* e = getenv("FMD_SPLIT_POST"))
       b->split_post = atoi(e) != 0;
     if (b->split_post)
@@ -746,10 +753,20 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     k.p_lock_delay = d.p_lock_delay;
     k.osc_cos = d.rds_osc_cos;
     k.osc_sin = d.rds_osc_sin;
-    hipLaunchKernelGGL(fmd::k_demod_serial, dim3(CP / 64), dim3(128), 0, sS, b->demod[q].p,
-                       b->Mstride, M, C, CP, k, b->st, b->br[q].p, Hbb, b->mix[q].p,
-                       unsigned(d.hb[0].len - 1), b->sctab.p,
-                       FmdSincosTab{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo});
+    // Up to 8192 channels the batch is latency-bound by this stage and needs at most 64 CUs for
+    // it: two channel groups per workgroup, each workgroup owning its CU (k_demod_serial, EXCL).
+    // Larger batches need the CUs for throughput and keep the shared form.
+    const unsigned groups = CP / 64;
+    const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
+    const unsigned Hmix = unsigned(d.hb[0].len - 1);
+    if (b->serial_exclusive && !serial_mode)
+      hipLaunchKernelGGL((fmd::k_demod_serial<2, true>), dim3((groups + 1) / 2), dim3(256), 0, sS,
+                         b->demod[q].p, b->Mstride, M, C, CP, k, b->st, b->br[q].p, Hbb, b->mix[q].p,
+                         Hmix, b->sctab.p, sct);
+    else
+      hipLaunchKernelGGL((fmd::k_demod_serial<1, false>), dim3(groups), dim3(128), 0, sS, b->demod[q].p,
+                         b->Mstride, M, C, CP, k, b->st, b->br[q].p, Hbb, b->mix[q].p, Hmix,
+                         b->sctab.p, sct);
   }
   signal(ce[fmd_batch::EV_SER], sS);
   mark(2);

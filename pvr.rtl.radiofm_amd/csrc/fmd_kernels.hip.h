@@ -540,26 +540,43 @@ __global__ __launch_bounds__(64) void k_if_level(const typename IN::elem* __rest
 /*     Chunks of DS samples are double-buffered in LDS, one barrier per chunk.  A lone wave     */
 /*     issues one VALU op every ~4 cycles, so the longest role sets the time per sample.       */
 /* ------------------------------------------------------------------------------------------ */
+
+/* NG = channel groups (of 64) per workgroup, one pair of role waves each.  EXCL: every wave claims
+ * the whole register file of its SIMD (512 = 256 arch + 256 acc VGPRs), so with NG = 2 a workgroup
+ * owns its CU: no bandwidth kernel's wave shares a SIMD with a role wave (such a wave delays each
+ * of the recurrence's dependent instructions by up to one 4-cycle issue), and the CUs left to the
+ * bandwidth kernels are whole ones.  Only sensible while the batch needs few workgroups (see the
+ * launch). */
+/* Measured and dropped: four groups per workgroup with the two role waves of a group on ONE
+ * SIMD (half the register file each, 32 CUs owned): the waves do not fit into each other's issue
+ * gaps, the stage takes 3.5 ms (151 GS/s). */
 constexpr int DS = 32; // samples per LDS chunk
 
-__global__ __launch_bounds__(128) void k_demod_serial(
+template <int NG, bool EXCL>
+__global__ __launch_bounds__(128 * NG) void k_demod_serial(
     const float2* __restrict__ demod, unsigned Mstride, unsigned M, unsigned C, unsigned CP,
     DemodConsts k, ChannelState st, float2* __restrict__ br, unsigned Hbb,
     float2* __restrict__ mix, unsigned Hmix, const double* __restrict__ sctab_g, FmdSincosTab sct)
 {
-  __shared__ float chunk[2][DS][64];   // baseband, FM role -> pilot/RDS role
-  __shared__ float2 stage[2][DS][64];  // IF-FIR output, pilot/RDS role -> FM role
+  __shared__ float chunk_all[NG][2][DS][64];  // baseband, FM role -> pilot/RDS role
+  __shared__ float2 stage_all[NG][2][DS][64]; // IF-FIR output, pilot/RDS role -> FM role
   __shared__ double sctab[2 * FMD_SINCOS_TAB_SIZE];
   __shared__ float atab[FMD_ATAN_TAB_FLOATS];
   // latency-bound recurrence: when bandwidth kernels of other calls share the SIMD, issue first
   __builtin_amdgcn_s_setprio(3);
-  for (unsigned i = threadIdx.x; i < 2 * FMD_SINCOS_TAB_SIZE; i += 128)
+  if (EXCL)
+    asm volatile("" ::: "v255", "a255");
+  for (unsigned i = threadIdx.x; i < 2 * FMD_SINCOS_TAB_SIZE; i += 128 * NG)
     sctab[i] = sctab_g[i];
   if (threadIdx.x == 0)
     fmd_atan_table_fill(atab);
   const unsigned lane = threadIdx.x & 63u;
-  const unsigned role = threadIdx.x >> 6;
-  const unsigned c0 = blockIdx.x * 64 + lane;
+  const unsigned wave = threadIdx.x >> 6;
+  const unsigned role = wave & 1u;
+  const unsigned grp = wave >> 1;
+  float (*chunk)[DS][64] = chunk_all[grp];
+  float2 (*stage)[DS][64] = stage_all[grp];
+  const unsigned c0 = (blockIdx.x * NG + grp) * 64 + lane;
   const bool active = c0 < C;
   const unsigned c = active ? c0 : C - 1; // padded lanes shadow the last channel, stores masked
   const unsigned nchunks = (M + DS - 1) / DS;
