@@ -106,7 +106,7 @@ struct fmd_batch
   unsigned lastM = 0, lastA = 0, lastR = 0;
 
   // device memory
-  DevBuf<float2> lut, hist[2], demod[2], br[2], mix[2], rdsraw, rlpf, rs, alp;
+  DevBuf<float2> lut, hist[2], demod[2], br[2], mix[2], rdsraw, rlpf[2], rs, alp[2];
   std::vector<DevBuf<float2>> hbbuf; // input buffers of stages 1..n-1 (stage 0 reads mix)
   DevBuf<float> if_coeff, rs_coeff, rds_lpf_taps, mf_taps2, audio_taps, ktab;
   DevBuf<float> rpll, rmf, tap_sync;
@@ -148,7 +148,7 @@ struct fmd_batch
   hipStream_t s_fir = nullptr, s_ser = nullptr, s_post = nullptr, s_rds = nullptr;
   bool split_post = false;
   bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
-  enum { EV_IN, EV_FIR, EV_SER, EV_BRFREE, EV_MIXFREE, EV_AUD, EV_RDS, EV_N };
+  enum { EV_IN, EV_FIR, EV_SER, EV_BRFREE, EV_MIXFREE, EV_AUD, EV_RDS, EV_HEAVY, EV_N };
   hipEvent_t cev[NSLOT][EV_N] = {};
   bool cev_ready = false;
   uint32_t slot_call[NSLOT] = {0, 0, 0, 0}; // call index that last used the slot (0 = never)
@@ -167,9 +167,11 @@ struct fmd_batch
     mix[0].release();
     mix[1].release();
     rdsraw.release();
-    rlpf.release();
+    rlpf[0].release();
+    rlpf[1].release();
     rs.release();
-    alp.release();
+    alp[0].release();
+    alp[1].release();
     for (auto& b : hbbuf)
       b.release();
     if_coeff.release();
@@ -395,12 +397,14 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   for (size_t s = 1; s < d.hb.size(); s++)
     bad |= b->hbbuf[s - 1].alloc(size_t(d.hb[s].len - 1 + b->hb_nmax[s]) * CP);
   bad |= b->rdsraw.alloc(size_t(T_lpf - 1 + b->Rmax) * CP);
-  bad |= b->rlpf.alloc(size_t(b->Rmax) * CP);
+  bad |= b->rlpf[0].alloc(size_t(b->Rmax) * CP);
+  bad |= b->rlpf[1].alloc(size_t(b->Rmax) * CP);
   bad |= b->rpll.alloc(size_t(T_mf - 1 + b->Rmax) * CP);
   bad |= b->rmf.alloc(size_t(b->Rmax) * CP);
   bad |= b->tap_sync.alloc(size_t(b->Rmax) * CP);
   bad |= b->rs.alloc(size_t(T_alp - 1 + b->Amax) * CP);
-  bad |= b->alp.alloc(size_t(b->Amax) * CP);
+  bad |= b->alp[0].alloc(size_t(b->Amax) * CP);
+  bad |= b->alp[1].alloc(size_t(b->Amax) * CP);
   bad |= b->rds_lpf_taps.alloc(T_lpf);
   bad |= b->mf_taps2.alloc(size_t(2) * T_mf);
   bad |= b->audio_taps.alloc(T_alp);
@@ -462,8 +466,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
       b->serial_exclusive = atoi(e) != 0;
     if (const char* e = getenv("FMD_SPLIT_POST"))
       b->split_post = atoi(e) != 0;
-    if (b->split_post)
-      HIPCHK(hipStreamCreateWithPriority(&b->s_rds, hipStreamNonBlocking, lo));
+    HIPCHK(hipStreamCreateWithPriority(&b->s_rds, hipStreamNonBlocking, lo));
   }
   for (auto& row : b->cev)
     for (auto& e : row)
@@ -676,6 +679,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   hipStream_t sS = serial_mode ? stream : b->s_ser;
   hipStream_t sP = serial_mode ? stream : b->s_post;
   hipStream_t sA = sP, sR = (!serial_mode && b->split_post) ? b->s_rds : sP;
+  // one-stream form: the light parts of the post chain go to their own stream (see below)
+  hipStream_t sL = serial_mode ? stream : b->s_rds;
   hipEvent_t* ce = b->cev[es];
   auto after = [&](hipStream_t s, hipEvent_t e) {
     if (!serial_mode)
@@ -712,11 +717,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   if (have_prev2)
   {
     after(sF, pe2[fmd_batch::EV_SER]); // demod[q] was last read by the serial stage two calls ago
-    // Also run behind the post chain of two calls ago.  During one serial stage (the pipeline's
-    // period) the chip has to fit one FIR and one post chain; back to back they each only share
-    // it with the light serial kernel, side by side both ran ~25 % slower (measured).
-    after(sF, pe2[fmd_batch::EV_AUD]);
-    after(sF, pe2[fmd_batch::EV_RDS]);
+    // Also run behind the bandwidth-heavy part of the post chain of two calls ago (half-bands, RDS
+    // low-pass, resamplers, audio low-pass): side by side with those the FIR and they were both
+    // ~25 % slower.  The rest of that chain (RDS PLL, matched filter, bit recovery, audio tail) is
+    // lane-per-channel work that leaves most CUs idle: the FIR runs beside it.
+    after(sF, pe2[fmd_batch::EV_HEAVY]);
   }
   {
     const std::function<void(int)> markfn = mark;
@@ -774,92 +779,132 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   const dim3 rt(256);
   auto rgrid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
 
-  /* ---- RDS branch  (stream R): half-bands, 75-tap LPF, PLL, matched filter, bits ---- */
-  after(sR, ce[fmd_batch::EV_SER]);
-  {
-    const float2* in = b->mix[q].p;
-    for (size_t s = 0; s < d.hb.size(); s++)
+  /* The post chain in four pieces.  "Heavy" = bandwidth / LDS bound and filling the chip; "light" =
+   * lane-per-channel recurrences on CP/64 workgroups. */
+  auto rds_heavy = [&]() {
+    /* ---- RDS branch  (stream R): half-bands, 75-tap LPF, PLL, matched filter, bits ---- */
+    after(sR, ce[fmd_batch::EV_SER]);
     {
-      const unsigned n_out = (hb_in[s] + 1) / 2;
-      const bool last = (s + 1 == d.hb.size());
-      float2* outp = last ? b->rdsraw.p : b->hbbuf[s].p;
-      const unsigned Hout = last ? (T_lpf - 1) : unsigned(d.hb[s + 1].len - 1);
-      hipLaunchKernelGGL(fmd::k_halfband, dim3(CP / 64, (n_out + 4 * fmd::HB_R - 1) / (4 * fmd::HB_R)),
-                         dim3(64, 4), 0, sR, in, outp, n_out, d.hb[s].len, b->hbcoef[s], C, CP, Hout);
-      // keep the last L-1 input rows of this stage for the next call, then its input is free
-      const unsigned Hs = unsigned(d.hb[s].len - 1);
-      if (s == 0)
-      { // tail of mix[q] -> history rows of mix[q^1], which the next call's half-band reads
-        hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->mix[q].p, b->mix[q ^ 1].p, Hs,
-                           hb_in[0], CP);
-        signal(ce[fmd_batch::EV_MIXFREE], sR);
+      const float2* in = b->mix[q].p;
+      for (size_t s = 0; s < d.hb.size(); s++)
+      {
+        const unsigned n_out = (hb_in[s] + 1) / 2;
+        const bool last = (s + 1 == d.hb.size());
+        float2* outp = last ? b->rdsraw.p : b->hbbuf[s].p;
+        const unsigned Hout = last ? (T_lpf - 1) : unsigned(d.hb[s + 1].len - 1);
+        hipLaunchKernelGGL(fmd::k_halfband, dim3(CP / 64, (n_out + 4 * fmd::HB_R - 1) / (4 * fmd::HB_R)),
+                           dim3(64, 4), 0, sR, in, outp, n_out, d.hb[s].len, b->hbcoef[s], C, CP, Hout);
+        // keep the last L-1 input rows of this stage for the next call, then its input is free
+        const unsigned Hs = unsigned(d.hb[s].len - 1);
+        if (s == 0)
+        { // tail of mix[q] -> history rows of mix[q^1], which the next call's half-band reads
+          hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->mix[q].p, b->mix[q ^ 1].p, Hs,
+                             hb_in[0], CP);
+          signal(ce[fmd_batch::EV_MIXFREE], sR);
+        }
+        else
+          hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->hbbuf[s - 1].p,
+                             b->hbbuf[s - 1].p, Hs, hb_in[s], CP);
+        in = outp;
       }
-      else
-        hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->hbbuf[s - 1].p,
-                           b->hbbuf[s - 1].p, Hs, hb_in[s], CP);
-      in = outp;
     }
-  }
-  mark(3);
-  hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
-                     size_t(T_lpf - 1 + fmd::RF_TI) * 64 * sizeof(float2), sR, b->rdsraw.p,
-                     b->rlpf.p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C, CP, 0u);
-  hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, sR, b->rdsraw.p, b->rdsraw.p, T_lpf - 1, R, CP);
-  mark(4);
-  {
-    fmd::RdsConsts k{};
-    k.pll_alpha = d.rds_pll_alpha;
-    k.pll_beta = d.rds_pll_beta;
-    k.nco_hl = d.rds_nco_hl;
-    k.nco_ll = d.rds_nco_ll;
-    k.bs_b0 = d.bitsync.b0;
-    k.bs_b1 = d.bitsync.b1;
-    k.bs_b2 = d.bitsync.b2;
-    k.bs_a1 = d.bitsync.a1;
-    k.bs_a2 = d.bitsync.a2;
-    k.mf_taps = int(T_mf);
-    const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
-    hipLaunchKernelGGL(fmd::k_rds_pll, dim3(CP / 64), dim3(64), 0, sR, b->rlpf.p, R, C, CP, k,
-                       b->st, b->rpll.p, T_mf - 1, b->sctab.p, sct);
-    hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI),
-                       dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), sR,
-                       b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C, CP, 0u);
-    hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, sR, b->rpll.p, b->rpll.p, T_mf - 1, R, CP);
-    hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, sR, b->rmf.p, R, C, CP, k,
-                       b->st, b->call_index, b->queue[es].p, b->queue_count[es].p, b->queue_cap,
-                       b->tap_sync.p, b->write_taps);
-  }
-  signal(ce[fmd_batch::EV_RDS], sR);
-  mark(5);
+    mark(3);
+    hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
+                       size_t(T_lpf - 1 + fmd::RF_TI) * 64 * sizeof(float2), sR, b->rdsraw.p,
+                       b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C, CP, 0u);
+    hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, sR, b->rdsraw.p, b->rdsraw.p, T_lpf - 1, R, CP);
+    mark(4);
+  };
+  auto rds_light = [&]() {
+    {
+      fmd::RdsConsts k{};
+      k.pll_alpha = d.rds_pll_alpha;
+      k.pll_beta = d.rds_pll_beta;
+      k.nco_hl = d.rds_nco_hl;
+      k.nco_ll = d.rds_nco_ll;
+      k.bs_b0 = d.bitsync.b0;
+      k.bs_b1 = d.bitsync.b1;
+      k.bs_b2 = d.bitsync.b2;
+      k.bs_a1 = d.bitsync.a1;
+      k.bs_a2 = d.bitsync.a2;
+      k.mf_taps = int(T_mf);
+      const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
+      hipLaunchKernelGGL(fmd::k_rds_pll, dim3(CP / 64), dim3(64), 0, sR, b->rlpf[q].p, R, C, CP, k,
+                         b->st, b->rpll.p, T_mf - 1, b->sctab.p, sct);
+      hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI),
+                         dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), sR,
+                         b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C, CP, 0u);
+      hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, sR, b->rpll.p, b->rpll.p, T_mf - 1, R, CP);
+      hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, sR, b->rmf.p, R, C, CP, k,
+                         b->st, b->call_index, b->queue[es].p, b->queue_count[es].p, b->queue_cap,
+                         b->tap_sync.p, b->write_taps);
+    }
+  };
+  auto audio_heavy = [&]() {
 
-  /* ---- audio branch  (stream A): resamplers, 15 kHz LPF, de-emphasis / notch / matrix ---- */
-  after(sA, ce[fmd_batch::EV_SER]);
-  hipLaunchKernelGGL(fmd::k_rs_table, dim3(A), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p,
-                     pstep, A, b->ktab.p, b->pidx.p);
-  hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
-                     dim3(64, 4), 0, sA, b->br[q].p, Hbb, d.rs_order, b->ktab.p, b->pidx.p, A,
-                     b->rs.p, T_alp - 1, C, CP);
-  hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hbb), rt, 0, sA, b->br[q].p, b->br[q ^ 1].p, Hbb, M, CP);
-  signal(ce[fmd_batch::EV_BRFREE], sA);
-  mark(6);
-  hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (A + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
-                     size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), sA, b->rs.p, b->alp.p, A,
-                     int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
-  hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_alp - 1), rt, 0, sA, b->rs.p, b->rs.p, T_alp - 1, A, CP);
-  mark(7);
-  {
-    fmd::AudioConsts k{};
-    k.de_alpha = d.de_alpha;
-    k.n_b0 = d.notch.b0;
-    k.n_b1 = d.notch.b1;
-    k.n_b2 = d.notch.b2;
-    k.n_a1 = d.notch.a1;
-    k.n_a2 = d.notch.a2;
-    hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, sA, b->alp.p, A, C, CP, k,
-                       b->st, d_audio, audio_channel_stride);
+    /* ---- audio branch  (stream A): resamplers, 15 kHz LPF, de-emphasis / notch / matrix ---- */
+    after(sA, ce[fmd_batch::EV_SER]);
+    hipLaunchKernelGGL(fmd::k_rs_table, dim3(A), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p,
+                       pstep, A, b->ktab.p, b->pidx.p);
+    hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
+                       dim3(64, 4), 0, sA, b->br[q].p, Hbb, d.rs_order, b->ktab.p, b->pidx.p, A,
+                       b->rs.p, T_alp - 1, C, CP);
+    hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hbb), rt, 0, sA, b->br[q].p, b->br[q ^ 1].p, Hbb, M, CP);
+    signal(ce[fmd_batch::EV_BRFREE], sA);
+    mark(6);
+    hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (A + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
+                       size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), sA, b->rs.p, b->alp[q].p, A,
+                       int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
+    hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_alp - 1), rt, 0, sA, b->rs.p, b->rs.p, T_alp - 1, A, CP);
+    mark(7);
+  };
+  auto audio_light = [&]() {
+    {
+      fmd::AudioConsts k{};
+      k.de_alpha = d.de_alpha;
+      k.n_b0 = d.notch.b0;
+      k.n_b1 = d.notch.b1;
+      k.n_b2 = d.notch.b2;
+      k.n_a1 = d.notch.a1;
+      k.n_a2 = d.notch.a2;
+      hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, sA, b->alp[q].p, A, C, CP, k,
+                         b->st, d_audio, audio_channel_stride);
+    }
+  };
+  if (serial_mode || b->split_post)
+  { // stage order of the reference (what the per-stage profile is keyed to), or two streams
+    rds_heavy();
+    rds_light();
+    signal(ce[fmd_batch::EV_RDS], sR);
+    mark(5);
+    audio_heavy();
+    audio_light();
+    signal(ce[fmd_batch::EV_AUD], sA);
+    mark(8);
+    after(sA, ce[fmd_batch::EV_RDS]);
+    signal(ce[fmd_batch::EV_HEAVY], sA);
   }
-  signal(ce[fmd_batch::EV_AUD], sA);
-  mark(8);
+  else
+  { // Both heavy parts first on the post stream, the light parts behind them on a stream of their
+    // own: the next call's FIR runs beside the light parts, and the next call's heavy parts do
+    // not queue behind them (rlpf / alp, the buffers between a heavy and a light part, are
+    // double-buffered by call parity; their readers of two calls ago are long done).
+    if (have_prev2)
+    {
+      after(sP, pe2[fmd_batch::EV_RDS]);
+      after(sP, pe2[fmd_batch::EV_AUD]);
+    }
+    rds_heavy();
+    audio_heavy();
+    signal(ce[fmd_batch::EV_HEAVY], sA);
+    after(sL, ce[fmd_batch::EV_HEAVY]);
+    sR = sL;
+    sA = sL;
+    rds_light();
+    signal(ce[fmd_batch::EV_RDS], sL);
+    audio_light();
+    signal(ce[fmd_batch::EV_AUD], sL);
+  }
   mark(9);
   HIPCHK(hipGetLastError());
   b->slot_call[es] = b->call_index;
@@ -1162,7 +1207,7 @@ int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsig
         return int(rows);
       }
     case FMD_TAP_RDS_LPF:
-      src = b->rlpf.p;
+      src = b->rlpf[b->call_index & 1u].p;
       esize = 8;
       rows = b->lastR;
       break;
