@@ -544,6 +544,7 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
     kfn = rounds <= 2 ? &fmd::k_if_fir<IN, TILE, 2, true, E>
         : rounds <= 4 ? &fmd::k_if_fir<IN, TILE, 4, true, E>
         : rounds <= 6 ? &fmd::k_if_fir<IN, TILE, 6, true, E>
+        : rounds <= 7 ? &fmd::k_if_fir<IN, TILE, 7, true, E>
                       : &fmd::k_if_fir<IN, TILE, 8, true, E>;
   if (pow2 && longasm)
     kfn = &fmd::k_if_fir<IN, TILE, 8, true, E, TILE == 256 && E == 1>;
