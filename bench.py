@@ -179,7 +179,7 @@ def main():
                                       table_size=table, if_filter_order=order),
                       C, tuning_shifts=shifts, device=local_rank, record_callbacks=False)
     a_stride = (batch.max_audio_floats(N) + 63) // 64 * 64
-    NBUF = 4  # outputs are consumed two steps after they are produced
+    NBUF = 6  # outputs are consumed three steps after they are produced
     audio = [torch.zeros((C, a_stride), dtype=torch.float32, device=dev) for _ in range(NBUF)]
     RCAP = C  # RDS records gathered per rank per step (<= 1 group per channel per 27 ms step)
     rds_dev = [torch.zeros((RCAP, 4), dtype=torch.int32, device=dev) for _ in range(NBUF)]
@@ -194,7 +194,7 @@ def main():
     total_groups = 0
 
     batch.set_concurrency(args.concurrency)  # 2: FIR of step i+1 overlaps the serial stages of step i
-    LAG = 2  # outputs of step i are consumed after step i+2 is submitted: the host never stalls
+    LAG = 3  # outputs of step i are consumed after step i+3 is submitted: the host never stalls
     groups_by_call = {}
     state = {"submitted": -1, "finalized": -1}
 
@@ -232,19 +232,27 @@ def main():
             pending[slot] = [w1, w2]
         state["finalized"] = i
 
+    host_t = {"process": 0.0, "collect": 0.0}
+
     def step(i):
         slot = i % NBUF
         if pending[slot] is not None:  # an old gather still reads this slot's buffers
             for w in pending[slot]:
                 w.wait()
             pending[slot] = None
+        th0 = time.perf_counter()
         nf = batch.process_device(iq[i % ring].data_ptr(), 0 if shared else N, N,
                                   audio[slot].data_ptr(), a_stride, stream, u8=u8)
+        host_t["process"] += time.perf_counter() - th0
         state["submitted"] = i
         if i - LAG > state["finalized"]:
             # orders the torch stream after the calls that are at least LAG old, drains their groups
+            th0 = time.perf_counter()
             batch.wait(stream=stream, lag=LAG)
+            th1 = time.perf_counter()
             pull_groups(LAG)
+            host_t["collect"] += time.perf_counter() - th1
+            host_t["wait"] = host_t.get("wait", 0.0) + (th1 - th0)
             while state["finalized"] < i - LAG:
                 finalize(state["finalized"] + 1)
         return nf
@@ -273,6 +281,7 @@ def main():
     for i in range(W):
         step(i)
     drain()
+    host_t["process"] = host_t["collect"] = host_t["wait"] = 0.0
     batch.set_profiling(1)  # HIP events around the IF FIR kernel of every timed call
     total_groups = 0
     barrier()
@@ -327,7 +336,10 @@ def main():
                        "input_format": args.input,
                        "channels_per_gpu": C, "samples_per_call": N, "input_ring_blocks": ring,
                        "audio_floats_per_channel_step": nf, "rds_groups_in_timed_region": total_groups,
-                       "gather": "rank-0 RCCL gather of audio+RDS per step" if world > 1 else "none (1 GPU)"},
+                       "gather": "rank-0 RCCL gather of audio+RDS per step" if world > 1 else "none (1 GPU)",
+                       "host_ms_per_step": {"submit": round(host_t["process"] / K * 1e3, 3),
+                                            "wait": round(host_t.get("wait", 0.0) / K * 1e3, 3),
+                                            "collect_rds": round(host_t["collect"] / K * 1e3, 3)}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "k_if_fir (cFineTuner + cDownsampleFilter complex)",

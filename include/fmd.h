@@ -154,7 +154,7 @@ int fmd_batch_process_host_u8(fmd_batch* b, const uint8_t* iq_u8, size_t iq_chan
 int fmd_batch_collect_rds(fmd_batch* b, fmd_rds_group* out, unsigned cap, int run_group_decoder,
                           void* stream);
 
-/* Like fmd_batch_collect_rds, but the `lag` (0..2) newest calls are left alone: only calls at
+/* Like fmd_batch_collect_rds, but the `lag` (0..4) newest calls are left alone: only calls at
  * least that old are waited for and their groups drained (use with concurrency 2, where the
  * newest calls are still running). */
 int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap,
@@ -172,7 +172,9 @@ int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap,
 int fmd_batch_set_concurrency(fmd_batch* b, int mode);
 /* Orders `stream` after every call submitted so far (outputs complete, inputs released). */
 int fmd_batch_wait(fmd_batch* b, void* stream);
-/* lag = 1 or 2: every call except the newest one / two (whose kernels may still be running). */
+/* lag = 1..4: every call except the newest `lag` ones (whose kernels may still be running; the
+ * light tail of a call's post chain finishes beside the FIR of the call after next, so a host that
+ * must never block consumes outputs three calls late). */
 int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream);
 
 int fmd_batch_get_status(fmd_batch* b, unsigned channel, fmd_status* st);

@@ -115,7 +115,7 @@ struct fmd_batch
   DevBuf<float> fstate; // all float state arrays, CP each
   DevBuf<int> istate;
   DevBuf<uint16_t> r_data;
-  static constexpr int NSLOT = 4; // event sets / RDS queues in rotation (call_index % NSLOT)
+  static constexpr int NSLOT = 8; // event sets / RDS queues in rotation (call_index % NSLOT)
   DevBuf<fmd::RdsGroupRec> queue[NSLOT]; // never drained while a call that appends to it is in flight
   DevBuf<unsigned> queue_count[NSLOT];
   unsigned queue_cap = 0;
@@ -151,7 +151,7 @@ struct fmd_batch
   enum { EV_IN, EV_FIR, EV_SER, EV_BRFREE, EV_MIXFREE, EV_AUD, EV_RDS, EV_HEAVY, EV_N };
   hipEvent_t cev[NSLOT][EV_N] = {};
   bool cev_ready = false;
-  uint32_t slot_call[NSLOT] = {0, 0, 0, 0}; // call index that last used the slot (0 = never)
+  uint32_t slot_call[NSLOT] = {}; // call index that last used the slot (0 = never)
   std::vector<hipEvent_t> ev; // [calls][ST_COUNT + 1]
   unsigned prof_calls = 0;
 
@@ -960,8 +960,8 @@ static bool slot_eligible(const fmd_batch* b, int q, int lag)
 
 int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream_)
 {
-  if (!b || lag < 0 || lag > 2)
-    return fail(FMD_ERR_ARG, "fmd_batch_wait: bad argument (lag must be 0, 1 or 2)");
+  if (!b || lag < 0 || lag > 4)
+    return fail(FMD_ERR_ARG, "fmd_batch_wait: bad argument (lag must be 0..4)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
   for (int q = 0; q < fmd_batch::NSLOT; q++)
@@ -1011,8 +1011,8 @@ static int drain_queue(fmd_batch* b, int q, hipStream_t stream, std::vector<fmd:
 int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap, int run_group_decoder,
                                  int lag, void* stream_)
 {
-  if (!b || lag < 0 || lag > 2)
-    return fail(FMD_ERR_ARG, "fmd_batch_collect_rds: bad argument (lag must be 0, 1 or 2)");
+  if (!b || lag < 0 || lag > 4)
+    return fail(FMD_ERR_ARG, "fmd_batch_collect_rds: bad argument (lag must be 0..4)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
   std::vector<fmd::RdsGroupRec> recs;
