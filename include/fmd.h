@@ -166,9 +166,11 @@ int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap,
  *   1  on internal streams, the caller's stream is ordered after each call (default; same
  *      observable semantics as 0)
  *   2  on internal streams and the caller's stream is NOT ordered after the call: the FIR of
- *      call k+1 overlaps the serial stages of call k.  The caller must use a different audio
- *      buffer for consecutive calls, keep d_iq valid, and call fmd_batch_wait (or collect_rds)
- *      before consuming outputs. */
+ *      call k+1 overlaps the serial stages of call k, and the last part of a call's post chain
+ *      (RDS bit recovery, audio tail) is only submitted together with the next call, or when its
+ *      results are asked for (fmd_batch_wait / fmd_batch_collect_rds with lag 0, the getters).
+ *      The caller must use different audio buffers for calls in flight, keep d_iq and d_audio
+ *      valid, and call fmd_batch_wait[_lagged] (or collect_rds) before consuming outputs. */
 int fmd_batch_set_concurrency(fmd_batch* b, int mode);
 /* Orders `stream` after every call submitted so far (outputs complete, inputs released). */
 int fmd_batch_wait(fmd_batch* b, void* stream);

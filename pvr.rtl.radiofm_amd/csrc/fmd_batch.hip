@@ -146,6 +146,17 @@ struct fmd_batch
   //                  fmd_batch_collect_rds; lets call k+1's FIR overlap call k's serial stages
   int concurrency = 1;
   hipStream_t s_fir = nullptr, s_ser = nullptr, s_post = nullptr, s_rds = nullptr;
+  // The light part of a call's post chain (RDS PLL, matched filter, bit recovery, audio tail), kept
+  // back until the next call is submitted (or its results are asked for): see process_device_impl.
+  struct LightJob
+  {
+    bool pending = false;
+    unsigned R = 0, A = 0, mf_g = 0;
+    int q = 0, es = 0;
+    uint32_t call_index = 0;
+    float* d_audio = nullptr;
+    size_t audio_stride = 0;
+  } light_job;
   bool split_post = false;
   bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
   enum { EV_IN, EV_FIR, EV_SER, EV_BRFREE, EV_MIXFREE, EV_AUD, EV_RDS, EV_HEAVY, EV_N };
@@ -255,6 +266,8 @@ int zero_rows(T* p, size_t rows, size_t CP)
  * clears the demod/RDS recurrences and re-initialises the three RDS filters; leaves tuner index,
  * FIR/resampler histories, pilot PLL, half-band histories, oscillator, de-emphasis, notch,
  * audio LPF and the block-sync shift register untouched, like the reference. */
+void flush_light(fmd_batch* b);
+
 int do_reset(fmd_batch* b)
 {
   const size_t CP = b->CP;
@@ -265,7 +278,7 @@ int do_reset(fmd_batch* b)
   for (int slot : fz)
     if (hipMemset(s.F(slot), 0, CP * sizeof(float)) != hipSuccess)
       return -1;
-  const int iz[] = {I_STEREO, I_R_LAST_BIT, I_R_BITPOS, I_R_BLOCK, I_R_STATE, I_R_BOFF};
+  const int iz[] = {I_STEREO, I_STEREO_Q0, I_STEREO_Q1, I_R_LAST_BIT, I_R_BITPOS, I_R_BLOCK, I_R_STATE, I_R_BOFF};
   for (int slot : iz)
     if (hipMemset(s.I(slot), 0, CP * sizeof(int)) != hipSuccess)
       return -1;
@@ -479,6 +492,8 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
 
 void fmd_batch_destroy(fmd_batch* b)
 {
+  if (b && b->light_job.pending)
+    flush_light(b);
   delete b;
 }
 
@@ -487,6 +502,7 @@ int fmd_batch_reset(fmd_batch* b)
   if (!b)
     return fail(FMD_ERR_ARG, "null batch");
   HIPCHK(hipSetDevice(b->device));
+  flush_light(b);
   HIPCHK(hipDeviceSynchronize());
   if (do_reset(b))
     return fail(FMD_ERR_DEVICE, "state reset failed");
@@ -602,6 +618,67 @@ int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, un
   return launch_if_stage_e<IN, 256>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
 }
 
+/* The light part of one call's post chain on stream s: cRDSRxSignalProcessor's PLL, matched filter
+ * and bit recovery, then the audio tail; records the call's EV_RDS / EV_AUD. */
+void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, bool record)
+{
+  const fmd::Design& d = b->des;
+  const unsigned C = b->C, CP = b->CP;
+  const unsigned T_mf = unsigned(d.rds_mf_taps.size());
+  const dim3 rt(256);
+  auto rgrid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
+  {
+    fmd::RdsConsts k{};
+    k.pll_alpha = d.rds_pll_alpha;
+    k.pll_beta = d.rds_pll_beta;
+    k.nco_hl = d.rds_nco_hl;
+    k.nco_ll = d.rds_nco_ll;
+    k.bs_b0 = d.bitsync.b0;
+    k.bs_b1 = d.bitsync.b1;
+    k.bs_b2 = d.bitsync.b2;
+    k.bs_a1 = d.bitsync.a1;
+    k.bs_a2 = d.bitsync.a2;
+    k.mf_taps = int(T_mf);
+    const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
+    hipLaunchKernelGGL(fmd::k_rds_pll, dim3(CP / 64), dim3(64), 0, s, b->rlpf[j.q].p, j.R, C, CP, k, b->st,
+                       b->rpll.p, T_mf - 1, b->sctab.p, sct);
+    hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (j.R + fmd::RF_TI - 1) / fmd::RF_TI),
+                       dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), s, b->rpll.p,
+                       b->rmf.p, j.R, int(T_mf), b->mf_taps2.p, j.mf_g, C, CP, 0u);
+    hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, s, b->rpll.p, b->rpll.p, T_mf - 1, j.R,
+                       CP);
+    hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, s, b->rmf.p, j.R, C, CP, k, b->st,
+                       j.call_index, b->queue[j.es].p, b->queue_count[j.es].p, b->queue_cap,
+                       b->tap_sync.p, b->write_taps);
+  }
+  if (record)
+    (void)hipEventRecord(b->cev[j.es][fmd_batch::EV_RDS], s);
+  {
+    fmd::AudioConsts k{};
+    k.de_alpha = d.de_alpha;
+    k.n_b0 = d.notch.b0;
+    k.n_b1 = d.notch.b1;
+    k.n_b2 = d.notch.b2;
+    k.n_a1 = d.notch.a1;
+    k.n_a2 = d.notch.a2;
+    hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, s, b->alp[j.q].p, j.A, C, CP, k,
+                       b->st, j.d_audio, j.audio_stride, unsigned(j.q));
+  }
+  if (record)
+    (void)hipEventRecord(b->cev[j.es][fmd_batch::EV_AUD], s);
+}
+
+/* Submits a kept-back light part now (its results are wanted, or the batch changes mode). */
+void flush_light(fmd_batch* b)
+{
+  if (!b->light_job.pending)
+    return;
+  const fmd_batch::LightJob j = b->light_job;
+  b->light_job.pending = false;
+  (void)hipStreamWaitEvent(b->s_rds, b->cev[j.es][fmd_batch::EV_HEAVY], 0);
+  launch_light(b, j, b->s_rds, true);
+}
+
 enum IqFormat
 {
   IQ_F32 = 0, // complex<float>, the ProcessStream argument (FmDecode.h:135)
@@ -676,6 +753,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   const bool have_prev2 = b->call_index > 2;
   hipEvent_t* pe2 = b->cev[(b->call_index + fmd_batch::NSLOT - 2) % fmd_batch::NSLOT];
   const bool serial_mode = b->concurrency == 0 || b->profiling >= 2;
+  if (b->light_job.pending && (serial_mode || b->split_post || b->concurrency != 2))
+    flush_light(b); // leaving the overlapped form: nothing stays kept back
   hipStream_t sF = serial_mode ? stream : b->s_fir;
   hipStream_t sS = serial_mode ? stream : b->s_ser;
   hipStream_t sP = serial_mode ? stream : b->s_post;
@@ -768,11 +847,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     if (b->serial_exclusive && !serial_mode)
       hipLaunchKernelGGL((fmd::k_demod_serial<2, true>), dim3((groups + 1) / 2), dim3(256), 0, sS,
                          b->demod[q].p, b->Mstride, M, C, CP, k, b->st, b->br[q].p, Hbb, b->mix[q].p,
-                         Hmix, b->sctab.p, sct);
+                         Hmix, b->sctab.p, sct, unsigned(q));
     else
       hipLaunchKernelGGL((fmd::k_demod_serial<1, false>), dim3(groups), dim3(128), 0, sS, b->demod[q].p,
                          b->Mstride, M, C, CP, k, b->st, b->br[q].p, Hbb, b->mix[q].p, Hmix,
-                         b->sctab.p, sct);
+                         b->sctab.p, sct, unsigned(q));
   }
   signal(ce[fmd_batch::EV_SER], sS);
   mark(2);
@@ -869,7 +948,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       k.n_a1 = d.notch.a1;
       k.n_a2 = d.notch.a2;
       hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, sA, b->alp[q].p, A, C, CP, k,
-                         b->st, d_audio, audio_channel_stride);
+                         b->st, d_audio, audio_channel_stride, unsigned(q));
     }
   };
   if (serial_mode || b->split_post)
@@ -898,13 +977,37 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     rds_heavy();
     audio_heavy();
     signal(ce[fmd_batch::EV_HEAVY], sA);
-    after(sL, ce[fmd_batch::EV_HEAVY]);
-    sR = sL;
-    sA = sL;
-    rds_light();
-    signal(ce[fmd_batch::EV_RDS], sL);
-    audio_light();
-    signal(ce[fmd_batch::EV_AUD], sL);
+    fmd_batch::LightJob job;
+    job.pending = true;
+    job.R = R;
+    job.A = A;
+    job.mf_g = b->mf_g;
+    job.q = q;
+    job.es = es;
+    job.call_index = b->call_index;
+    job.d_audio = d_audio;
+    job.audio_stride = audio_channel_stride;
+    if (b->concurrency == 2)
+    { // Overlapped calls: the light part of the PREVIOUS call goes out now, behind this call's
+      // serial stage, i.e. it runs beside the heavy part of this call at the start of the next
+      // period and not beside the FIR of the next call (which then only shares the chip with the
+      // serial stage on its own CUs).  This call's light part is kept back the same way; anything
+      // that asks for its results submits it (flush_light).
+      if (b->light_job.pending)
+      {
+        const fmd_batch::LightJob prev = b->light_job;
+        b->light_job.pending = false;
+        after(sL, b->cev[prev.es][fmd_batch::EV_HEAVY]);
+        after(sL, ce[fmd_batch::EV_SER]);
+        launch_light(b, prev, sL, true);
+      }
+      b->light_job = job;
+    }
+    else
+    {
+      after(sL, ce[fmd_batch::EV_HEAVY]);
+      launch_light(b, job, sL, true);
+    }
   }
   mark(9);
   HIPCHK(hipGetLastError());
@@ -964,6 +1067,8 @@ int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream_)
     return fail(FMD_ERR_ARG, "fmd_batch_wait: bad argument (lag must be 0..4)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
+  if (lag == 0)
+    flush_light(b); // the newest call's light part may still be kept back
   for (int q = 0; q < fmd_batch::NSLOT; q++)
     if (slot_eligible(b, q, lag))
     {
@@ -984,6 +1089,7 @@ int fmd_batch_set_concurrency(fmd_batch* b, int mode)
   if (!b || mode < 0 || mode > 2)
     return fail(FMD_ERR_ARG, "fmd_batch_set_concurrency: mode must be 0, 1 or 2");
   HIPCHK(hipSetDevice(b->device));
+  flush_light(b);
   HIPCHK(hipDeviceSynchronize());
   b->concurrency = mode;
   return FMD_OK;
@@ -1015,6 +1121,8 @@ int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap,
     return fail(FMD_ERR_ARG, "fmd_batch_collect_rds: bad argument (lag must be 0..4)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
+  if (lag == 0)
+    flush_light(b);
   std::vector<fmd::RdsGroupRec> recs;
   for (int q = 0; q < fmd_batch::NSLOT; q++)
   {
@@ -1130,6 +1238,7 @@ int fmd_batch_get_status(fmd_batch* b, unsigned channel, fmd_status* stt)
   if (!b || !stt || channel >= b->C)
     return fail(FMD_ERR_ARG, "fmd_batch_get_status: bad argument");
   HIPCHK(hipSetDevice(b->device));
+  flush_light(b);
   HIPCHK(hipDeviceSynchronize());
   float if_level = 0, bb_mean = 0, bb_level = 0, p_level = 0;
   int stereo = 0, rstate = 0;
@@ -1155,6 +1264,7 @@ int fmd_batch_get_audio_level(fmd_batch* b, unsigned channel, fmd_audio_level* o
   if (!b || !out || channel >= b->C)
     return fail(FMD_ERR_ARG, "fmd_batch_get_audio_level: bad argument");
   HIPCHK(hipSetDevice(b->device));
+  flush_light(b);
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(&out->mean, b->st.F(fmd::F_AUDIO_MEAN) + channel, 4, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&out->rms, b->st.F(fmd::F_AUDIO_RMS) + channel, 4, hipMemcpyDeviceToHost));
@@ -1167,6 +1277,7 @@ int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsig
   if (!b || !out || channel >= b->C)
     return fail(FMD_ERR_ARG, "fmd_batch_get_tap: bad argument");
   HIPCHK(hipSetDevice(b->device));
+  flush_light(b);
   HIPCHK(hipDeviceSynchronize());
   const size_t CP = b->CP;
   const void* src = nullptr;

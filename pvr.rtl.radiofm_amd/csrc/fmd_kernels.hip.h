@@ -65,7 +65,8 @@ enum FSlot
 };
 enum ISlot
 {
-  I_P_LOCK_CNT, I_STEREO, I_R_LAST_BIT, I_R_BITS, I_R_BLOCK, I_R_BITPOS, I_R_STATE, I_R_BOFF,
+  I_P_LOCK_CNT, I_STEREO, I_STEREO_Q0, I_STEREO_Q1, // _Q0/_Q1: the flag per call parity (audio tail)
+  I_R_LAST_BIT, I_R_BITS, I_R_BLOCK, I_R_BITPOS, I_R_STATE, I_R_BOFF,
   I_R_ERRORS, I_R_SEQ, I_SLOTS
 };
 struct ChannelState
@@ -556,7 +557,8 @@ template <int NG, bool EXCL>
 __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     const float2* __restrict__ demod, unsigned Mstride, unsigned M, unsigned C, unsigned CP,
     DemodConsts k, ChannelState st, float2* __restrict__ br, unsigned Hbb,
-    float2* __restrict__ mix, unsigned Hmix, const double* __restrict__ sctab_g, FmdSincosTab sct)
+    float2* __restrict__ mix, unsigned Hmix, const double* __restrict__ sctab_g, FmdSincosTab sct,
+    unsigned stereo_q)
 {
   __shared__ float chunk_all[NG][2][DS][64];  // baseband, FM role -> pilot/RDS role
   __shared__ float2 stage_all[NG][2][DS][64]; // IF-FIR output, pilot/RDS role -> FM role
@@ -771,6 +773,8 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           cnt = 0;
         st.I(I_P_LOCK_CNT)[c] = cnt;
         st.I(I_STEREO)[c] = cnt >= k.p_lock_delay;
+        // the audio tail of this call may run after the next call's serial stage: its own copy
+        st.I(I_STEREO_Q0 + (int)stereo_q)[c] = cnt >= k.p_lock_delay;
       }
       { // baseband stats (FmDecode.cpp:439-442)
         const float mean = vsum / (float)M;
@@ -1341,7 +1345,7 @@ constexpr int AT_STEPS = 16; // audio frames buffered per lane before a coalesce
 __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp, unsigned A,
                                                    unsigned C, unsigned CP, AudioConsts k,
                                                    ChannelState st, float* __restrict__ audio,
-                                                   size_t audio_stride)
+                                                   size_t audio_stride, unsigned stereo_q)
 {
   // [channel lane][AT_STEPS frames + pad]: one row = 128 B of a channel's interleaved L/R output
   __shared__ float2 tile[64][AT_STEPS + 1];
@@ -1352,7 +1356,7 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
   const unsigned c = active ? c0 : C - 1;
   float de_re = st.F(F_DE_RE)[c], de_im = st.F(F_DE_IM)[c];
   float w1a = st.F(F_N_W1A)[c], w2a = st.F(F_N_W2A)[c], w1b = st.F(F_N_W1B)[c], w2b = st.F(F_N_W2B)[c];
-  const int stereo = st.I(I_STEREO)[c];
+  const int stereo = st.I(I_STEREO_Q0 + (int)stereo_q)[c];
   const float one_minus_alpha = 1.0f - k.de_alpha;
   // cRadioReceiver::SamplesMeanRMS over the packet (RadioReceiver.cpp:584-598): float sums over
   // the interleaved samples L0, R0, L1, R1, ... in that order
