@@ -103,7 +103,21 @@ def main():
                     help="fmd_batch_set_concurrency mode (2 = calls overlap, the default)")
     ap.add_argument("--stage-profile", action="store_true",
                     help="after the timed region, run 3 extra steps with per-stage events")
+    ap.add_argument("--watchdog", type=int, default=900,
+                    help="seconds after which a run that has not finished kills itself (a hung "
+                         "collective or kernel must not keep the box busy)")
     args = ap.parse_args()
+
+    import threading
+
+    def _expired():
+        sys.stderr.write("bench.py: watchdog expired after %d s, exiting\n" % args.watchdog)
+        sys.stderr.flush()
+        os._exit(3)
+
+    wd = threading.Timer(args.watchdog, _expired)
+    wd.daemon = True
+    wd.start()
 
     import torch
     import torch.distributed as dist
