@@ -608,7 +608,12 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           fmd_sincos_tab(nco_phase, sctab, sct, &sn, &cs);
           const float dre = cs * sre - sn * sim; // ComplexType(Cos, Sin) * signal[i]
           const float dim = cs * sim + sn * sre;
-          const float err = -fmd_atan2f_tab(dim, dre, atab);
+          /* One wave-uniform test for both kinds of rare input (arctangent outside the table form's
+           * range; a phase step outside (-2pi, 4pi), impossible with the clamps): the common path
+           * carries no fix-up code, the rare path redoes the update literally. */
+          bool lit;
+          const float err = -fmd_atan2f_tab_core(dim, dre, atab, &lit);
+          const float incr0 = nco_incr, phase0 = nco_phase;
           nco_incr += k.pll_beta * err;
           nco_incr = (nco_incr < k.nco_ll) ? k.nco_ll : nco_incr;
           nco_incr = (nco_incr > k.nco_hl) ? k.nco_hl : nco_incr;
@@ -616,27 +621,33 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           {
             /* :404-407  if (phase >= 2pi) phase = fmod(phase, 2pi); while (phase < 0) phase += 2pi;
              * For phase in [2pi, 4pi) fmod is the exact difference phase - 2pi, and for
-             * [-2pi, 0) the loop runs once; the clamps above keep every step inside
-             * (-2pi, 4pi), anything else takes the literal slow path. */
+             * [-2pi, 0) the loop runs once. */
             const double pd = (double)nco_phase;
             const bool ge = pd >= FMD_K_2PI;
             const bool lt = nco_phase < 0;
             const double off = ge ? -FMD_K_2PI : FMD_K_2PI;
             const float moved = (float)(pd + off); // exact difference / sum, rounded once
             const bool far = (pd >= 2.0 * FMD_K_2PI) | (pd < -FMD_K_2PI);
-            float next = (ge | lt) ? moved : nco_phase;
-            if (FMD_ANY_LANE(far))
-            { // never with the clamps above; kept literal
-              if (far)
+            nco_phase = (ge | lt) ? moved : nco_phase;
+            const bool redo = lit | far;
+            if (FMD_ANY_LANE(redo))
+            {
+              if (redo)
               {
-                next = nco_phase;
-                if (ge)
-                  next = (float)fmod(pd, FMD_K_2PI);
-                while (next < 0)
-                  next = (float)((double)next + FMD_K_2PI);
+                const float e2 = lit ? -fmd_atan2f(dim, dre) : err;
+                float in2 = incr0 + k.pll_beta * e2;
+                in2 = (in2 < k.nco_ll) ? k.nco_ll : in2;
+                in2 = (in2 > k.nco_hl) ? k.nco_hl : in2;
+                float ph2 = phase0 + (in2 + k.pll_alpha * e2);
+                const double pd2 = (double)ph2;
+                if (pd2 >= FMD_K_2PI)
+                  ph2 = (float)fmod(pd2, FMD_K_2PI);
+                while (ph2 < 0)
+                  ph2 = (float)((double)ph2 + FMD_K_2PI);
+                nco_incr = in2;
+                nco_phase = ph2;
               }
             }
-            nco_phase = next;
           }
           chunk[j & 1][u][lane] = 2 * nco_incr; // phaseIncr (:409); the output filter runs in wave 1
         }

@@ -322,7 +322,8 @@ FMD_HD void fmd_atan_table_fill(float* t)
       t[r * 8 + k] = v[r][k];
 }
 
-FMD_HD float fmd_atan2f_tab(float y, float x, const float* tab)
+/* core: the common-range result and whether this lane needs the literal path instead */
+FMD_HD float fmd_atan2f_tab_core(float y, float x, const float* tab, bool* need_literal)
 {
   const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
               aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
@@ -336,7 +337,9 @@ FMD_HD float fmd_atan2f_tab(float y, float x, const float* tab)
    * its range index is clamped, nothing here can trap) */
   const uint32_t ic = rare ? 0x3f800000u : iq;
   const float qc = fmd_u2f(ic);
-  const int r = (ic >= 0x3ee00000u) + (ic >= 0x3f300000u) + (ic >= 0x3f980000u) + (ic >= 0x401c0000u);
+  /* range index without compares: (ic - T) is negative, i.e. shifts to -1, exactly when ic < T */
+  const int r = 4 + ((int32_t)(ic - 0x3ee00000u) >> 31) + ((int32_t)(ic - 0x3f300000u) >> 31) +
+                ((int32_t)(ic - 0x3f980000u) >> 31) + ((int32_t)(ic - 0x401c0000u) >> 31);
   const float* t = tab + 8 * r;
   /* a = d and c = -b in every row (a: 1 2 1 1 0, c: 0 1 1 1.5 1), so the reduction only needs two
    * small numbers per range; they come out of two packed byte constants (a, 2c) with a shift and a
@@ -357,7 +360,14 @@ FMD_HD float fmd_atan2f_tab(float y, float x, const float* tab)
   /* quadrant: x >= 0 -> at, x < 0 -> pi - (at - pi_lo); then the sign of y (m = 1, 3 negate) */
   const float left = pi - (at - pi_lo);
   const float base = ((int32_t)fmd_f2u(x) < 0) ? left : at;
-  float res = fmd_u2f(fmd_f2u(base) ^ (fmd_f2u(y) & 0x80000000u));
+  *need_literal = rare;
+  return fmd_u2f(fmd_f2u(base) ^ (fmd_f2u(y) & 0x80000000u));
+}
+
+FMD_HD float fmd_atan2f_tab(float y, float x, const float* tab)
+{
+  bool rare;
+  float res = fmd_atan2f_tab_core(y, x, tab, &rare);
   if (FMD_ANY_LANE(rare))
   {
     if (rare)
