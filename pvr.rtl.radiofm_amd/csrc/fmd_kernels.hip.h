@@ -614,9 +614,10 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           bool lit;
           const float err = -fmd_atan2f_tab_core(dim, dre, atab, &lit);
           const float incr0 = nco_incr, phase0 = nco_phase;
+          /* :399-402 as max / min: the same as the reference's two compares for every number; a
+           * NaN state (only ever out of non-finite input) goes through the literal path below */
           nco_incr += k.pll_beta * err;
-          nco_incr = (nco_incr < k.nco_ll) ? k.nco_ll : nco_incr;
-          nco_incr = (nco_incr > k.nco_hl) ? k.nco_hl : nco_incr;
+          nco_incr = fminf(fmaxf(nco_incr, k.nco_ll), k.nco_hl);
           nco_phase += nco_incr + k.pll_alpha * err;
           {
             /* :404-407  if (phase >= 2pi) phase = fmod(phase, 2pi); while (phase < 0) phase += 2pi;
@@ -627,7 +628,8 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
             const bool lt = nco_phase < 0;
             const double off = ge ? -FMD_K_2PI : FMD_K_2PI;
             const float moved = (float)(pd + off); // exact difference / sum, rounded once
-            const bool far = (pd >= 2.0 * FMD_K_2PI) | (pd < -FMD_K_2PI);
+            // outside (-2pi, 4pi) (never with the clamps), tested generously: |phase - pi| >= 9.4
+            const bool far = !(fabsf(nco_phase - 3.1415927f) < 9.4f) | (incr0 != incr0);
             nco_phase = (ge | lt) ? moved : nco_phase;
             const bool redo = lit | far;
             if (FMD_ANY_LANE(redo))

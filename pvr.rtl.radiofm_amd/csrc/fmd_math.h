@@ -342,12 +342,17 @@ FMD_HD float fmd_atan2f_tab_core(float y, float x, const float* tab, bool* need_
                 ((int32_t)(ic - 0x3f980000u) >> 31) + ((int32_t)(ic - 0x401c0000u) >> 31);
   const float* t = tab + 8 * r;
   /* a = d and c = -b in every row (a: 1 2 1 1 0, c: 0 1 1 1.5 1), so the reduction only needs two
-   * small numbers per range; they come out of two packed byte constants (a, 2c) with a shift and a
-   * byte conversion instead of waiting for the table row, which is then only needed for hi / lo at
-   * the very end. */
-  const unsigned sh = 8u * (unsigned)r;
-  const float ca = (float)((0x0001010201ull >> sh) & 0xffu);        /* bytes r=0..4: 1 2 1 1 0 */
-  const float cc = (float)((0x0203020200ull >> sh) & 0xffu) * 0.5f; /* 2c:         0 2 2 3 2 */
+   * small numbers per range; they come out of two packed nibble constants (a, 2c) with a bit-field
+   * extract and a conversion instead of waiting for the table row, which is then only needed for
+   * hi / lo at the very end. */
+  /* nibble r of 0x01121 is a (1 2 1 1 0 for r = 0..4), of 0x23220 is 2c (0 2 2 3 2) */
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float ca = (float)__builtin_amdgcn_ubfe(0x01121u, 4u * (unsigned)r, 4u);
+  const float cc = (float)__builtin_amdgcn_ubfe(0x23220u, 4u * (unsigned)r, 4u) * 0.5f;
+#else
+  const float ca = (float)((0x01121u >> (4u * (unsigned)r)) & 0xfu);
+  const float cc = (float)((0x23220u >> (4u * (unsigned)r)) & 0xfu) * 0.5f;
+#endif
   const float num = ca * qc + (-cc);
   const float den = cc * qc + ca; /* 1, 2+q, q+1, 1+1.5q or q: within [0.4375, 2^25] */
   const float xr = fmd_div_midrange(num, den);
