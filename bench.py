@@ -188,6 +188,9 @@ def main():
             gen.generate(iq[r], r * N, N)
     torch.cuda.synchronize()
 
+    # development aid: other users of hardware queues in the process, created first
+    extra_streams = [torch.cuda.Stream(device=dev)
+                     for _ in range(int(os.environ.get("FMD_BENCH_EXTRA_STREAMS", "0")))]
     shifts = (np.arange(C, dtype=np.int32) % table) - table // 2 if shared else None
     batch = pkg.Batch(pkg.make_params(FS, 0.0 if shared else -0.15 * FS, 48000.0, 15000.0, D,
                                       table_size=table, if_filter_order=order),

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <functional>
 #include <memory>
@@ -295,6 +296,53 @@ int do_reset(fmd_batch* b)
   return 0;
 }
 
+/* HIP multiplexes streams onto a few hardware queues, and two of this library's chains on one
+ * queue block each other (the FIR of the next call would queue behind the previous call's post
+ * chain: measured -13 % when just one unrelated stream created earlier shifted the assignment).
+ * So the internal streams are picked by measurement: candidates are created until `n` of them run
+ * a no-op kernel at once while all already chosen ones are kept busy by a spinning wave. */
+int pick_independent_streams(int n, const int* priority, hipStream_t* out)
+{
+  std::vector<hipStream_t> rejected;
+  int have = 0;
+  for (int attempt = 0; attempt < 24 && have < n; attempt++)
+  {
+    hipStream_t cand = nullptr;
+    if (hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, priority[have]) != hipSuccess)
+      break;
+    bool independent = true;
+    {
+      const long long spin = 1200000; // ~0.5 ms
+      for (int i = 0; i < have; i++)
+        hipLaunchKernelGGL(fmd::k_probe_spin, dim3(1), dim3(64), 0, out[i], spin, nullptr);
+      // the default stream too: it is the caller's stream more often than not
+      hipLaunchKernelGGL(fmd::k_probe_spin, dim3(1), dim3(64), 0, nullptr, spin, nullptr);
+      const auto t0 = std::chrono::steady_clock::now();
+      hipLaunchKernelGGL(fmd::k_probe_nop, dim3(1), dim3(64), 0, cand, nullptr);
+      (void)hipStreamSynchronize(cand);
+      const double us =
+          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      independent = us < 250.0; // behind a spinning wave it would take ~500 us
+      for (int i = 0; i < have; i++)
+        (void)hipStreamSynchronize(out[i]);
+      (void)hipStreamSynchronize(nullptr);
+    }
+    if (independent)
+      out[have++] = cand;
+    else
+      rejected.push_back(cand);
+  }
+  // whatever is still missing (no independent queue left): take the rejected ones, it still works
+  while (have < n && !rejected.empty())
+  {
+    out[have++] = rejected.back();
+    rejected.pop_back();
+  }
+  for (hipStream_t s : rejected)
+    (void)hipStreamDestroy(s);
+  return have == n ? 0 : -1;
+}
+
 } // namespace
 
 extern "C" {
@@ -462,9 +510,14 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     // post chain has slack every call and goes last
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi)); // lo = least, hi = greatest priority
-    HIPCHK(hipStreamCreateWithPriority(&b->s_fir, hipStreamNonBlocking, hi));
-    HIPCHK(hipStreamCreateWithPriority(&b->s_ser, hipStreamNonBlocking, hi));
-    HIPCHK(hipStreamCreateWithPriority(&b->s_post, hipStreamNonBlocking, lo));
+    const int prio[4] = {hi, hi, lo, lo};
+    hipStream_t st4[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (pick_independent_streams(4, prio, st4) != 0)
+      return fail(FMD_ERR_DEVICE, "could not create the internal streams");
+    b->s_fir = st4[0];
+    b->s_ser = st4[1];
+    b->s_post = st4[2];
+    b->s_rds = st4[3];
     // RDS chain and audio chain behind the serial stage are independent.  With more channels than
     // the chip holds serial-stage workgroups (256 CUs x 64 channels) the batch is throughput-bound
     // and they run side by side on two streams (+10 % at 24 576, +12 % at 32 768 channels); below
@@ -479,7 +532,6 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
       b->serial_exclusive = atoi(e) != 0;
     if (const char* e = getenv("FMD_SPLIT_POST"))
       b->split_post = atoi(e) != 0;
-    HIPCHK(hipStreamCreateWithPriority(&b->s_rds, hipStreamNonBlocking, lo));
   }
   for (auto& row : b->cev)
     for (auto& e : row)

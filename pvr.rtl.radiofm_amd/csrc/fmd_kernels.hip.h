@@ -1454,6 +1454,24 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Stream probe (fmd_batch_create): one wave that stays busy for `cycles`, and a no-op.         */
+/* ------------------------------------------------------------------------------------------ */
+__global__ void k_probe_spin(long long cycles, int* sink)
+{
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  int n = 0;
+  while (__builtin_amdgcn_s_memtime() - t0 < cycles)
+    n++;
+  if (sink && n < 0)
+    *sink = n;
+}
+__global__ void k_probe_nop(int* sink)
+{
+  if (sink && threadIdx.x == 12345)
+    *sink = 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Test aid: the device builds of the fmd_math.h helpers on arrays of arguments, so their      */
 /* device-only code (reciprocal-based division, ballot branches, table forms) can be swept      */
 /* against the host libm directly (fmd_debug_math).                                             */
