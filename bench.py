@@ -188,6 +188,11 @@ def main():
             gen.generate(iq[r], r * N, N)
     torch.cuda.synchronize()
 
+    # the communicator (and its streams) first: the decoder picks its internal streams by a probe
+    # when the batch is created and should see everything else that uses hardware queues
+    if world > 1:
+        dg.gather_preflight(dev if backend == "nccl" else "cpu")
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     # development aid: other users of hardware queues in the process, created first
     extra_streams = [torch.cuda.Stream(device=dev)
                      for _ in range(int(os.environ.get("FMD_BENCH_EXTRA_STREAMS", "0")))]
@@ -204,9 +209,6 @@ def main():
         g_audio = [[torch.empty_like(audio[0]) for _ in range(world)] for _ in range(NBUF)]
         g_rds = [[torch.empty_like(rds_dev[0]) for _ in range(world)] for _ in range(NBUF)]
     stream = torch.cuda.current_stream().cuda_stream
-    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    if world > 1:
-        dg.gather_preflight(dev if backend == "nccl" else "cpu")
     pending = [None] * NBUF
     total_groups = 0
 
