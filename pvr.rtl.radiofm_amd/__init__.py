@@ -93,7 +93,7 @@ class FmdPvrSignalStatus(C.Structure):
 STREAM_AUDIO, STREAM_RDS, STREAM_CHANGE, STREAM_TIME_BASE = 1, 2, -11, 1000000
 
 EXPORTS = [
-    "fmd_debug_math", "fmd_design_lanczos", "fmd_design_lp_kaiser", "fmd_design_biquad", "fmd_design_tuner_lut",
+    "fmd_debug_math", "fmd_batch_debug_serial_probe", "fmd_design_lanczos", "fmd_design_lp_kaiser", "fmd_design_biquad", "fmd_design_tuner_lut",
     "fmd_batch_get_audio_level", "fmd_receiver_open", "fmd_receiver_close", "fmd_receiver_write_iq",
     "fmd_receiver_write_u8", "fmd_receiver_end", "fmd_receiver_queued_samples",
     "fmd_receiver_set_stream_change", "fmd_receiver_demux_read", "fmd_receiver_signal_status",
@@ -159,6 +159,7 @@ def lib():
         L.fmd_batch_get_tap.argtypes = [vp, i, u, vp, u]
         L.fmd_batch_get_audio_level.argtypes = [vp, u, C.POINTER(FmdAudioLevel)]
         L.fmd_debug_math.argtypes = [i, u, vp, vp, vp, vp]
+        L.fmd_batch_debug_serial_probe.argtypes = [vp, vp, u]
         L.fmd_design_lanczos.argtypes = [u, C.c_double, vp, u]
         L.fmd_design_lp_kaiser.argtypes = [C.c_float] * 5 + [vp, u]
         L.fmd_design_biquad.argtypes = [i, C.c_float, C.c_float, C.c_float, vp]
@@ -335,6 +336,14 @@ class Batch:
         a = FmdAudioLevel()
         _check(lib().fmd_batch_get_audio_level(self._h, channel, C.byref(a)))
         return (a.mean, a.rms, a.level)
+
+    def debug_serial_probe(self):
+        """FMD_SERIAL_PROBE=1: (start, end, cycles) int64 per workgroup of the serial stage's last 8
+        launches, shape (8, slots, 3), launch = call index mod 8; unused slots are zero."""
+        buf = np.zeros((8 * 4096, 3), dtype=np.int64)
+        n = _check(lib().fmd_batch_debug_serial_probe(self._h, buf.ctypes.data, buf.shape[0]))
+        n -= n % 8
+        return buf[:n].reshape(8, -1, 3).copy() if n else buf[:0].reshape(8, 0, 3)
 
     def tap(self, name, channel=0):
         cap = 2 * 65536

@@ -113,6 +113,7 @@ struct fmd_batch
   DevBuf<float> rpll, rmf, tap_sync;
   DevBuf<double> sctab;
   DevBuf<int> pidx;
+  DevBuf<long long> serial_probe; // FMD_SERIAL_PROBE=1: per-workgroup timing of the serial stage
   DevBuf<float> fstate; // all float state arrays, CP each
   DevBuf<int> istate;
   DevBuf<uint16_t> r_data;
@@ -199,6 +200,7 @@ struct fmd_batch
     tap_sync.release();
     sctab.release();
     pidx.release();
+    serial_probe.release();
     fstate.release();
     istate.release();
     r_data.release();
@@ -469,8 +471,10 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->rds_lpf_taps.alloc(T_lpf);
   bad |= b->mf_taps2.alloc(size_t(2) * T_mf);
   bad |= b->audio_taps.alloc(T_alp);
-  bad |= b->ktab.alloc(size_t(b->Amax) * (d.rs_order + 1));
+  bad |= b->ktab.alloc(size_t(b->Amax) * (d.rs_order + 1) + 2 * fmd::RSL_PAD); // padded: k_resample_lds
   bad |= b->pidx.alloc(b->Amax);
+  if (getenv("FMD_SERIAL_PROBE") && atoi(getenv("FMD_SERIAL_PROBE")))
+    bad |= b->serial_probe.alloc(size_t(8) * 3 * (b->CP / 64)); // the last 8 launches
   bad |= b->sctab.alloc(d.sincos_tab.size());
   bad |= b->fstate.alloc(size_t(fmd::F_SLOTS) * CP);
   bad |= b->istate.alloc(size_t(fmd::I_SLOTS) * CP);
@@ -899,11 +903,13 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     if (b->serial_exclusive && !serial_mode)
       hipLaunchKernelGGL((fmd::k_demod_serial<2, true>), dim3((groups + 1) / 2), dim3(256), 0, sS,
                          b->demod[q].p, b->Mstride, M, C, CP, k, b->st, b->br[q].p, Hbb, b->mix[q].p,
-                         Hmix, b->sctab.p, sct, unsigned(q));
+                         Hmix, b->sctab.p, sct, unsigned(q),
+                         b->serial_probe.p ? b->serial_probe.p + size_t(b->call_index % 8) * 3 * (CP / 64) : nullptr);
     else
       hipLaunchKernelGGL((fmd::k_demod_serial<1, false>), dim3(groups), dim3(128), 0, sS, b->demod[q].p,
                          b->Mstride, M, C, CP, k, b->st, b->br[q].p, Hbb, b->mix[q].p, Hmix,
-                         b->sctab.p, sct, unsigned(q));
+                         b->sctab.p, sct, unsigned(q),
+                         b->serial_probe.p ? b->serial_probe.p + size_t(b->call_index % 8) * 3 * (CP / 64) : nullptr);
   }
   signal(ce[fmd_batch::EV_SER], sS);
   mark(2);
@@ -911,11 +917,26 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   const dim3 rt(256);
   auto rgrid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
 
+  /* With overlapped calls three things become runnable the moment this call's serial stage ends: the
+   * next call's serial stage (already queued behind it), this call's post chain and the previous
+   * call's light part.  The exclusive serial stage needs EMPTY CUs; when the half-band kernel of the
+   * post chain is dispatched first it fills every CU and the serial stage starts only once those
+   * workgroups have drained (measured: 136 us after its predecessor ended, every call).  So the
+   * post chain and the light part start behind a single wave that idles for a few microseconds:
+   * the serial stage is dispatched first (30-50 us after its predecessor, period 2.50 -> 2.42 ms).
+   * FMD_POST_DELAY_US overrides (0 = off). */
+  static const int post_delay_us = getenv("FMD_POST_DELAY_US") ? atoi(getenv("FMD_POST_DELAY_US")) : 20;
+  auto post_delay = [&](hipStream_t s) {
+    if (post_delay_us > 0 && b->serial_exclusive && !serial_mode && b->concurrency == 2)
+      hipLaunchKernelGGL(fmd::k_delay, dim3(1), dim3(64), 0, s, unsigned(post_delay_us) * 100u);
+  };
+
   /* The post chain in four pieces.  "Heavy" = bandwidth / LDS bound and filling the chip; "light" =
    * lane-per-channel recurrences on CP/64 workgroups. */
   auto rds_heavy = [&]() {
     /* ---- RDS branch  (stream R): half-bands, 75-tap LPF, PLL, matched filter, bits ---- */
     after(sR, ce[fmd_batch::EV_SER]);
+    post_delay(sR);
     {
       const float2* in = b->mix[q].p;
       for (size_t s = 0; s < d.hb.size(); s++)
@@ -977,9 +998,23 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     /* ---- audio branch  (stream A): resamplers, 15 kHz LPF, de-emphasis / notch / matrix ---- */
     after(sA, ce[fmd_batch::EV_SER]);
     hipLaunchKernelGGL(fmd::k_rs_table, dim3(A), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p,
-                       pstep, A, b->ktab.p, b->pidx.p);
+                       pstep, A, b->ktab.p + fmd::RSL_PAD, b->pidx.p);
+    static const int rs_lds_env = getenv("FMD_RS_LDS") ? atoi(getenv("FMD_RS_LDS")) : 4;
+    // the padded tap table covers the staged kernel's reads for any step the reference can have
+    // (step = fb / 48000 < 9); anything wider takes the plain kernel
+    const int rs_lds =
+        (fmd::RS_R - 1) * (int(pstep) + 1) + fmd::RSL_NB <= fmd::RSL_PAD ? rs_lds_env : 0;
+    if (rs_lds == 8)
+      hipLaunchKernelGGL(fmd::k_resample_lds<8>, dim3(CP / 64, (A + 8 * fmd::RS_R - 1) / (8 * fmd::RS_R)),
+                         dim3(64, 8), 0, sA, b->br[q].p, Hbb, d.rs_order, b->ktab.p + fmd::RSL_PAD, b->pidx.p, A,
+                         b->rs.p, T_alp - 1, C, CP);
+    else if (rs_lds == 4)
+      hipLaunchKernelGGL(fmd::k_resample_lds<4>, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
+                         dim3(64, 4), 0, sA, b->br[q].p, Hbb, d.rs_order, b->ktab.p + fmd::RSL_PAD, b->pidx.p, A,
+                         b->rs.p, T_alp - 1, C, CP);
+    else
     hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
-                       dim3(64, 4), 0, sA, b->br[q].p, Hbb, d.rs_order, b->ktab.p, b->pidx.p, A,
+                       dim3(64, 4), 0, sA, b->br[q].p, Hbb, d.rs_order, b->ktab.p + fmd::RSL_PAD, b->pidx.p, A,
                        b->rs.p, T_alp - 1, C, CP);
     hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hbb), rt, 0, sA, b->br[q].p, b->br[q ^ 1].p, Hbb, M, CP);
     signal(ce[fmd_batch::EV_BRFREE], sA);
@@ -1051,6 +1086,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
         b->light_job.pending = false;
         after(sL, b->cev[prev.es][fmd_batch::EV_HEAVY]);
         after(sL, ce[fmd_batch::EV_SER]);
+        post_delay(sL);
         launch_light(b, prev, sL, true);
       }
       b->light_job = job;
@@ -1582,6 +1618,20 @@ int fmd_debug_math(int what, unsigned n, const float* a, const float* b, float* 
   d1.release();
   tab.release();
   return bad ? fail(FMD_ERR_DEVICE, "fmd_debug_math: device error") : FMD_OK;
+}
+
+int fmd_batch_debug_serial_probe(fmd_batch* b, long long* out, unsigned cap_workgroups)
+{
+  if (!b || !out)
+    return fail(FMD_ERR_ARG, "fmd_batch_debug_serial_probe: null argument");
+  if (!b->serial_probe.p)
+    return 0;
+  const unsigned wgs = std::min<unsigned>(cap_workgroups, unsigned(b->serial_probe.n / 3));
+  // 8 launches x (CP / 64) slots, launch = call index mod 8 (the exclusive form uses every other slot's worth)
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(out, b->serial_probe.p, size_t(wgs) * 3 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(FMD_ERR_DEVICE, "fmd_batch_debug_serial_probe: copy failed");
+  return int(wgs);
 }
 
 /* ---- cRadioReceiver's stream side (csrc/fmd_receiver.hpp) ------------------------------------ */

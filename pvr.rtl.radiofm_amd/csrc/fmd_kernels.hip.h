@@ -558,8 +558,12 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     const float2* __restrict__ demod, unsigned Mstride, unsigned M, unsigned C, unsigned CP,
     DemodConsts k, ChannelState st, float2* __restrict__ br, unsigned Hbb,
     float2* __restrict__ mix, unsigned Hmix, const double* __restrict__ sctab_g, FmdSincosTab sct,
-    unsigned stereo_q)
+    unsigned stereo_q, long long* __restrict__ wg_probe)
 {
+  // dev aid (FMD_SERIAL_PROBE=1): when each workgroup started and ended on the 100 MHz clock, and
+  // its shader-clock cycles in between
+  const long long probe_r0 = wg_probe ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+  const long long probe_c0 = wg_probe ? (long long)__builtin_readcyclecounter() : 0;
   __shared__ float chunk_all[NG][2][DS][64];  // baseband, FM role -> pilot/RDS role
   __shared__ float2 stage_all[NG][2][DS][64]; // IF-FIR output, pilot/RDS role -> FM role
   __shared__ double sctab[2 * FMD_SINCOS_TAB_SIZE];
@@ -796,6 +800,12 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
         st.F(F_BB_LEVEL)[c] = 0.95f * st.F(F_BB_LEVEL)[c] + 0.05f * rms;
       }
     }
+  }
+  if (wg_probe && threadIdx.x == 64) // a pilot/RDS role wave: the last to finish
+  {
+    wg_probe[3 * blockIdx.x] = probe_r0;
+    wg_probe[3 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    wg_probe[3 * blockIdx.x + 2] = (long long)__builtin_readcyclecounter() - probe_c0;
   }
 }
 
@@ -1349,6 +1359,148 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br,
       out[(size_t)(Hout + i0 + r) * CP + c] = make_float2(acc[r].y, acc[r].x);
 }
 
+/* The same filter with the rows staged through LDS: a workgroup owns 64 channels x W*RS_R
+ * consecutive outputs, whose windows overlap almost entirely, and walks the union of them once from
+ * the newest row down in batches of RSL_NB rows (double-buffered, one barrier per batch).  Every row
+ * is fetched from L2 once per workgroup instead of once per wave; wave wy applies the rows of a
+ * batch that fall into the windows of its own RS_R outputs, still in ascending j. */
+constexpr int RSL_NB = 8;
+/* Entries of padding before and after the tap table: a wave reads the taps of a whole batch for all
+ * of its outputs, up to RSL_NB - 1 + (RS_R - 1) * ceil(step) entries outside an output's 0..order. */
+constexpr int RSL_PAD = 64;
+
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_resample_lds(const float2* __restrict__ br, unsigned Hbb,
+                                                         unsigned order,
+                                                         const float* __restrict__ ktab,
+                                                         const int* __restrict__ pidx, unsigned A,
+                                                         float2* __restrict__ out, unsigned Hout,
+                                                         unsigned C, unsigned CP)
+{
+  static_assert(RSL_NB % W == 0, "rows of a batch are split evenly over the waves");
+  constexpr int LR = RSL_NB / W; // rows a wave fetches per batch
+  __shared__ float2 rows[2][RSL_NB][64];
+  const unsigned lane = threadIdx.x;
+  const unsigned c = blockIdx.x * 64 + lane; // < CP: the row buffers are padded to CP
+  const unsigned wy = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
+  const unsigned ib = blockIdx.y * (W * RS_R);
+  const unsigned ilast = min(ib + W * RS_R, A) - 1;
+  const int top_b = pidx[ilast];
+  const int nrows = top_b - (pidx[ib] - (int)order) + 1; // union window of the workgroup
+  const int nbatch = (nrows + RSL_NB - 1) / RSL_NB;
+  const unsigned K1 = order + 1;
+
+  const unsigned i0 = ib + wy * RS_R;
+  const int nr = i0 < A ? (int)min((unsigned)RS_R, A - i0) : 0;
+  const int top_w = nr ? pidx[i0 + nr - 1] : top_b;
+  const int shift = top_b - top_w; // workgroup row t is this wave's row t - shift
+  int off[RS_R];
+  const float* kp[RS_R];
+#pragma unroll
+  for (int r = 0; r < RS_R; r++)
+  {
+    const unsigned idx = nr ? i0 + (unsigned)(r < nr ? r : nr - 1) : ilast;
+    off[r] = top_w - pidx[idx];
+    kp[r] = ktab + (size_t)idx * K1 - off[r];
+  }
+  const int off0 = off[0];
+  const int tend = off0 + (int)order;
+  float2 acc[RS_R];
+#pragma unroll
+  for (int r = 0; r < RS_R; r++)
+    acc[r] = make_float2(0.0f, 0.0f);
+
+  const float2* __restrict__ gp = br + (size_t)(Hbb + (unsigned)top_b) * CP + c;
+  float2 pre[LR];
+  auto fetch = [&](int b) {
+#pragma unroll
+    for (int q = 0; q < LR; q++)
+    {
+      const int t = min(b * RSL_NB + (int)wy * LR + q, nrows - 1); // past the end: a row nobody takes
+      pre[q] = gp[-(ptrdiff_t)t * CP];
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < LR; q++)
+      rows[buf][wy * LR + q][lane] = pre[q];
+  };
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  for (int b = 0; b < nbatch; b++)
+  {
+    const bool more = b + 1 < nbatch;
+    if (more)
+      fetch(b + 1);
+    const int lo = b * RSL_NB - shift; // this wave's row index of the batch's first row
+    if (nr && lo + RSL_NB > 0 && lo <= tend)
+    {
+      float2 xs[RSL_NB];
+#pragma unroll
+      for (int q = 0; q < RSL_NB; q++)
+        xs[q] = rows[b & 1][q][lane];
+      // the batch's taps of every output, whether the output takes the row or not (wide scalar
+      // loads; the table is padded by RSL_PAD entries on either side for the rows outside 0..order)
+      float kk[RS_R][RSL_NB];
+#pragma unroll
+      for (int r = 0; r < RS_R; r++)
+      {
+#pragma unroll
+        for (int q = 0; q < RSL_NB; q++)
+          kk[r][q] = kp[r][lo + q];
+      }
+      if (lo >= off0 && lo + RSL_NB - 1 <= (int)order)
+      { // every output of the wave takes every row of the batch
+#pragma unroll
+        for (int q = 0; q < RSL_NB; q++)
+        {
+#pragma unroll
+          for (int r = 0; r < RS_R; r++)
+          {
+            acc[r].x += kk[r][q] * xs[q].x;
+            acc[r].y += kk[r][q] * xs[q].y;
+          }
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int r = 0; r < RS_R; r++)
+        {
+#pragma unroll
+          for (int q = 0; q < RSL_NB; q++)
+            asm volatile("" : "+s"(kk[r][q])); // keeps the loads above the tests
+        }
+#pragma unroll
+        for (int q = 0; q < RSL_NB; q++)
+        {
+#pragma unroll
+          for (int r = 0; r < RS_R; r++)
+          {
+            const int j = lo + q - off[r];
+            if (j >= 0 && j <= (int)order)
+            {
+              acc[r].x += kk[r][q] * xs[q].x;
+              acc[r].y += kk[r][q] * xs[q].y;
+            }
+          }
+        }
+      }
+    }
+    if (more)
+      stage((b + 1) & 1);
+    __syncthreads();
+  }
+  if (c < C)
+  {
+#pragma unroll
+    for (int r = 0; r < RS_R; r++)
+      if (r < nr) // (stereo, mono) = ProcessTwo's (A, B): x came from baseband -> mono
+        out[(size_t)(Hout + i0 + r) * CP + c] = make_float2(acc[r].y, acc[r].x);
+  }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* K8: audio tail, one lane per channel: ProcessDeemphasisFilter (FmDecode.cpp:348-359),        */
 /*     19 kHz notch cIirFilter::ProcessTwo (IirFilter.cpp:89-105), L/R matrix (:473-499).       */
@@ -1465,6 +1617,15 @@ __global__ void k_probe_spin(long long cycles, int* sink)
   if (sink && n < 0)
     *sink = n;
 }
+/* One wave that does nothing for `ticks` of the 100 MHz clock (see the post chain's start in
+ * fmd_batch.hip). */
+__global__ void k_delay(unsigned ticks)
+{
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks)
+    __builtin_amdgcn_s_sleep(4);
+}
+
 __global__ void k_probe_nop(int* sink)
 {
   if (sink && threadIdx.x == 12345)
