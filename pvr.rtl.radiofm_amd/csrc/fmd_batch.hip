@@ -113,6 +113,7 @@ struct fmd_batch
   DevBuf<float> rpll, rmf, tap_sync;
   DevBuf<double> sctab;
   DevBuf<int> pidx;
+  unsigned rs_pad = 0; // entries before / after ktab (fmd::rs_table_pad)
   DevBuf<long long> serial_probe; // FMD_SERIAL_PROBE=1: per-workgroup timing of the serial stage
   DevBuf<float> fstate; // all float state arrays, CP each
   DevBuf<int> istate;
@@ -471,7 +472,8 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->rds_lpf_taps.alloc(T_lpf);
   bad |= b->mf_taps2.alloc(size_t(2) * T_mf);
   bad |= b->audio_taps.alloc(T_alp);
-  bad |= b->ktab.alloc(size_t(b->Amax) * (d.rs_order + 1) + 2 * fmd::RSL_PAD); // padded: k_resample_lds
+  b->rs_pad = fmd::rs_table_pad(d.rs_step);
+  bad |= b->ktab.alloc(size_t(b->Amax) * (d.rs_order + 1) + 2 * b->rs_pad); // padded: k_resample
   bad |= b->pidx.alloc(b->Amax);
   if (getenv("FMD_SERIAL_PROBE") && atoi(getenv("FMD_SERIAL_PROBE")))
     bad |= b->serial_probe.alloc(size_t(8) * 3 * (b->CP / 64)); // the last 8 launches
@@ -998,23 +1000,9 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     /* ---- audio branch  (stream A): resamplers, 15 kHz LPF, de-emphasis / notch / matrix ---- */
     after(sA, ce[fmd_batch::EV_SER]);
     hipLaunchKernelGGL(fmd::k_rs_table, dim3(A), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p,
-                       pstep, A, b->ktab.p + fmd::RSL_PAD, b->pidx.p);
-    static const int rs_lds_env = getenv("FMD_RS_LDS") ? atoi(getenv("FMD_RS_LDS")) : 4;
-    // the padded tap table covers the staged kernel's reads for any step the reference can have
-    // (step = fb / 48000 < 9); anything wider takes the plain kernel
-    const int rs_lds =
-        (fmd::RS_R - 1) * (int(pstep) + 1) + fmd::RSL_NB <= fmd::RSL_PAD ? rs_lds_env : 0;
-    if (rs_lds == 8)
-      hipLaunchKernelGGL(fmd::k_resample_lds<8>, dim3(CP / 64, (A + 8 * fmd::RS_R - 1) / (8 * fmd::RS_R)),
-                         dim3(64, 8), 0, sA, b->br[q].p, Hbb, d.rs_order, b->ktab.p + fmd::RSL_PAD, b->pidx.p, A,
-                         b->rs.p, T_alp - 1, C, CP);
-    else if (rs_lds == 4)
-      hipLaunchKernelGGL(fmd::k_resample_lds<4>, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
-                         dim3(64, 4), 0, sA, b->br[q].p, Hbb, d.rs_order, b->ktab.p + fmd::RSL_PAD, b->pidx.p, A,
-                         b->rs.p, T_alp - 1, C, CP);
-    else
+                       pstep, A, b->ktab.p + b->rs_pad, b->pidx.p);
     hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
-                       dim3(64, 4), 0, sA, b->br[q].p, Hbb, d.rs_order, b->ktab.p + fmd::RSL_PAD, b->pidx.p, A,
+                       dim3(64, 4), 0, sA, b->br[q].p, Hbb, d.rs_order, b->ktab.p + b->rs_pad, b->pidx.p, A,
                        b->rs.p, T_alp - 1, C, CP);
     hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hbb), rt, 0, sA, b->br[q].p, b->br[q ^ 1].p, Hbb, M, CP);
     signal(ce[fmd_batch::EV_BRFREE], sA);
