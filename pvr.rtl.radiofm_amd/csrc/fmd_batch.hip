@@ -113,7 +113,8 @@ struct fmd_batch
   DevBuf<float> rpll, rmf, tap_sync;
   DevBuf<double> sctab;
   DevBuf<int> pidx;
-  unsigned rs_pad = 0; // entries before / after ktab (fmd::rs_table_pad)
+  float2* brp(int q) const { return br[q].p + size_t(fmd::RS_B) * CP; } // row 0 of br[q]
+  unsigned rs_margin = 0, rs_row = 0; // ktab: zero entries around each output's taps, row length
   DevBuf<long long> serial_probe; // FMD_SERIAL_PROBE=1: per-workgroup timing of the serial stage
   DevBuf<float> fstate; // all float state arrays, CP each
   DevBuf<int> istate;
@@ -451,8 +452,9 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->demod[1].alloc(size_t(b->Mstride) * C);
   bad |= b->if_coeff.alloc(d.if_coeff.size() + 64); // zero padding: fir_long_e1_asm's dummy load
   bad |= b->rs_coeff.alloc(d.rs_coeff.size());
-  bad |= b->br[0].alloc(size_t(d.rs_order + b->Mmax) * CP);
-  bad |= b->br[1].alloc(size_t(d.rs_order + b->Mmax) * CP);
+  // RS_B rows of zeros in front: the resampler's last batch may reach that far below its window
+  bad |= b->br[0].alloc(size_t(fmd::RS_B + d.rs_order + b->Mmax) * CP);
+  bad |= b->br[1].alloc(size_t(fmd::RS_B + d.rs_order + b->Mmax) * CP);
   if (d.hb.empty())
     return fail(FMD_ERR_ARG, "baseband rate too low for the RDS decimation chain");
   bad |= b->mix[0].alloc(size_t(d.hb[0].len - 1 + b->Mmax) * CP);
@@ -472,8 +474,9 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->rds_lpf_taps.alloc(T_lpf);
   bad |= b->mf_taps2.alloc(size_t(2) * T_mf);
   bad |= b->audio_taps.alloc(T_alp);
-  b->rs_pad = fmd::rs_table_pad(d.rs_step);
-  bad |= b->ktab.alloc(size_t(b->Amax) * (d.rs_order + 1) + 2 * b->rs_pad); // padded: k_resample
+  b->rs_margin = fmd::rs_table_margin(d.rs_step); // zeros around every output's taps: k_resample
+  b->rs_row = d.rs_order + 1 + 2 * b->rs_margin;
+  bad |= b->ktab.alloc(size_t(b->Amax) * b->rs_row + 64);
   bad |= b->pidx.alloc(b->Amax);
   if (getenv("FMD_SERIAL_PROBE") && atoi(getenv("FMD_SERIAL_PROBE")))
     bad |= b->serial_probe.alloc(size_t(8) * 3 * (b->CP / 64)); // the last 8 launches
@@ -904,12 +907,12 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     const unsigned Hmix = unsigned(d.hb[0].len - 1);
     if (b->serial_exclusive && !serial_mode)
       hipLaunchKernelGGL((fmd::k_demod_serial<2, true>), dim3((groups + 1) / 2), dim3(256), 0, sS,
-                         b->demod[q].p, b->Mstride, M, C, CP, k, b->st, b->br[q].p, Hbb, b->mix[q].p,
+                         b->demod[q].p, b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p,
                          Hmix, b->sctab.p, sct, unsigned(q),
                          b->serial_probe.p ? b->serial_probe.p + size_t(b->call_index % 8) * 3 * (CP / 64) : nullptr);
     else
       hipLaunchKernelGGL((fmd::k_demod_serial<1, false>), dim3(groups), dim3(128), 0, sS, b->demod[q].p,
-                         b->Mstride, M, C, CP, k, b->st, b->br[q].p, Hbb, b->mix[q].p, Hmix,
+                         b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p, Hmix,
                          b->sctab.p, sct, unsigned(q),
                          b->serial_probe.p ? b->serial_probe.p + size_t(b->call_index % 8) * 3 * (CP / 64) : nullptr);
   }
@@ -1000,11 +1003,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     /* ---- audio branch  (stream A): resamplers, 15 kHz LPF, de-emphasis / notch / matrix ---- */
     after(sA, ce[fmd_batch::EV_SER]);
     hipLaunchKernelGGL(fmd::k_rs_table, dim3(A), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p,
-                       pstep, A, b->ktab.p + b->rs_pad, b->pidx.p);
+                       pstep, A, b->ktab.p, b->rs_row, b->rs_margin, b->pidx.p);
     hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
-                       dim3(64, 4), 0, sA, b->br[q].p, Hbb, d.rs_order, b->ktab.p + b->rs_pad, b->pidx.p, A,
-                       b->rs.p, T_alp - 1, C, CP);
-    hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hbb), rt, 0, sA, b->br[q].p, b->br[q ^ 1].p, Hbb, M, CP);
+                       dim3(64, 4), 0, sA, b->brp(q), Hbb, d.rs_order, b->ktab.p, b->rs_row,
+                       b->rs_margin, b->pidx.p, A, b->rs.p, T_alp - 1, C, CP);
+    hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hbb), rt, 0, sA, b->brp(q), b->brp(q ^ 1), Hbb, M, CP);
     signal(ce[fmd_batch::EV_BRFREE], sA);
     mark(6);
     hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (A + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
@@ -1375,7 +1378,7 @@ int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsig
       rows = b->lastM;
       if (rows > cap_floats)
         return fail(FMD_ERR_ARG, "tap buffer too small");
-      const char* s0 = reinterpret_cast<const char*>(b->br[b->call_index & 1u].p) +
+      const char* s0 = reinterpret_cast<const char*>(b->brp(int(b->call_index & 1u))) +
                        (size_t(b->des.rs_order) * CP + channel) * 8 + (tap == FMD_TAP_PILOT38 ? 4 : 0);
       if (rows)
         HIPCHK(hipMemcpy2D(out, 4, s0, CP * 8, 4, rows, hipMemcpyDeviceToHost));

@@ -1219,8 +1219,10 @@ __global__ __launch_bounds__(64) void k_rds_bits(const float* __restrict__ mf, u
 /*     filter proper is a plain per-output dot product over the window, in j order.             */
 /* ------------------------------------------------------------------------------------------ */
 __global__ void k_rs_table(const float* __restrict__ coeff, unsigned order, float p, float pstep,
-                           unsigned A, float* __restrict__ ktab, int* __restrict__ pidx)
-{
+                           unsigned A, float* __restrict__ ktab, unsigned row_stride, unsigned margin,
+                           int* __restrict__ pidx)
+{ // row i = [margin zeros][k_0 .. k_order][margin zeros]; the margins are never written (zero since
+  // allocation): a tap index outside 0..order reads an exact zero
   const unsigned i = blockIdx.x;
   if (i >= A)
     return;
@@ -1229,7 +1231,7 @@ __global__ void k_rs_table(const float* __restrict__ coeff, unsigned order, floa
   const float k1 = pf - (float)pi;
   const float k0 = 1 - k1;
   for (unsigned j = threadIdx.x; j <= order; j += blockDim.x)
-    ktab[(size_t)i * (order + 1) + j] = coeff[j] * k0 + coeff[j + 1] * k1;
+    ktab[(size_t)i * row_stride + margin + j] = coeff[j] * k0 + coeff[j + 1] * k1;
   if (threadIdx.x == 0)
     pidx[i] = pi;
 }
@@ -1242,23 +1244,26 @@ __global__ void k_rs_table(const float* __restrict__ coeff, unsigned order, floa
 #endif
 constexpr int RS_R = FMD_RS_R; // outputs per thread; their windows overlap by ~(order - 4.5*7) rows
 constexpr int RS_B = FMD_RS_B; // rows per batch: RS_R * RS_B taps live in SGPRs at a time
-/* Entries of padding the host puts before and after the tap table: a wave reads the taps of a whole
- * batch for all of its outputs, up to RS_B - 1 + (RS_R - 1) * ceil(step) entries outside an output's
- * 0..order. */
-inline unsigned rs_table_pad(float step)
+/* Zero entries the host leaves before and after every output's taps in the table: a wave reads the
+ * taps of a whole batch for all of its outputs, up to RS_B - 1 + (RS_R - 1) * ceil(step) entries
+ * outside an output's 0..order. */
+inline unsigned rs_table_margin(float step)
 {
-  return unsigned(RS_B + (RS_R - 1) * (int(step) + 2) + 63) / 64 * 64;
+  return unsigned(RS_B + (RS_R - 1) * (int(step) + 2) + 7) / 8 * 8;
 }
 
 /* Thread = (channel lane, group of RS_R consecutive outputs).  The union of the group's windows is
  * walked once from the newest row down in batches of RS_B rows; row `top - t` feeds output r with
  * tap j = t - off_r (off_r = top - pidx[r]), so every output still accumulates in ascending j like
- * the reference.  The taps of a batch are fetched for all outputs with wide scalar loads whether an
- * output takes the row or not (hence the padded table); inside the common part of the windows the
- * batch runs without tests.  in = (baseband, raw-stereo) pairs, so both resamplers share each load
- * and each tap. */
+ * the reference.  Rows of the union outside an output's own window meet a ZERO tap from the table's
+ * margins: the product is +-0 and leaves the sum as it is, bit for bit (a sum that started at +0
+ * is never -0), so every batch runs the same test-free code with wide scalar tap loads.  That holds
+ * for finite samples only; a batch at the edge of the windows that holds an infinity or a NaN
+ * (0 * inf = NaN) takes the literal per-output tests instead (wave-uniform, never in practice).
+ * in = (baseband, raw-stereo) pairs, so both resamplers share each load and each tap. */
 __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br, unsigned Hbb,
                                                   unsigned order, const float* __restrict__ ktab,
+                                                  unsigned row_stride, unsigned margin,
                                                   const int* __restrict__ pidx, unsigned A,
                                                   float2* __restrict__ out, unsigned Hout, unsigned C,
                                                   unsigned CP)
@@ -1266,10 +1271,9 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br,
   const unsigned c = blockIdx.x * 64 + threadIdx.x;
   const unsigned wy = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y); // wave-uniform
   const unsigned i0 = (blockIdx.y * blockDim.y + wy) * RS_R;
-  if (c >= C || i0 >= A)
+  if (i0 >= A)
     return;
   const int nr = (int)min((unsigned)RS_R, A - i0);
-  const unsigned K1 = order + 1;
   int off[RS_R];
   const float* kp[RS_R]; // kp[r][t] = tap of output r for window row t
   const int top = pidx[i0 + nr - 1];
@@ -1278,13 +1282,17 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br,
   { // a partial last group computes its last output more than once (not stored)
     const int rr = r < nr ? r : nr - 1;
     off[r] = top - pidx[i0 + rr];
-    kp[r] = ktab + (size_t)(i0 + rr) * K1 - off[r];
+    kp[r] = ktab + (size_t)(i0 + rr) * row_stride + margin - off[r];
   }
   float2 acc[RS_R];
 #pragma unroll
   for (int r = 0; r < RS_R; r++)
     acc[r] = make_float2(0.0f, 0.0f);
-  const float2* __restrict__ p = br + (size_t)(Hbb + (unsigned)top) * CP + c;
+  // wave-uniform row pointer + 32-bit lane offset (c < CP: the row buffers are padded to CP lanes,
+  // and the host keeps RS_B rows of zeros in front of row 0 for the last batch's overhang)
+  const char* __restrict__ rp = reinterpret_cast<const char*>(br + (size_t)(Hbb + (unsigned)top) * CP);
+  const unsigned lane_off = c * (unsigned)sizeof(float2);
+  const size_t row_bytes = (size_t)CP * sizeof(float2);
   const int off0 = off[0];            // largest offset (oldest output of the group)
   const int tend = off0 + (int)order; // last row of the union window
 
@@ -1292,8 +1300,11 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br,
   {
     float2 xs[RS_B];
 #pragma unroll
-    for (int q = 0; q < RS_B; q++)
-      xs[q] = p[-(ptrdiff_t)min(t + q, tend) * CP]; // past the end: a row nobody takes
+    for (int q = 0; q < RS_B; q++) // past the end of the window: rows nobody takes (zero taps)
+    {
+      xs[q] = *reinterpret_cast<const float2*>(rp + lane_off);
+      rp -= row_bytes;
+    }
     float kk[RS_R][RS_B];
 #pragma unroll
     for (int r = 0; r < RS_R; r++)
@@ -1302,8 +1313,17 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br,
       for (int q = 0; q < RS_B; q++)
         kk[r][q] = kp[r][t + q];
     }
-    if (t >= off0 && t + RS_B - 1 <= (int)order)
-    { // every output of the group takes every row of the batch
+    bool literal = false;
+    if (!(t >= off0 && t + RS_B - 1 <= (int)order))
+    { // a batch with rows outside some output's window: zero taps are only exact for finite samples
+      bool fin = true;
+#pragma unroll
+      for (int q = 0; q < RS_B; q++)
+        fin = fin && __builtin_isfinite(xs[q].x) && __builtin_isfinite(xs[q].y);
+      literal = FMD_ANY_LANE(!fin);
+    }
+    if (!literal)
+    {
 #pragma unroll
       for (int q = 0; q < RS_B; q++)
       {
@@ -1317,13 +1337,6 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br,
     }
     else
     {
-#pragma unroll
-      for (int r = 0; r < RS_R; r++)
-      {
-#pragma unroll
-        for (int q = 0; q < RS_B; q++)
-          asm volatile("" : "+s"(kk[r][q])); // keeps the loads above the tests
-      }
 #pragma unroll
       for (int q = 0; q < RS_B; q++)
       {
@@ -1340,10 +1353,13 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br,
       }
     }
   }
+  if (c < C)
+  {
 #pragma unroll
-  for (int r = 0; r < RS_R; r++)
-    if (r < nr) // (stereo, mono) = ProcessTwo's (A, B): x came from baseband -> mono
-      out[(size_t)(Hout + i0 + r) * CP + c] = make_float2(acc[r].y, acc[r].x);
+    for (int r = 0; r < RS_R; r++)
+      if (r < nr) // (stereo, mono) = ProcessTwo's (A, B): x came from baseband -> mono
+        out[(size_t)(Hout + i0 + r) * CP + c] = make_float2(acc[r].y, acc[r].x);
+  }
 }
 
 /* Measured and dropped: the rows of a workgroup's 16 outputs staged once through LDS (double-buffered
