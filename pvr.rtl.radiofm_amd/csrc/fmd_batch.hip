@@ -163,7 +163,7 @@ struct fmd_batch
   } light_job;
   bool split_post = false;
   bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
-  enum { EV_IN, EV_FIR, EV_SER, EV_BRFREE, EV_MIXFREE, EV_AUD, EV_RDS, EV_HEAVY, EV_N };
+  enum { EV_IN, EV_FIR, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_N };
   hipEvent_t cev[NSLOT][EV_N] = {};
   bool cev_ready = false;
   uint32_t slot_call[NSLOT] = {}; // call index that last used the slot (0 = never)
@@ -875,12 +875,10 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   signal(ce[fmd_batch::EV_FIR], sF);
 
   /* ---- K2: baseband-rate recurrences  (stream S) ---- */
+  // br[q] / mix[q] were last read by the resampler / first half-band two calls ago: this call's FIR
+  // already waited for that call's whole heavy part (EV_HEAVY above), so EV_FIR covers them and the
+  // serial stream carries one wait instead of three between two serial stages
   after(sS, ce[fmd_batch::EV_FIR]);
-  if (have_prev2)
-  { // br[q] / mix[q] were last read by the resampler / first half-band two calls ago
-    after(sS, pe2[fmd_batch::EV_BRFREE]);
-    after(sS, pe2[fmd_batch::EV_MIXFREE]);
-  }
   {
     fmd::DemodConsts k{};
     k.pll_alpha = d.pll_alpha;
@@ -958,7 +956,6 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
         { // tail of mix[q] -> history rows of mix[q^1], which the next call's half-band reads
           hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->mix[q].p, b->mix[q ^ 1].p, Hs,
                              hb_in[0], CP);
-          signal(ce[fmd_batch::EV_MIXFREE], sR);
         }
         else
           hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->hbbuf[s - 1].p,
@@ -1008,7 +1005,6 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                        dim3(64, 4), 0, sA, b->brp(q), Hbb, d.rs_order, b->ktab.p, b->rs_row,
                        b->rs_margin, b->pidx.p, A, b->rs.p, T_alp - 1, C, CP);
     hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hbb), rt, 0, sA, b->brp(q), b->brp(q ^ 1), Hbb, M, CP);
-    signal(ce[fmd_batch::EV_BRFREE], sA);
     mark(6);
     hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (A + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
                        size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), sA, b->rs.p, b->alp[q].p, A,
