@@ -317,7 +317,22 @@ def main():
     serial_probe = None
     if os.environ.get("FMD_SERIAL_PROBE"):  # dev aid: per-workgroup timing of the serial stage
         pr = batch.debug_serial_probe()
+        where = pr[:, :, 2] >> 40          # CU/SH/SE byte of HW_ID, XCC id above it
+        pr[:, :, 2] &= (1 << 40) - 1
         serial_probe = []
+        if os.environ.get("FMD_PROBE_RAW"):  # per launch: the slow workgroups (index: xcc.se.cu)
+            order = np.argsort(pr[:, 0, 0])
+            for l in order:
+                u = pr[l]
+                if not (u[:, 1] > 0).any():
+                    continue
+                cyc = u[:, 2] / 1e6
+                w = where[l]
+                thr = cyc[u[:, 1] > 0].min() * 1.05
+                slow = [i for i in range(len(u)) if u[i, 1] > 0 and cyc[i] > thr]
+                print("PROBE_RAW launch", int(l), "min Mcyc", round(float(cyc[u[:, 1] > 0].min()), 3), "slow:",
+                      " ".join("%d:%d.%d.%d" % (i, int(w[i] >> 8), int(w[i] & 0xff) >> 5, int(w[i] & 0xf))
+                               for i in slow), file=sys.stderr)
         for l in range(pr.shape[0]):
             u = pr[l][pr[l][:, 1] > 0]
             if len(u):

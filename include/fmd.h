@@ -243,7 +243,7 @@ int fmd_debug_math(int what, unsigned n, const float* a, const float* b, float* 
 
 /* Dev aid, only with FMD_SERIAL_PROBE=1 in the environment at batch creation: per workgroup of the
  * serial stage's last 8 launches, (start, end) on the device's 100 MHz clock and the shader-clock
- * cycles in between: 8 x (padded channels / 64) records of 3 x int64, launch = call index mod 8,
+ * cycles in between (low 40 bits; HW_ID bits 8-15 and XCC_ID above): 8 x (padded channels / 64) records of 3 x int64, launch = call index mod 8,
  * records of workgroups that did not exist stay zero.  Returns the number of records written (0
  * when the probe is off).  Synchronises the device. */
 int fmd_batch_debug_serial_probe(fmd_batch* b, long long* out, unsigned cap_workgroups);

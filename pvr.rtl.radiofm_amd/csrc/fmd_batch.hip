@@ -448,8 +448,9 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->lut.alloc(size_t(d.table_size) * C);
   bad |= b->hist[0].alloc(size_t(d.if_order) * C);
   bad |= b->hist[1].alloc(size_t(d.if_order) * C);
-  bad |= b->demod[0].alloc(size_t(b->Mstride) * C);
-  bad |= b->demod[1].alloc(size_t(b->Mstride) * C);
+  // + DS: the serial stage loads whole chunks, also behind the last sample of the last channel
+  bad |= b->demod[0].alloc(size_t(b->Mstride) * C + fmd::DS);
+  bad |= b->demod[1].alloc(size_t(b->Mstride) * C + fmd::DS);
   bad |= b->if_coeff.alloc(d.if_coeff.size() + 64); // zero padding: fir_long_e1_asm's dummy load
   bad |= b->rs_coeff.alloc(d.rs_coeff.size());
   // RS_B rows of zeros in front: the resampler's last batch may reach that far below its window

@@ -676,9 +676,8 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
             const bool far = !(fabsf(nco_phase - 3.1415927f) < 9.4f) | (incr0 != incr0);
             nco_phase = (ge | lt) ? moved : nco_phase;
             const bool redo = lit | far;
-            if (FMD_ANY_LANE(redo))
+            if (__builtin_expect(redo, 0))
             {
-              if (redo)
               {
                 const float e2 = lit ? -fmd_atan2f(dim, dre) : err;
                 float in2 = incr0 + k.pll_beta * e2;
@@ -720,6 +719,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     // are the staged chunk's, and nothing in the sample loop waits for them
     __builtin_amdgcn_s_waitcnt(0);
     float vsum = 0.0f, vsumsq = 0.0f;
+    const bool any_active = __builtin_amdgcn_ballot_w64(active) != 0; // else the stores are branched over
     float2* __restrict__ brp = br + (size_t)Hbb * CP + c; // (baseband, 38 kHz * 2 * baseband)
     float2* __restrict__ mixp = mix + (size_t)Hmix * CP + c;
     for (unsigned j = 0; j <= nchunks; j++)
@@ -731,13 +731,44 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
        * no margin against HBM latency once other kernels use the memory system). */
       const unsigned pf0 = (j + 1) * DS; // first sample of the chunk being staged
       const bool staging = (j + 1) < nchunks;
-      float2 pre[DS];
-      if (staging)
+      /* Whole chunks in the whole-CU form: loads and their wait written by hand.  The compiler cannot
+       * count the sample loop's stores, so in front of the LDS writes below it waits for the wave's
+       * LAST operations too -- the two stores of the sample just finished, 3-8 us under load --
+       * and a second wave that late makes the FM wave wait (seen per workgroup with the probe: up
+       * to +13 % cycles, in a third of the workgroups of a launch).  Vector memory operations
+       * retire in issue order: with the 64 stores of a full chunk behind the 32 loads,
+       * `s_waitcnt vmcnt(63)` is enough, and the oldest of those stores is a chunk old.
+       * (A ragged last chunk is loaded whole: the host leaves DS samples of slack behind the last
+       * channel's row; what lies beyond M is never used.) */
+      float2 pre[DS], pre_h[DS];
+      if (PAIRSYNC)
+      {
+        if (staging)
+        {
+        const float2* src = row + pf0;
+#pragma unroll
+        for (unsigned u = 0; u < DS; u += 8)
+          asm volatile("global_load_dwordx2 %0, %8, off offset:%9\n\t"
+                       "global_load_dwordx2 %1, %8, off offset:%9+8\n\t"
+                       "global_load_dwordx2 %2, %8, off offset:%9+16\n\t"
+                       "global_load_dwordx2 %3, %8, off offset:%9+24\n\t"
+                       "global_load_dwordx2 %4, %8, off offset:%9+32\n\t"
+                       "global_load_dwordx2 %5, %8, off offset:%9+40\n\t"
+                       "global_load_dwordx2 %6, %8, off offset:%9+48\n\t"
+                       "global_load_dwordx2 %7, %8, off offset:%9+56"
+                       : "=&v"(pre_h[u]), "=&v"(pre_h[u + 1]), "=&v"(pre_h[u + 2]), "=&v"(pre_h[u + 3]),
+                         "=&v"(pre_h[u + 4]), "=&v"(pre_h[u + 5]), "=&v"(pre_h[u + 6]), "=&v"(pre_h[u + 7])
+                       : "v"(src), "n"(u * 8)
+                       : "memory");
+        }
+      }
+      else if (staging)
       {
 #pragma unroll
         for (unsigned u = 0; u < DS; u++)
           pre[u] = row[min(pf0 + u, M - 1)];
       }
+      unsigned stores_behind = 0; // vector stores issued behind those loads
       if (PAIRSYNC && j >= 1) // chunk j - 1 written, stage[(j + 1) & 1] read: FM wave done with j - 1
         lds_wait_ge(done_fm, j);
       if (j >= 1)
@@ -802,8 +833,22 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           brp += CP;
           mixp += CP;
         }
+        stores_behind = any_active ? 2 * cnt : 0;
       }
-      if (staging)
+      if (PAIRSYNC)
+      {
+        if (staging)
+        {
+          if (stores_behind >= 64)
+            asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (unsigned u = 0; u < DS; u++)
+            stage[(j + 1) & 1][u][lane] = pre_h[u];
+        }
+      }
+      else if (staging)
       {
 #pragma unroll
         for (unsigned u = 0; u < DS; u++)
@@ -853,7 +898,13 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
   {
     wg_probe[3 * blockIdx.x] = probe_r0;
     wg_probe[3 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
-    wg_probe[3 * blockIdx.x + 2] = (long long)__builtin_readcyclecounter() - probe_c0;
+    // cycles in the low 40 bits; above them where the workgroup ran: HW_ID (bits 8-15: CU, SH, SE)
+    // and XCC_ID
+    const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    const unsigned xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    wg_probe[3 * blockIdx.x + 2] = (((long long)__builtin_readcyclecounter() - probe_c0) & 0xffffffffffll) |
+                                   ((long long)((hw_id >> 8) & 0xffu) << 40) |
+                                   ((long long)(xcc_id & 0xfu) << 48);
   }
 }
 
