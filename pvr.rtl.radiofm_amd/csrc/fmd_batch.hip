@@ -163,7 +163,7 @@ struct fmd_batch
   } light_job;
   bool split_post = false;
   bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
-  enum { EV_IN, EV_FIR, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_N };
+  enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_N };
   hipEvent_t cev[NSLOT][EV_N] = {};
   bool cev_ready = false;
   uint32_t slot_call[NSLOT] = {}; // call index that last used the slot (0 = never)
@@ -866,14 +866,20 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     after(sF, pe2[fmd_batch::EV_HEAVY]);
   }
   {
-    const std::function<void(int)> markfn = mark;
+    // EV_FIR right behind the FIR kernel (the serial stage waits for nothing else); the level meter
+    // behind it also reads the input: EV_INDONE is what tells the caller its buffer is free
+    const std::function<void(int)> markfn = [&](int i) {
+      mark(i);
+      if (i == 1)
+        signal(ce[fmd_batch::EV_FIR], sF);
+    };
     const int rc = fmt == IQ_U8
                        ? launch_if_stage<fmd::InU8>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn)
                        : launch_if_stage<fmd::InF32>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn);
     if (rc != FMD_OK)
       return rc;
   }
-  signal(ce[fmd_batch::EV_FIR], sF);
+  signal(ce[fmd_batch::EV_INDONE], sF);
 
   /* ---- K2: baseband-rate recurrences  (stream S) ---- */
   // br[q] / mix[q] were last read by the resampler / first half-band two calls ago: this call's FIR
@@ -965,6 +971,12 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       }
     }
     mark(3);
+    static const int ring4 = getenv("FMD_RING4") ? atoi(getenv("FMD_RING4")) : 1;
+    if (ring4 && T_lpf >= 4)
+      hipLaunchKernelGGL(fmd::k_ring_fir4, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
+                         sR, b->rdsraw.p, b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C,
+                         CP, 0u);
+    else
     hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
                        size_t(T_lpf - 1 + fmd::RF_TI) * 64 * sizeof(float2), sR, b->rdsraw.p,
                        b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C, CP, 0u);
@@ -1007,6 +1019,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                        b->rs_margin, b->pidx.p, A, b->rs.p, T_alp - 1, C, CP);
     hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hbb), rt, 0, sA, b->brp(q), b->brp(q ^ 1), Hbb, M, CP);
     mark(6);
+    static const int ring4a = getenv("FMD_RING4") ? atoi(getenv("FMD_RING4")) : 1;
+    if (ring4a && T_alp >= 4)
+      hipLaunchKernelGGL(fmd::k_ring_fir4, dim3(CP / 64, (A + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
+                         sA, b->rs.p, b->alp[q].p, A, int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
+    else
     hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (A + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
                        size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), sA, b->rs.p, b->alp[q].p, A,
                        int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
@@ -1092,7 +1109,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   { // order the caller's stream after everything this call launched
     (void)hipStreamWaitEvent(stream, ce[fmd_batch::EV_AUD], 0);
     (void)hipStreamWaitEvent(stream, ce[fmd_batch::EV_RDS], 0);
-    (void)hipStreamWaitEvent(stream, ce[fmd_batch::EV_FIR], 0);
+    (void)hipStreamWaitEvent(stream, ce[fmd_batch::EV_INDONE], 0);
   }
 
   /* ---- advance the host-tracked positions ---- */
@@ -1150,7 +1167,7 @@ int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream_)
     {
       HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_AUD], 0));
       HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_RDS], 0));
-      HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_FIR], 0));
+      HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_INDONE], 0));
     }
   return FMD_OK;
 }

@@ -1038,6 +1038,102 @@ __global__ __launch_bounds__(256) void k_ring_fir(const E* __restrict__ in, E* _
   }
 }
 
+/* The same filter for the two float2 instances on the heavy part of the post chain (RDS low-pass,
+ * audio low-pass), without LDS and without a barrier: thread = (channel lane, RG consecutive
+ * outputs), rows straight from L2 / L1.  Output i sums times B, B-1, ..., i-T+1 and then i, i-1,
+ * ..., B+1 with B = i - ((g0 + i) mod T), the time of the sample in ring slot 0; consecutive
+ * outputs of one ring period share B, so a group walks the rows all of its outputs take once
+ * (four taps per row, contiguous in the table: age = output - row), and the few rows only some of
+ * them take on their own.  Every output's accumulator starts at -0 (x + -0 = x for every x), the
+ * order is the reference's.  A group that straddles a ring period is done as two groups. */
+constexpr int RG = 4;
+
+template <int RR>
+__device__ __forceinline__ void ring_group(const float2* __restrict__ in, float2* __restrict__ out,
+                                           unsigned i, int T, const float* __restrict__ taps,
+                                           unsigned g0, unsigned c, unsigned CP, unsigned Hout, bool store)
+{
+  const int a0 = (int)((g0 + i) % (unsigned)T); // a0 + RR - 1 <= T - 1: one ring period
+  float2 acc[RR];
+#pragma unroll
+  for (int r = 0; r < RR; r++)
+    acc[r] = make_float2(-0.0f, -0.0f);
+  // buffer row of time t is T - 1 + t
+  const float2* __restrict__ p1 = in + (size_t)((unsigned)T - 1 + i - (unsigned)a0) * CP + c; // time B
+  const float* __restrict__ k1 = taps + a0;
+  const int n1 = T - a0 - (RR - 1); // rows B .. i+RR-T, taken by every output: ages a0 + r + s
+#pragma unroll 8
+  for (int s = 0; s < n1; s++)
+  {
+    const float2 x = *p1;
+    p1 -= CP;
+#pragma unroll
+    for (int r = 0; r < RR; r++)
+      rf_acc(acc[r], k1[s + r], x);
+  }
+#pragma unroll
+  for (int m = 0; m < RR - 1; m++) // the oldest rows: output r takes RR-1-r of them, up to age T-1
+  {
+    const float2 x = *p1;
+    p1 -= CP;
+#pragma unroll
+    for (int r = 0; r < RR - 1 - m; r++)
+      rf_acc(acc[r], taps[T - (RR - 1) + r + m], x);
+  }
+  const float2* __restrict__ p2 = in + (size_t)((unsigned)T - 1 + i + RR - 1) * CP + c; // time i+RR-1
+#pragma unroll
+  for (int m = 0; m < RR - 1; m++) // the newest rows: output r takes the last r of them, from age 0
+  {
+    const float2 x = *p2;
+    p2 -= CP;
+#pragma unroll
+    for (int r = RR - 1 - m; r < RR; r++)
+      rf_acc(acc[r], taps[r - (RR - 1 - m)], x);
+  }
+#pragma unroll 8
+  for (int s = 0; s < a0; s++) // rows i .. B+1, taken by every output: ages r + s
+  {
+    const float2 x = *p2;
+    p2 -= CP;
+#pragma unroll
+    for (int r = 0; r < RR; r++)
+      rf_acc(acc[r], taps[s + r], x);
+  }
+  if (store)
+  {
+#pragma unroll
+    for (int r = 0; r < RR; r++)
+      out[(size_t)(Hout + i + r) * CP + c] = acc[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ring_fir4(const float2* __restrict__ in, float2* __restrict__ out,
+                                                   unsigned n, int T, const float* __restrict__ taps,
+                                                   unsigned g0, unsigned C, unsigned CP, unsigned Hout)
+{
+  const unsigned c = blockIdx.x * 64 + threadIdx.x; // < CP: the row buffers are padded
+  const unsigned y = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
+  unsigned i = (blockIdx.y * blockDim.y + y) * RG;
+  if (i >= n)
+    return;
+  const bool store = c < C;
+  unsigned left = min((unsigned)RG, n - i);
+  while (left)
+  { // as many outputs as stay within one ring period
+    const unsigned room = (unsigned)T - (g0 + i) % (unsigned)T;
+    const unsigned take = min(left, room);
+    switch (take)
+    {
+      case 4: ring_group<4>(in, out, i, T, taps, g0, c, CP, Hout, store); break;
+      case 3: ring_group<3>(in, out, i, T, taps, g0, c, CP, Hout, store); break;
+      case 2: ring_group<2>(in, out, i, T, taps, g0, c, CP, Hout, store); break;
+      default: ring_group<1>(in, out, i, T, taps, g0, c, CP, Hout, store); break;
+    }
+    i += take;
+    left -= take;
+  }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* K5: RDS recurrences at the RDS rate.  The matched filter between the two serial kernels     */
 /*     (cFirFilter::Process(real), FirFilter.cpp:360-377) runs time-parallel in k_ring_fir.      */
