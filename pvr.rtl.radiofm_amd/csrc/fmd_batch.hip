@@ -7,6 +7,7 @@
 #include "../../include/fmd.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -599,7 +600,8 @@ using FirFn = void (*)(const typename IN::elem*, size_t, unsigned, const float2*
 
 template <class IN, int TILE, int E>
 int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
-                      unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark)
+                      unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
+                      hipEvent_t ev_start, hipEvent_t ev_stop)
 {
   const fmd::Design& d = b->des;
   const unsigned C = b->C, D = d.D, T = d.table_size;
@@ -631,10 +633,19 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const typename IN::elem* x = static_cast<const typename IN::elem*>(d_iq);
   mark(0);
-  hipLaunchKernelGGL(kfn, dim3(C * ntiles), dim3(TILE), lds, sF, x, iq_channel_stride, N,
-                     b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, T, b->lut_idx,
-                     b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles,
-                     (C % 8 == 0) ? 1u : 0u);
+  // profiled calls: the two events take the kernel's own start and stop (hipExtLaunchKernelGGL),
+  // not the stream's state around it (a recorded event also counts the dispatch gap behind it)
+  if (ev_start)
+    hipExtLaunchKernelGGL(kfn, dim3(C * ntiles), dim3(TILE), unsigned(lds), sF, ev_start, ev_stop, 0u, x,
+                          iq_channel_stride, N, (const float2*)b->hist[b->hist_sel].p,
+                          (float2*)b->hist[b->hist_sel ^ 1].p, (const float2*)b->lut.p, T, b->lut_idx,
+                          (const float*)b->if_coeff.p, d.if_order, D, pos, M, (float2*)b->demod[q].p,
+                          b->Mstride, ntiles, (C % 8 == 0) ? 1u : 0u);
+  else
+    hipLaunchKernelGGL(kfn, dim3(C * ntiles), dim3(TILE), lds, sF, x, iq_channel_stride, N,
+                       b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, T, b->lut_idx,
+                       b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles,
+                       (C % 8 == 0) ? 1u : 0u);
   mark(1);
   hipLaunchKernelGGL(fmd::k_if_level<IN>, dim3(C), dim3(64), 0, sF, x, iq_channel_stride, N, b->lut.p, T,
                      b->lut_idx, b->st);
@@ -646,14 +657,15 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
  * lane stride stays even: fewer conflicts, not none). */
 template <class IN, int TILE>
 int launch_if_stage_e(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
-                      unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark)
+                      unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
+                      hipEvent_t ev_start, hipEvent_t ev_stop)
 {
   const unsigned D = b->des.D;
   if (D % 2 != 0)
-    return launch_if_stage_t<IN, TILE, 0>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
+    return launch_if_stage_t<IN, TILE, 0>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
   if (D % 4 != 0)
-    return launch_if_stage_t<IN, TILE, 1>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
-  return launch_if_stage_t<IN, TILE, 2>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
+    return launch_if_stage_t<IN, TILE, 1>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
+  return launch_if_stage_t<IN, TILE, 2>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
 }
 
 /* Outputs per workgroup.  Small workgroups suffer least from the serial stage: its two role waves
@@ -664,7 +676,8 @@ int launch_if_stage_e(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
  * halo is amortised and the window fits LDS a useful number of times. */
 template <class IN>
 int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
-                    unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark)
+                    unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
+                      hipEvent_t ev_start, hipEvent_t ev_stop)
 {
   const fmd::Design& d = b->des;
   const unsigned T = d.table_size;
@@ -674,10 +687,10 @@ int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, un
     return pow2 && d.if_order <= 4u * tile * d.D / 8u && lds <= 16 * 1024; // halo <= half the tile span
   };
   if (fits(64))
-    return launch_if_stage_e<IN, 64>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
+    return launch_if_stage_e<IN, 64>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
   if (fits(128))
-    return launch_if_stage_e<IN, 128>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
-  return launch_if_stage_e<IN, 256>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark);
+    return launch_if_stage_e<IN, 128>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
+  return launch_if_stage_e<IN, 256>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
 }
 
 /* The light part of one call's post chain on stream s: cRDSRxSignalProcessor's PLL, matched filter
@@ -848,8 +861,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   }
   // level 2: events between all stages (serial mode); level 1: only around the FIR kernel, on
   // the stream that kernel is launched on
-  auto mark = [&](int i) {
-    if (evset && (b->profiling >= 2 || i <= 1))
+  auto mark = [&](int i) { // events 0 and 1 are the FIR kernel's own start and stop (launch_if_stage)
+    if (evset && b->profiling >= 2 && i > 1)
       (void)hipEventRecord(evset[i], sF);
   };
 
@@ -874,8 +887,10 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
         signal(ce[fmd_batch::EV_FIR], sF);
     };
     const int rc = fmt == IQ_U8
-                       ? launch_if_stage<fmd::InU8>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn)
-                       : launch_if_stage<fmd::InF32>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn);
+                       ? launch_if_stage<fmd::InU8>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn,
+                                                   evset ? evset[0] : nullptr, evset ? evset[1] : nullptr)
+                       : launch_if_stage<fmd::InF32>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn,
+                                                    evset ? evset[0] : nullptr, evset ? evset[1] : nullptr);
     if (rc != FMD_OK)
       return rc;
   }
