@@ -18,6 +18,15 @@ for name in ("bench", "bench_serialised", "bench_config5", "bench_config3", "ben
         line = open(src).read().strip().splitlines()[-1]
         json.loads(line)
         open(os.path.join(pr, "%s_%s.json" % (tag, name)), "w").write(line + "\n")
+# the bench line printed by the very runs rocprofv3 traced (its event-based FIR time belongs beside
+# the kernel-stats csv of the same run)
+for name, dst in (("stats", "bench_under_rocprofv3"), ("stats_ser", "bench_serialised_under_rocprofv3")):
+    src = os.path.join(go, "%s_%s.log" % (tag, name))
+    if os.path.exists(src):
+        lines = [l for l in open(src).read().splitlines() if l.startswith('{"metric"')]
+        if lines:
+            json.loads(lines[-1])
+            open(os.path.join(pr, "%s_%s.json" % (tag, dst)), "w").write(lines[-1] + "\n")
 st2 = glob.glob(os.path.join(go, tag + "_stats_ser", "**", "*_kernel_stats.csv"), recursive=True)
 if st2:
     shutil.copy(st2[0], os.path.join(pr, tag + "_kernel_stats_serialised.csv"))
@@ -25,7 +34,7 @@ st = glob.glob(os.path.join(go, tag + "_stats", "**", "*_kernel_stats.csv"), rec
 if st:
     shutil.copy(st[0], os.path.join(pr, tag + "_kernel_stats.csv"))
 out = open(os.path.join(pr, tag + "_pmc_k_if_fir.txt"), "w")
-out.write("rocprofv3 --pmc passes (separate runs, counters only) on k_if_fir (instance named in the kernel-stats csv of the same tag), 8192 channels,\n"
+out.write("rocprofv3 --pmc passes (separate runs, counters only) on k_if_fir<InF32,64,7,true,0,false>, 8192 channels,\n"
           "bench.py --concurrency 0; mean per launch.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE\n"
           "counts 1/2 of a wide coalesced read stream (MI355X_MICROARCH.md, HBM): read bytes = 2*FETCH_SIZE*1024.\n")
 vals = {}
