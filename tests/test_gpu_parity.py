@@ -258,3 +258,83 @@ def test_concurrency_modes_agree(pkg, fmsig):
         assert n == n0
         assert np.array_equal(a.view(np.uint32), a0.view(np.uint32)), mode
         assert g == g0, mode
+
+
+DEGENERATE = ["silence", "dc", "noise", "clipped", "tone_at_carrier", "tiny"]
+
+
+@pytest.mark.parametrize("kind", DEGENERATE)
+def test_degenerate_inputs(pkg, oracle, kind):
+    """Inputs no station produces: an unplugged antenna (all zeros: atan2f(0, 0), 0 / 0 behind the
+    pilot loop's select), DC, white noise (PLLs never lock, the NCO limits and the rare-input paths
+    are hit), full-scale square waves, an unmodulated carrier exactly at the tuned frequency, and
+    a signal near the bottom of the float range.  Audio bits and the status getters equal the
+    oracle's; all of it must stay finite."""
+    fs, D = 2.4e6, 11
+    rng = np.random.default_rng(12345)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    d = pkg.FmDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    n0 = 0
+    for blk in range(4):
+        t = np.arange(n0, n0 + N, dtype=np.float64)
+        if kind == "silence":
+            z = np.zeros(N, np.complex64)
+        elif kind == "dc":
+            z = np.full(N, 0.3 + 0.2j, np.complex64)
+        elif kind == "noise":
+            z = (0.5 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(np.complex64)
+        elif kind == "clipped":
+            z = (np.where((t // 7) % 2 == 0, 1.0, -1.0) + 1j * np.where((t // 5) % 2 == 0, 1.0, -1.0)).astype(np.complex64)
+        elif kind == "tone_at_carrier":
+            z = (0.5 * np.exp(2j * np.pi * (-0.15) * t)).astype(np.complex64)  # lands on 0 Hz after the tuner
+        else:
+            z = (1e-30 * np.exp(2j * np.pi * (-0.15 + 0.01 * np.sin(2 * np.pi * 1000 / fs * t)) * t)).astype(np.complex64)
+        n0 += N
+        iq = np.ascontiguousarray(z).view(np.float32)
+        r = o.process_stream(iq)
+        a = d.ProcessStream(z)
+        assert np.all(np.isfinite(r)), (kind, blk)
+        assert _bits_equal(a, r), (kind, blk, _rms(a, r))
+    so = o.status()
+    assert d.StereoDetected() == bool(so.stereo)
+    assert np.float32(d.GetPilotLevel()) == np.float32(so.pilot_level)
+    assert np.float32(d.GetBasebandLevel()) == np.float32(so.baseband_level)
+    assert np.float32(d.GetInterfaceLevel()) == np.float32(so.if_level)
+    assert np.float32(d.GetTuningOffset()) == np.float32(so.tuning_offset)
+
+
+def test_degenerate_inputs_whole_cu_form(pkg, oracle):
+    """The same six inputs through a 1026-channel batch with overlapped calls: the serial stage runs in its
+    whole-CU form (hand-counted waits, per-pair hand-off, out-of-line rare-input path; one workgroup
+    with an empty second group and padded lanes).  Channel c gets input c mod 6: one channel of
+    each kind against the oracle, every other channel against its twin."""
+    import torch
+    fs, D, C, nblk = 2.4e6, 11, 1026, 3
+    rng = np.random.default_rng(12345)
+    base = np.zeros((nblk, 6, N), np.complex64)
+    for blk in range(nblk):
+        t = np.arange(blk * N, (blk + 1) * N, dtype=np.float64)
+        base[blk, 1] = 0.3 + 0.2j
+        base[blk, 2] = 0.5 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))
+        base[blk, 3] = np.where((t // 7) % 2 == 0, 1.0, -1.0) + 1j * np.where((t // 5) % 2 == 0, 1.0, -1.0)
+        base[blk, 4] = 0.5 * np.exp(2j * np.pi * (-0.15) * t)
+        base[blk, 5] = 1e-30 * np.exp(2j * np.pi * (-0.15 + 0.01 * np.sin(2 * np.pi * 1000 / fs * t)) * t)
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
+    b.set_concurrency(2)
+    stride = (b.max_audio_floats(N) + 63) // 64 * 64
+    st = torch.cuda.current_stream().cuda_stream
+    idx = torch.arange(C, device="cuda") % 6
+    iq = [torch.view_as_real(torch.from_numpy(base[k]).cuda()[idx]).contiguous() for k in range(nblk)]
+    audio = [torch.zeros((C, stride), dtype=torch.float32, device="cuda") for _ in range(nblk)]
+    nf = [b.process_device(iq[k].data_ptr(), N, N, audio[k].data_ptr(), stride, st) for k in range(nblk)]
+    b.wait(stream=st)
+    torch.cuda.synchronize()
+    refs = [oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for _ in range(6)]
+    for k in range(nblk):
+        a = audio[k][:, :nf[k]].cpu().numpy()
+        for kind in range(6):
+            r = refs[kind].process_stream(np.ascontiguousarray(base[k, kind]).view(np.float32))
+            assert _bits_equal(a[kind], r), (k, kind)
+            twins = a[kind::6]
+            assert np.array_equal(twins.view(np.uint32), np.broadcast_to(a[kind], twins.shape).view(np.uint32)), (k, kind)
+    b.close()
