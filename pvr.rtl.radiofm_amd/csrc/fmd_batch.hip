@@ -987,7 +987,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     }
     mark(3);
     static const int ring4 = getenv("FMD_RING4") ? atoi(getenv("FMD_RING4")) : 1;
-    if (ring4 && T_lpf >= 4)
+    if (ring4 && T_lpf >= unsigned(fmd::RG))
       hipLaunchKernelGGL(fmd::k_ring_fir4, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
                          sR, b->rdsraw.p, b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C,
                          CP, 0u);
@@ -1035,7 +1035,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hbb), rt, 0, sA, b->brp(q), b->brp(q ^ 1), Hbb, M, CP);
     mark(6);
     static const int ring4a = getenv("FMD_RING4") ? atoi(getenv("FMD_RING4")) : 1;
-    if (ring4a && T_alp >= 4)
+    if (ring4a && T_alp >= unsigned(fmd::RG))
       hipLaunchKernelGGL(fmd::k_ring_fir4, dim3(CP / 64, (A + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
                          sA, b->rs.p, b->alp[q].p, A, int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
     else

@@ -918,7 +918,10 @@ struct HbCoef
   float c[52];
 };
 
-constexpr int HB_R = 4; // outputs per thread: each even input row is loaded once for up to 4 outputs
+#ifndef FMD_HB_R
+#define FMD_HB_R 4
+#endif
+constexpr int HB_R = FMD_HB_R; // outputs per thread: each even input row is loaded once for up to 4 outputs
 
 __global__ __launch_bounds__(256) void k_halfband(const float2* __restrict__ in,
                                                   float2* __restrict__ out, unsigned n_out, int L,
@@ -1046,7 +1049,10 @@ __global__ __launch_bounds__(256) void k_ring_fir(const E* __restrict__ in, E* _
  * (four taps per row, contiguous in the table: age = output - row), and the few rows only some of
  * them take on their own.  Every output's accumulator starts at -0 (x + -0 = x for every x), the
  * order is the reference's.  A group that straddles a ring period is done as two groups. */
-constexpr int RG = 4;
+#ifndef FMD_RG
+#define FMD_RG 4
+#endif
+constexpr int RG = FMD_RG;
 
 template <int RR>
 __device__ __forceinline__ void ring_group(const float2* __restrict__ in, float2* __restrict__ out,
@@ -1107,6 +1113,18 @@ __device__ __forceinline__ void ring_group(const float2* __restrict__ in, float2
   }
 }
 
+template <int RR>
+__device__ __forceinline__ void ring_dispatch(unsigned take, const float2* __restrict__ in,
+                                              float2* __restrict__ out, unsigned i, int T,
+                                              const float* __restrict__ taps, unsigned g0, unsigned c,
+                                              unsigned CP, unsigned Hout, bool store)
+{ // take is wave-uniform: one scalar branch per size
+  if (take == (unsigned)RR)
+    ring_group<RR>(in, out, i, T, taps, g0, c, CP, Hout, store);
+  else if constexpr (RR > 1)
+    ring_dispatch<RR - 1>(take, in, out, i, T, taps, g0, c, CP, Hout, store);
+}
+
 __global__ __launch_bounds__(256) void k_ring_fir4(const float2* __restrict__ in, float2* __restrict__ out,
                                                    unsigned n, int T, const float* __restrict__ taps,
                                                    unsigned g0, unsigned C, unsigned CP, unsigned Hout)
@@ -1122,13 +1140,7 @@ __global__ __launch_bounds__(256) void k_ring_fir4(const float2* __restrict__ in
   { // as many outputs as stay within one ring period
     const unsigned room = (unsigned)T - (g0 + i) % (unsigned)T;
     const unsigned take = min(left, room);
-    switch (take)
-    {
-      case 4: ring_group<4>(in, out, i, T, taps, g0, c, CP, Hout, store); break;
-      case 3: ring_group<3>(in, out, i, T, taps, g0, c, CP, Hout, store); break;
-      case 2: ring_group<2>(in, out, i, T, taps, g0, c, CP, Hout, store); break;
-      default: ring_group<1>(in, out, i, T, taps, g0, c, CP, Hout, store); break;
-    }
+    ring_dispatch<RG>(take, in, out, i, T, taps, g0, c, CP, Hout, store);
     i += take;
     left -= take;
   }
