@@ -354,10 +354,16 @@ def main():
     stage, calls = batch.stage_ms()
     fir_ms = stage["if_fir"]
 
+    # after the timed region: four more steps with the stages one after the other on one stream and
+    # events between them -- every kernel alone on the chip (the FIR's figure alone goes beside the
+    # in-pipeline one in `roofline`)
     stage_all = None
-    if args.stage_profile:
+    if args.stage_profile or args.concurrency == 2:
+        drain()
+        if args.concurrency != 0:
+            batch.set_concurrency(0)
         batch.set_profiling(2)
-        for i in range(W + K, W + K + 3):
+        for i in range(W + K, W + K + 4):
             step(i)
         drain()
         stage_all, _ = batch.stage_ms()
@@ -415,6 +421,14 @@ def main():
             out["serial_probe_last_8_launches"] = serial_probe
         if stage_all:
             out["stage_ms"] = {k: round(v, 4) for k, v in stage_all.items()}
+            if stage_all.get("if_fir", 0) > 0:
+                a_ms = stage_all["if_fir"]
+                out["roofline"]["alone"] = {"avg_ms": round(a_ms, 4),
+                                            "achieved": round(bytes_per_launch / (a_ms * 1e-3) / 1e9, 1),
+                                            "frac": round(bytes_per_launch / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                            "note": "same kernel with nothing else on the chip (4 serialised "
+                                                    "steps after the timed region); avg_ms / achieved / frac "
+                                                    "above are inside the overlapped pipeline"}
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
