@@ -338,3 +338,30 @@ def test_degenerate_inputs_whole_cu_form(pkg, oracle):
             twins = a[kind::6]
             assert np.array_equal(twins.view(np.uint32), np.broadcast_to(a[kind], twins.shape).view(np.uint32)), (k, kind)
     b.close()
+
+
+def test_serial_stage_probe(pkg, fmsig, monkeypatch):
+    """The per-workgroup probe of the serial stage (dev aid): off by default, and with
+    FMD_SERIAL_PROBE=1 one (start, end, cycles) record per workgroup and launch, in both forms."""
+    fs, D = 2.4e6, 11
+    p = fmsig.default_params(fs, noise_sigma=0.01)
+    iq = fmsig.generate_f32(p, 0, N).view(np.complex64)
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 2)
+    b.process_host(np.stack([iq, iq]))
+    assert b.debug_serial_probe().shape[1] == 0
+    b.close()
+    monkeypatch.setenv("FMD_SERIAL_PROBE", "1")
+    for C, wgs in ((2, 1), (1100, 9)):  # shared form: one workgroup per 64 channels; whole-CU form: per 128
+        b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
+        b.process_host(np.broadcast_to(iq, (C, N)).copy())
+        b.process_host(np.broadcast_to(iq, (C, N)).copy())
+        pr = b.debug_serial_probe()
+        used = [pr[l][pr[l][:, 1] > 0] for l in range(8)]
+        used = [u for u in used if len(u)]
+        assert len(used) == 2 and all(len(u) == wgs for u in used), [len(u) for u in used]
+        for u in used:
+            ticks = u[:, 1] - u[:, 0]
+            cycles = u[:, 2] & ((1 << 40) - 1)
+            assert (ticks > 0).all() and (cycles > 100000).all()
+            assert ((cycles / ticks) > 5).all() and ((cycles / ticks) < 40).all()  # shader clock / 100 MHz
+        b.close()
