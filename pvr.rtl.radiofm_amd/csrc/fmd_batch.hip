@@ -717,9 +717,14 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
     hipLaunchKernelGGL(fmd::k_rds_pll, dim3(CP / 64), dim3(64), 0, s, b->rlpf[j.q].p, j.R, C, CP, k, b->st,
                        b->rpll.p, T_mf - 1, b->sctab.p, sct);
-    hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (j.R + fmd::RF_TI - 1) / fmd::RF_TI),
-                       dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), s, b->rpll.p,
-                       b->rmf.p, j.R, int(T_mf), b->mf_taps2.p, j.mf_g, C, CP, 0u);
+    if (T_mf >= unsigned(fmd::RG))
+      hipLaunchKernelGGL(fmd::k_ring_fir4<float>, dim3(CP / 64, (j.R + 4 * fmd::RG - 1) / (4 * fmd::RG)),
+                         dim3(64, 4), 0, s, b->rpll.p, b->rmf.p, j.R, int(T_mf), b->mf_taps2.p, j.mf_g, C, CP,
+                         0u);
+    else
+      hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (j.R + fmd::RF_TI - 1) / fmd::RF_TI),
+                         dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), s, b->rpll.p,
+                         b->rmf.p, j.R, int(T_mf), b->mf_taps2.p, j.mf_g, C, CP, 0u);
     hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, s, b->rpll.p, b->rpll.p, T_mf - 1, j.R,
                        CP);
     hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, s, b->rmf.p, j.R, C, CP, k, b->st,
@@ -988,7 +993,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     mark(3);
     static const int ring4 = getenv("FMD_RING4") ? atoi(getenv("FMD_RING4")) : 1;
     if (ring4 && T_lpf >= unsigned(fmd::RG))
-      hipLaunchKernelGGL(fmd::k_ring_fir4, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
+      hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
                          sR, b->rdsraw.p, b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C,
                          CP, 0u);
     else
@@ -1014,9 +1019,14 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
       hipLaunchKernelGGL(fmd::k_rds_pll, dim3(CP / 64), dim3(64), 0, sR, b->rlpf[q].p, R, C, CP, k,
                          b->st, b->rpll.p, T_mf - 1, b->sctab.p, sct);
-      hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI),
-                         dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), sR,
-                         b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C, CP, 0u);
+      if (T_mf >= unsigned(fmd::RG))
+        hipLaunchKernelGGL(fmd::k_ring_fir4<float>, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)),
+                           dim3(64, 4), 0, sR, b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C,
+                           CP, 0u);
+      else
+        hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI),
+                           dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), sR,
+                           b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C, CP, 0u);
       hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, sR, b->rpll.p, b->rpll.p, T_mf - 1, R, CP);
       hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, sR, b->rmf.p, R, C, CP, k,
                          b->st, b->call_index, b->queue[es].p, b->queue_count[es].p, b->queue_cap,
@@ -1036,7 +1046,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     mark(6);
     static const int ring4a = getenv("FMD_RING4") ? atoi(getenv("FMD_RING4")) : 1;
     if (ring4a && T_alp >= unsigned(fmd::RG))
-      hipLaunchKernelGGL(fmd::k_ring_fir4, dim3(CP / 64, (A + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
+      hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (A + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
                          sA, b->rs.p, b->alp[q].p, A, int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
     else
     hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (A + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),

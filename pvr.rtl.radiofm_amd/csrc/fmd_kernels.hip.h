@@ -1054,24 +1054,27 @@ __global__ __launch_bounds__(256) void k_ring_fir(const E* __restrict__ in, E* _
 #endif
 constexpr int RG = FMD_RG;
 
-template <int RR>
-__device__ __forceinline__ void ring_group(const float2* __restrict__ in, float2* __restrict__ out,
+__device__ __forceinline__ float rf_neg_zero(float*) { return -0.0f; }
+__device__ __forceinline__ float2 rf_neg_zero(float2*) { return make_float2(-0.0f, -0.0f); }
+
+template <int RR, typename E>
+__device__ __forceinline__ void ring_group(const E* __restrict__ in, E* __restrict__ out,
                                            unsigned i, int T, const float* __restrict__ taps,
                                            unsigned g0, unsigned c, unsigned CP, unsigned Hout, bool store)
 {
   const int a0 = (int)((g0 + i) % (unsigned)T); // a0 + RR - 1 <= T - 1: one ring period
-  float2 acc[RR];
+  E acc[RR];
 #pragma unroll
   for (int r = 0; r < RR; r++)
-    acc[r] = make_float2(-0.0f, -0.0f);
+    acc[r] = rf_neg_zero((E*)nullptr);
   // buffer row of time t is T - 1 + t
-  const float2* __restrict__ p1 = in + (size_t)((unsigned)T - 1 + i - (unsigned)a0) * CP + c; // time B
+  const E* __restrict__ p1 = in + (size_t)((unsigned)T - 1 + i - (unsigned)a0) * CP + c; // time B
   const float* __restrict__ k1 = taps + a0;
   const int n1 = T - a0 - (RR - 1); // rows B .. i+RR-T, taken by every output: ages a0 + r + s
 #pragma unroll 8
   for (int s = 0; s < n1; s++)
   {
-    const float2 x = *p1;
+    const E x = *p1;
     p1 -= CP;
 #pragma unroll
     for (int r = 0; r < RR; r++)
@@ -1080,17 +1083,17 @@ __device__ __forceinline__ void ring_group(const float2* __restrict__ in, float2
 #pragma unroll
   for (int m = 0; m < RR - 1; m++) // the oldest rows: output r takes RR-1-r of them, up to age T-1
   {
-    const float2 x = *p1;
+    const E x = *p1;
     p1 -= CP;
 #pragma unroll
     for (int r = 0; r < RR - 1 - m; r++)
       rf_acc(acc[r], taps[T - (RR - 1) + r + m], x);
   }
-  const float2* __restrict__ p2 = in + (size_t)((unsigned)T - 1 + i + RR - 1) * CP + c; // time i+RR-1
+  const E* __restrict__ p2 = in + (size_t)((unsigned)T - 1 + i + RR - 1) * CP + c; // time i+RR-1
 #pragma unroll
   for (int m = 0; m < RR - 1; m++) // the newest rows: output r takes the last r of them, from age 0
   {
-    const float2 x = *p2;
+    const E x = *p2;
     p2 -= CP;
 #pragma unroll
     for (int r = RR - 1 - m; r < RR; r++)
@@ -1099,7 +1102,7 @@ __device__ __forceinline__ void ring_group(const float2* __restrict__ in, float2
 #pragma unroll 8
   for (int s = 0; s < a0; s++) // rows i .. B+1, taken by every output: ages r + s
   {
-    const float2 x = *p2;
+    const E x = *p2;
     p2 -= CP;
 #pragma unroll
     for (int r = 0; r < RR; r++)
@@ -1113,19 +1116,20 @@ __device__ __forceinline__ void ring_group(const float2* __restrict__ in, float2
   }
 }
 
-template <int RR>
-__device__ __forceinline__ void ring_dispatch(unsigned take, const float2* __restrict__ in,
-                                              float2* __restrict__ out, unsigned i, int T,
+template <int RR, typename E>
+__device__ __forceinline__ void ring_dispatch(unsigned take, const E* __restrict__ in,
+                                              E* __restrict__ out, unsigned i, int T,
                                               const float* __restrict__ taps, unsigned g0, unsigned c,
                                               unsigned CP, unsigned Hout, bool store)
 { // take is wave-uniform: one scalar branch per size
   if (take == (unsigned)RR)
-    ring_group<RR>(in, out, i, T, taps, g0, c, CP, Hout, store);
+    ring_group<RR, E>(in, out, i, T, taps, g0, c, CP, Hout, store);
   else if constexpr (RR > 1)
-    ring_dispatch<RR - 1>(take, in, out, i, T, taps, g0, c, CP, Hout, store);
+    ring_dispatch<RR - 1, E>(take, in, out, i, T, taps, g0, c, CP, Hout, store);
 }
 
-__global__ __launch_bounds__(256) void k_ring_fir4(const float2* __restrict__ in, float2* __restrict__ out,
+template <typename E>
+__global__ __launch_bounds__(256) void k_ring_fir4(const E* __restrict__ in, E* __restrict__ out,
                                                    unsigned n, int T, const float* __restrict__ taps,
                                                    unsigned g0, unsigned C, unsigned CP, unsigned Hout)
 {
@@ -1140,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_ring_fir4(const float2* __restrict__ in
   { // as many outputs as stay within one ring period
     const unsigned room = (unsigned)T - (g0 + i) % (unsigned)T;
     const unsigned take = min(left, room);
-    ring_dispatch<RG>(take, in, out, i, T, taps, g0, c, CP, Hout, store);
+    ring_dispatch<RG, E>(take, in, out, i, T, taps, g0, c, CP, Hout, store);
     i += take;
     left -= take;
   }
