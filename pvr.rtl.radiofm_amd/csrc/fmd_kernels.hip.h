@@ -1133,6 +1133,10 @@ __global__ __launch_bounds__(256) void k_ring_fir4(const E* __restrict__ in, E* 
                                                    unsigned n, int T, const float* __restrict__ taps,
                                                    unsigned g0, unsigned C, unsigned CP, unsigned Hout)
 {
+  // the real instance is the matched filter between two lane-per-channel kernels of the light part:
+  // short, and the light part should be over before the next FIR starts -> issue first, like them
+  if (sizeof(E) == sizeof(float))
+    __builtin_amdgcn_s_setprio(3);
   const unsigned c = blockIdx.x * 64 + threadIdx.x; // < CP: the row buffers are padded
   const unsigned y = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
   unsigned i = (blockIdx.y * blockDim.y + y) * RG;

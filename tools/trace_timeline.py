@@ -20,7 +20,9 @@ for s, e, n in ev:
 print("%-40s %6s %10s" % ("kernel", "calls", "mean_us"))
 for n, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
     print("%-40s %6d %10.1f" % (n[:40], len(v), sum(v) / len(v) / 1e3))
-ser = [(s, e) for s, e, n in ev if n.startswith("k_demod_serial")]
+ser = [(s, e) for s, e, n in ev if n.startswith("k_demod_serial<2")]  # the overlapped phase's form
+if len(ser) <= 6:
+    ser = [(s, e) for s, e, n in ev if n.startswith("k_demod_serial")]
 if len(ser) > 6:
     per = [(ser[i + 1][0] - ser[i][0]) / 1e3 for i in range(len(ser) - 1)]
     print("k_demod_serial start-to-start (us):", [round(x) for x in per[-8:]])
