@@ -628,6 +628,21 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
                       : &fmd::k_if_fir<IN, TILE, 8, true, E>;
   if (pow2 && longasm)
     kfn = &fmd::k_if_fir<IN, TILE, 8, true, E, TILE == 256 && E == 1>;
+  // several tiles per workgroup with the next tile's loads in flight during the tap loop
+  // (k_if_fir_mt): the headline geometry only.  Two tiles: 0.94-0.95 ms inside the pipeline against
+  // 0.98-1.00 (one tile per workgroup) on the same box, the same alone; 3, 4, 8 tiles: no better
+  // than one.  FMD_FIR_NT overrides (1 = k_if_fir).
+  static const int fir_nt = getenv("FMD_FIR_NT") ? atoi(getenv("FMD_FIR_NT")) : 2;
+  unsigned nblocks = C * ntiles;
+  if (TILE == 64 && E == 0 && pow2 && rounds == 7 && fir_nt > 1)
+  {
+    const unsigned nt = fir_nt >= 8 ? 8u : fir_nt >= 4 ? 4u : fir_nt == 3 ? 3u : 2u;
+    kfn = nt == 8 ? &fmd::k_if_fir_mt<IN, 7, 8>
+        : nt == 4 ? &fmd::k_if_fir_mt<IN, 7, 4>
+        : nt == 3 ? &fmd::k_if_fir_mt<IN, 7, 3>
+                  : &fmd::k_if_fir_mt<IN, 7, 2>;
+    nblocks = C * ((ntiles + nt - 1) / nt);
+  }
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -636,13 +651,13 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   // profiled calls: the two events take the kernel's own start and stop (hipExtLaunchKernelGGL),
   // not the stream's state around it (a recorded event also counts the dispatch gap behind it)
   if (ev_start)
-    hipExtLaunchKernelGGL(kfn, dim3(C * ntiles), dim3(TILE), unsigned(lds), sF, ev_start, ev_stop, 0u, x,
+    hipExtLaunchKernelGGL(kfn, dim3(nblocks), dim3(TILE), unsigned(lds), sF, ev_start, ev_stop, 0u, x,
                           iq_channel_stride, N, (const float2*)b->hist[b->hist_sel].p,
                           (float2*)b->hist[b->hist_sel ^ 1].p, (const float2*)b->lut.p, T, b->lut_idx,
                           (const float*)b->if_coeff.p, d.if_order, D, pos, M, (float2*)b->demod[q].p,
                           b->Mstride, ntiles, (C % 8 == 0) ? 1u : 0u);
   else
-    hipLaunchKernelGGL(kfn, dim3(C * ntiles), dim3(TILE), lds, sF, x, iq_channel_stride, N,
+    hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(TILE), lds, sF, x, iq_channel_stride, N,
                        b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, T, b->lut_idx,
                        b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles,
                        (C % 8 == 0) ? 1u : 0u);

@@ -521,6 +521,150 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
   }
 }
 
+/* The headline geometry (plain window, one wave per workgroup, power-of-two tuner table) with NT
+ * consecutive tiles of one channel per workgroup: the loads of tile t+1 are issued, into registers,
+ * before the tap loop of tile t.  A CU's LDS (25 windows) is all the data k_if_fir keeps in flight,
+ * and only while a workgroup waits for its loads; here a wave always has a tile's loads in flight
+ * (in its registers) next to the tile it computes on (in LDS).  Same arithmetic, same order. */
+template <class IN, int UNROLL, int NT>
+__global__ __launch_bounds__(64) void k_if_fir_mt(const typename IN::elem* __restrict__ iq,
+                                                  size_t chan_stride, unsigned N,
+                                                  const float2* __restrict__ hist_in,
+                                                  float2* __restrict__ hist_out,
+                                                  const float2* __restrict__ lut, unsigned T,
+                                                  unsigned lut_idx0, const float* __restrict__ coeff,
+                                                  unsigned order, unsigned D, unsigned pos, unsigned M,
+                                                  float2* __restrict__ out, unsigned Mstride,
+                                                  unsigned ntiles, unsigned xcd_map)
+{
+  typedef typename IN::pair pair_t;
+  constexpr int TILE = 64;
+  extern __shared__ __attribute__((aligned(16))) float2 win[];
+  __builtin_amdgcn_s_setprio(1);
+  const unsigned ngroups = (ntiles + NT - 1) / NT;
+  unsigned c, tg;
+  if (xcd_map)
+  {
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    c = (slot / ngroups) * 8u + xcd;
+    tg = slot % ngroups;
+  }
+  else
+  {
+    c = blockIdx.x / ngroups;
+    tg = blockIdx.x % ngroups;
+  }
+  const unsigned tid = threadIdx.x;
+  const typename IN::elem* __restrict__ x = iq + (size_t)c * chan_stride;
+  const float2* __restrict__ l = lut + (size_t)c * T;
+  const unsigned mask = T - 1;
+  const int kfull_all = (int)(N & ~1u);
+  // the two table entries of a lane are the same for every tile (T | TILE * D, host-checked)
+  float2 l0, l1;
+  {
+    const int k_al0 = ((int)(pos + tg * NT * TILE * D) - (int)order) & ~1;
+    const unsigned li = (lut_idx0 + (unsigned)k_al0 + 2u * tid) & mask;
+    l0 = l[li];
+    l1 = l[(li + 1) & mask];
+  }
+  pair_t v[UNROLL];
+  auto issue = [&](unsigned tile) { // the tile's window, two samples per lane and load
+    const unsigned m0 = tile * TILE;
+    const unsigned nout = min((unsigned)TILE, M - m0);
+    const int p_first = (int)(pos + m0 * D);
+    const int k_lo = p_first - (int)order;
+    const int k_hi = p_first + (int)((nout - 1) * D);
+    const int k_al = k_lo & ~1;
+    const int kfull = min(k_hi, kfull_all);
+    const int ifirst = k_al < 0 ? (-k_al) >> 1 : 0;
+    const int npairs = (kfull - k_al + 1) >> 1;
+    const pair_t* __restrict__ src = reinterpret_cast<const pair_t*>(x) + (k_al >> 1);
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++)
+      v[u] = src[max(min(u * TILE + (int)tid, npairs - 1), ifirst)];
+  };
+  const unsigned t_first = tg * NT;
+  issue(t_first);
+  for (unsigned i = 0; i < (unsigned)NT; i++)
+  {
+    const unsigned tile = t_first + i;
+    if (tile >= ntiles)
+      break;
+    const unsigned m0 = tile * TILE;
+    const unsigned nout = min((unsigned)TILE, M - m0);
+    const int p_first = (int)(pos + m0 * D);
+    const int k_lo = p_first - (int)order;
+    const int k_hi = p_first + (int)((nout - 1) * D);
+    const int k_al = k_lo & ~1;
+    if (k_lo < 0)
+    { // tail of the previous call (already tuned), only for the first tile(s)
+      const float2* __restrict__ h = hist_in + (size_t)c * order;
+      const int nh = min(-k_lo, k_hi - k_lo);
+      for (int q = (int)tid; q < nh; q += TILE)
+        win[q + (k_lo - k_al)] = h[(int)order + k_lo + q];
+    }
+    {
+      const int kfull = min(k_hi, kfull_all);
+      const int ifirst = k_al < 0 ? (-k_al) >> 1 : 0;
+      const int npairs = (kfull - k_al + 1) >> 1;
+      float4* dst = reinterpret_cast<float4*>(win);
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++)
+      {
+        const int q = u * TILE + (int)tid;
+        if (q >= ifirst && q < npairs)
+        {
+          float2 a, b;
+          IN::unpack(v[u], a, b);
+          a = cmul(a, l0);
+          b = cmul(b, l1);
+          dst[q] = make_float4(a.x, a.y, b.x, b.y);
+        }
+      }
+      // pairs beyond one round of loads (never with the UNROLL the host picks) and a ragged last sample
+      const pair_t* __restrict__ src = reinterpret_cast<const pair_t*>(x) + (k_al >> 1);
+      for (int q = UNROLL * TILE + (int)tid; q < npairs; q += TILE)
+      {
+        float2 a, b;
+        IN::unpack(src[max(q, ifirst)], a, b);
+        a = cmul(a, l0);
+        b = cmul(b, l1);
+        if (q >= ifirst)
+          dst[q] = make_float4(a.x, a.y, b.x, b.y);
+      }
+      for (int k = max(kfull, 0) + (int)tid; k < k_hi; k += TILE)
+        win[k - k_al] = cmul(IN::one(x, k), l[(lut_idx0 + (unsigned)k) & mask]);
+    }
+    lds_wave_sync();
+    if (i + 1 < (unsigned)NT && tile + 1 < ntiles)
+      issue(tile + 1); // in flight during the tap loop below
+    if (tid < nout)
+    {
+      float2 acc = make_float2(0.0f, 0.0f);
+      const float2* w = win + (k_lo - k_al) + tid * D + order; // w[-j] = x[p - j]
+#pragma unroll 8
+      for (unsigned j = 1; j <= order; j++)
+      {
+        const float k = coeff[j];
+        const float2 sm = w[-(int)j];
+        acc.x += sm.x * k;
+        acc.y += sm.y * k;
+      }
+      out[(size_t)c * Mstride + m0 + tid] = acc;
+    }
+    if (tile == ntiles - 1)
+    {
+      float2* __restrict__ ho = hist_out + (size_t)c * order;
+      for (unsigned q = tid; q < order; q += TILE)
+      {
+        const unsigned k = N - order + q;
+        ho[q] = cmul(IN::one(x, k), l[(lut_idx0 + k) % T]);
+      }
+    }
+    lds_wave_sync(); // this tile's window reads are done before the next tile's staging
+  }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* K2a: RMSLevelApprox (FmDecode.cpp:505-519) + EMA (:427).  One wave per channel: the lanes    */
 /*      form the |tuned sample|^2 terms (coalesced), lane 0 adds them in index order.           */
