@@ -426,9 +426,10 @@ def main():
                 out["roofline"]["alone"] = {"avg_ms": round(a_ms, 4),
                                             "achieved": round(bytes_per_launch / (a_ms * 1e-3) / 1e9, 1),
                                             "frac": round(bytes_per_launch / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                            "note": "same kernel with nothing else on the chip (4 serialised "
-                                                    "steps after the timed region); avg_ms / achieved / frac "
-                                                    "above are inside the overlapped pipeline"}
+                                            "note": "the FIR with nothing else on the chip (4 serialised steps "
+                                                    "after the timed region; one tile per workgroup there, two "
+                                                    "beside the serial stage); avg_ms / achieved / frac above "
+                                                    "are inside the overlapped pipeline"}
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
