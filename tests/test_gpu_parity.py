@@ -365,3 +365,35 @@ def test_serial_stage_probe(pkg, fmsig, monkeypatch):
             assert (ticks > 0).all() and (cycles > 100000).all()
             assert ((cycles / ticks) > 5).all() and ((cycles / ticks) < 40).all()  # shader clock / 100 MHz
         b.close()
+
+
+def test_ragged_block_sizes_overlapped_calls(pkg, oracle, fmsig):
+    """Block sizes other than 65536 with overlapped calls (the IF FIR then runs two tiles per
+    workgroup, k_if_fir_mt; odd sizes leave a ragged last sample and a partial last tile)."""
+    import torch
+    fs, D, C = 2.4e6, 11, 3
+    ps = [fmsig.default_params(fs, noise_sigma=0.01, seed=21 + c) for c in range(C)]
+    refs = [oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for _ in range(C)]
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
+    b.set_concurrency(2)
+    st = torch.cuda.current_stream().cuda_stream
+    sizes = [65536, 8193, 10007, 65535, 32768, 12345, 65536, 9001, 65536]
+    stride = (b.max_audio_floats(N) + 3) // 4 * 4
+    pos, ins, outs, nfs = 0, [], [], []
+    for n in sizes:
+        iq = np.stack([fmsig.generate_f32(ps[c], pos, n) for c in range(C)])
+        pos += n
+        ins.append(iq)
+        d_iq = torch.zeros((C, 2 * N), dtype=torch.float32, device="cuda")  # rows N IQ samples apart
+        d_iq[:, :2 * n] = torch.from_numpy(iq).cuda()
+        d_out = torch.zeros((C, stride), dtype=torch.float32, device="cuda")
+        nfs.append(b.process_device(d_iq.data_ptr(), N, n, d_out.data_ptr(), stride, st))
+        outs.append((d_iq, d_out))
+    b.wait(stream=st)
+    torch.cuda.synchronize()
+    for i, n in enumerate(sizes):
+        a = outs[i][1].cpu().numpy()
+        for c in range(C):
+            r = refs[c].process_stream(ins[i][c])
+            assert nfs[i] == r.size and _bits_equal(a[c, :nfs[i]], r), (i, n, c)
+    b.close()
