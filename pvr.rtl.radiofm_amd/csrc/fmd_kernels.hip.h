@@ -875,7 +875,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
        * no margin against HBM latency once other kernels use the memory system). */
       const unsigned pf0 = (j + 1) * DS; // first sample of the chunk being staged
       const bool staging = (j + 1) < nchunks;
-      /* Whole chunks in the whole-CU form: loads and their wait written by hand.  The compiler cannot
+      /* Loads and their wait written by hand.  The compiler cannot
        * count the sample loop's stores, so in front of the LDS writes below it waits for the wave's
        * LAST operations too -- the two stores of the sample just finished, 3-8 us under load --
        * and a second wave that late makes the FM wave wait (seen per workgroup with the probe: up
@@ -884,8 +884,9 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
        * `s_waitcnt vmcnt(63)` is enough, and the oldest of those stores is a chunk old.
        * (A ragged last chunk is loaded whole: the host leaves DS samples of slack behind the last
        * channel's row; what lies beyond M is never used.) */
+      constexpr bool BYHAND = true; // every form of the kernel (the compiler's loads: false)
       float2 pre[DS], pre_h[DS];
-      if (PAIRSYNC)
+      if (BYHAND)
       {
         if (staging)
         {
@@ -979,7 +980,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
         }
         stores_behind = any_active ? 2 * cnt : 0;
       }
-      if (PAIRSYNC)
+      if (BYHAND)
       {
         if (staging)
         {
