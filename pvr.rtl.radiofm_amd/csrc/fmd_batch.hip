@@ -114,7 +114,7 @@ struct fmd_batch
   DevBuf<float> rpll, rmf, tap_sync;
   DevBuf<double> sctab;
   DevBuf<int> pidx;
-  float2* brp(int q) const { return br[q].p + size_t(fmd::RS_B) * CP; } // row 0 of br[q]
+  float2* brp(int q) const { return br[q].p + size_t(2 * fmd::RS_B) * CP; } // row 0 of br[q]
   unsigned rs_margin = 0, rs_row = 0; // ktab: zero entries around each output's taps, row length
   DevBuf<long long> serial_probe; // FMD_SERIAL_PROBE=1: per-workgroup timing of the serial stage
   DevBuf<float> fstate; // all float state arrays, CP each
@@ -455,8 +455,8 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->if_coeff.alloc(d.if_coeff.size() + 64); // zero padding: fir_long_e1_asm's dummy load
   bad |= b->rs_coeff.alloc(d.rs_coeff.size());
   // RS_B rows of zeros in front: the resampler's last batch may reach that far below its window
-  bad |= b->br[0].alloc(size_t(fmd::RS_B + d.rs_order + b->Mmax) * CP);
-  bad |= b->br[1].alloc(size_t(fmd::RS_B + d.rs_order + b->Mmax) * CP);
+  bad |= b->br[0].alloc(size_t(2 * fmd::RS_B + d.rs_order + b->Mmax) * CP);
+  bad |= b->br[1].alloc(size_t(2 * fmd::RS_B + d.rs_order + b->Mmax) * CP);
   if (d.hb.empty())
     return fail(FMD_ERR_ARG, "baseband rate too low for the RDS decimation chain");
   bad |= b->mix[0].alloc(size_t(d.hb[0].len - 1 + b->Mmax) * CP);

@@ -1658,13 +1658,24 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br,
   const int off0 = off[0];            // largest offset (oldest output of the group)
   const int tend = off0 + (int)order; // last row of the union window
 
+  // the rows of the next batch are fetched while this one is accumulated
+  float2 xn[RS_B];
+#pragma unroll
+  for (int q = 0; q < RS_B; q++)
+  {
+    xn[q] = *reinterpret_cast<const float2*>(rp + lane_off);
+    rp -= row_bytes;
+  }
   for (int t = 0; t <= tend; t += RS_B)
   {
     float2 xs[RS_B];
 #pragma unroll
+    for (int q = 0; q < RS_B; q++)
+      xs[q] = xn[q];
+#pragma unroll
     for (int q = 0; q < RS_B; q++) // past the end of the window: rows nobody takes (zero taps)
     {
-      xs[q] = *reinterpret_cast<const float2*>(rp + lane_off);
+      xn[q] = *reinterpret_cast<const float2*>(rp + lane_off);
       rp -= row_bytes;
     }
     float kk[RS_R][RS_B];
