@@ -507,6 +507,8 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     fmd::HbCoef hc{};
     for (int i = 0; i < h.len; i++)
       hc.c[i] = h.coef[size_t(i)];
+    for (int j = 0; 2 * j < h.len && j < 28; j++)
+      hc.e[j] = hc.c[2 * j];
     b->hbcoef.push_back(hc);
   }
   bind_state(b.get());
@@ -993,6 +995,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
         const bool last = (s + 1 == d.hb.size());
         float2* outp = last ? b->rdsraw.p : b->hbbuf[s].p;
         const unsigned Hout = last ? (T_lpf - 1) : unsigned(d.hb[s + 1].len - 1);
+        static const int hb4 = getenv("FMD_HB4") ? atoi(getenv("FMD_HB4")) : 1;
+        if (hb4 && (d.hb[s].len - 1) / 2 >= 4 && d.hb[s].len <= 55)
+          hipLaunchKernelGGL(fmd::k_halfband4, dim3(CP / 64, (n_out + 15) / 16), dim3(64, 4), 0, sR, in, outp,
+                             n_out, d.hb[s].len, b->hbcoef[s], C, CP, Hout);
+        else
         hipLaunchKernelGGL(fmd::k_halfband, dim3(CP / 64, (n_out + 4 * fmd::HB_R - 1) / (4 * fmd::HB_R)),
                            dim3(64, 4), 0, sR, in, outp, n_out, d.hb[s].len, b->hbcoef[s], C, CP, Hout);
         // keep the last L-1 input rows of this stage for the next call, then its input is free

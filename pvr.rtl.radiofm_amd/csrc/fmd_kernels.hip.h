@@ -1063,6 +1063,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
 struct HbCoef
 {
   float c[52];
+  float e[28]; // the even taps c[0], c[2], ... packed (k_halfband4 reads runs of them)
 };
 
 #ifndef FMD_HB_R
@@ -1145,6 +1146,73 @@ __device__ __forceinline__ void rf_acc(float2& a, float k, float2 x)
 {
   a.x += k * x.x;
   a.y += k * x.y;
+}
+
+/* The same filter without per-term tests: thread = (channel lane, RR consecutive outputs).  Output
+ * r takes the even rows u = r .. r + half (row u = input row 2*k0 + 2u) with the even taps
+ * e[u - r]; so the rows u = RR-1 .. half are taken by every output, with RR taps that are
+ * contiguous in e[], and only the first and last RR-1 rows by some.  Tap 0 starts the sum and is
+ * added again, the centre tap comes last, like the reference.  Needs half >= RR. */
+template <int RR>
+__device__ __forceinline__ void hb_group(const float2* __restrict__ in, float2* __restrict__ out,
+                                         unsigned k0, int half, const HbCoef& hc, unsigned c, unsigned CP,
+                                         unsigned Hout)
+{
+  const float2* __restrict__ p = in + (size_t)(2 * k0) * CP + c;
+  float2 acc[RR];
+  const size_t step = (size_t)2 * CP;
+#pragma unroll
+  for (int u = 0; u < RR; u++) // the rows on which outputs start (u == r: tap 0, twice)
+  {
+    const float2 x = p[(size_t)u * step];
+    acc[u] = rf_mul(hc.e[0], x);
+    rf_acc(acc[u], hc.e[0], x);
+#pragma unroll
+    for (int r = 0; r < u; r++)
+      rf_acc(acc[r], hc.e[u - r], x);
+  }
+#pragma unroll 4
+  for (int u = RR; u <= half; u++) // every output: taps e[u], e[u-1], ..., e[u-RR+1]
+  {
+    const float2 x = p[(size_t)u * step];
+#pragma unroll
+    for (int r = 0; r < RR; r++)
+      rf_acc(acc[r], hc.e[u - r], x);
+  }
+#pragma unroll
+  for (int m = 1; m < RR; m++) // the rows behind the first output's window
+  {
+    const float2 x = p[(size_t)(half + m) * step];
+#pragma unroll
+    for (int r = m; r < RR; r++)
+      rf_acc(acc[r], hc.e[half + m - r], x);
+  }
+#pragma unroll
+  for (int r = 0; r < RR; r++)
+  {
+    const float2 x = p[(size_t)(2 * r + half) * CP];
+    rf_acc(acc[r], hc.c[half], x);
+    out[(size_t)(Hout + k0 + r) * CP + c] = acc[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_halfband4(const float2* __restrict__ in,
+                                                   float2* __restrict__ out, unsigned n_out, int L,
+                                                   HbCoef hc, unsigned C, unsigned CP, unsigned Hout)
+{
+  const unsigned c = blockIdx.x * 64 + threadIdx.x;
+  const unsigned wy = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
+  const unsigned k0 = (blockIdx.y * blockDim.y + wy) * 4;
+  if (c >= C || k0 >= n_out)
+    return;
+  const int half = (L - 1) / 2;
+  switch (min(4u, n_out - k0))
+  {
+    case 4: hb_group<4>(in, out, k0, half, hc, c, CP, Hout); break;
+    case 3: hb_group<3>(in, out, k0, half, hc, c, CP, Hout); break;
+    case 2: hb_group<2>(in, out, k0, half, hc, c, CP, Hout); break;
+    default: hb_group<1>(in, out, k0, half, hc, c, CP, Hout); break;
+  }
 }
 
 /* Workgroup = 64 channels x RF_TI outputs.  The T-1+RF_TI input rows of the tile are staged once
