@@ -60,4 +60,6 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
                "source": "profiles/%s_pmc_k_if_fir.txt" % tag},
               open(os.path.join(pr, "traffic_k_if_fir.json"), "w"), indent=1)
 out.close()
+# the overlapped-mode kernel's traffic is collected by hand (two more --pmc passes on the default
+# bench.py, kernel regex k_if_fir_mt) and appended to the summary; keep an appended note across refreshes
 print(open(os.path.join(pr, tag + "_pmc_k_if_fir.txt")).read())
