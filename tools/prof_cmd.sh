@@ -19,4 +19,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats_
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-include-regex "k_if_fir" --output-format csv -d gpurun_out/${TAG}_pmc1 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --concurrency 0 > gpurun_out/${TAG}_pmc1.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_if_fir" --output-format csv -d gpurun_out/${TAG}_pmc2 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --concurrency 0 > gpurun_out/${TAG}_pmc2.log 2>&1
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-include-regex "k_if_fir" --output-format csv -d gpurun_out/${TAG}_pmc3 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --concurrency 0 > gpurun_out/${TAG}_pmc3.log 2>&1
+# the same for the two-tile form that runs when calls overlap (default bench.py)
+rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_if_fir_mt" --output-format csv -d gpurun_out/${TAG}_pmc4 -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_pmc4.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_if_fir_mt" --output-format csv -d gpurun_out/${TAG}_pmc5 -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_pmc5.log 2>&1
 ls gpurun_out | head -30

@@ -60,6 +60,20 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
                "source": "profiles/%s_pmc_k_if_fir.txt" % tag},
               open(os.path.join(pr, "traffic_k_if_fir.json"), "w"), indent=1)
 out.close()
-# the overlapped-mode kernel's traffic is collected by hand (two more --pmc passes on the default
-# bench.py, kernel regex k_if_fir_mt) and appended to the summary; keep an appended note across refreshes
+# the two-tile form that runs when calls overlap (passes 4 and 5: default bench.py, regex k_if_fir_mt)
+mt = {}
+for d in ("pmc4", "pmc5"):
+    fs = glob.glob(os.path.join(go, "%s_%s" % (tag, d), "**", "*_counter_collection.csv"), recursive=True)
+    if fs:
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(fs[0])):
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            mt[k] = (sum(v) / len(v), len(v))
+if "FETCH_SIZE" in mt and "WRITE_SIZE" in mt:
+    rd, wr = 2 * mt["FETCH_SIZE"][0] * 1024, mt["WRITE_SIZE"][0] * 1024
+    with open(os.path.join(pr, tag + "_pmc_k_if_fir.txt"), "a") as out2:
+        out2.write("\nThe two-tile form that runs when calls overlap (k_if_fir_mt<InF32,7,2>, default bench.py, the same\n"
+                   "separate --pmc passes, n=%d launches): read %.4g B + write %.4g B = %.4g B per launch = %.3f x algorithmic.\n"
+                   % (mt["FETCH_SIZE"][1], rd, wr, rd + wr, (rd + wr) / 4.6854e9))
 print(open(os.path.join(pr, tag + "_pmc_k_if_fir.txt")).read())
