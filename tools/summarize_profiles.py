@@ -34,7 +34,7 @@ st = glob.glob(os.path.join(go, tag + "_stats", "**", "*_kernel_stats.csv"), rec
 if st:
     shutil.copy(st[0], os.path.join(pr, tag + "_kernel_stats.csv"))
 out = open(os.path.join(pr, tag + "_pmc_k_if_fir.txt"), "w")
-out.write("rocprofv3 --pmc passes (separate runs, counters only) on k_if_fir_mt<InF32,7,2> (the IF FIR kernel of the headline geometry), 8192 channels,\n"
+out.write("rocprofv3 --pmc passes (separate runs, counters only) on k_if_fir<InF32,64,7,true,0,false> (one tile per workgroup: calls not overlapped), 8192 channels,\n"
           "bench.py --concurrency 0; mean per launch.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE\n"
           "counts 1/2 of a wide coalesced read stream (MI355X_MICROARCH.md, HBM): read bytes = 2*FETCH_SIZE*1024.\n")
 vals = {}
