@@ -865,9 +865,14 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     // are the staged chunk's, and nothing in the sample loop waits for them
     __builtin_amdgcn_s_waitcnt(0);
     float vsum = 0.0f, vsumsq = 0.0f;
-    const bool any_active = __builtin_amdgcn_ballot_w64(active) != 0; // else the stores are branched over
-    float2* __restrict__ brp = br + (size_t)Hbb * CP + c; // (baseband, 38 kHz * 2 * baseband)
-    float2* __restrict__ mixp = mix + (size_t)Hmix * CP + c;
+    /* The two per-sample stores: wave-uniform row bases plus ONE 32-bit byte offset per lane that
+     * advances a row per sample (the row buffers stay below 4 GB).  Padded lanes shadow the last
+     * channel -- same state, same input, same results -- so their stores write the very same values to
+     * the very same places and need no mask (nor the exec save / branch / restore around it). */
+    char* __restrict__ br_rows = reinterpret_cast<char*>(br + (size_t)Hbb * CP); // (baseband, 38 kHz * 2 * baseband)
+    char* __restrict__ mix_rows = reinterpret_cast<char*>(mix + (size_t)Hmix * CP);
+    unsigned row_off = c * (unsigned)sizeof(float2);
+    const unsigned row_step = CP * (unsigned)sizeof(float2);
     for (unsigned j = 0; j <= nchunks; j++)
     {
       /* This wave also moves the FM wave's input: while that wave works on chunk j, the IF-FIR
@@ -972,15 +977,12 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           o_re = gn * osc.x;
           o_im = gn * osc.y;
           const float zero = 0.0f;
-          if (active)
-          {
-            *brp = make_float2(v, tone * (2 * v)); // FmDecode.cpp:456
-            *mixp = make_float2((v * osc.x) - (zero * osc.y), (v * osc.y) + (zero * osc.x));
-          }
-          brp += CP;
-          mixp += CP;
+          *reinterpret_cast<float2*>(br_rows + row_off) = make_float2(v, tone * (2 * v)); // FmDecode.cpp:456
+          *reinterpret_cast<float2*>(mix_rows + row_off) =
+              make_float2((v * osc.x) - (zero * osc.y), (v * osc.y) + (zero * osc.x));
+          row_off += row_step;
         }
-        stores_behind = any_active ? 2 * cnt : 0;
+        stores_behind = 2 * cnt;
       }
       if (BYHAND)
       {
