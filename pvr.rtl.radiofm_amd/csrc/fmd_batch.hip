@@ -635,9 +635,11 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   // 0.98-1.00 (one tile per workgroup) on the same box, the same alone; 3, 4, 8 tiles: no better
   // than one.  FMD_FIR_NT overrides (1 = k_if_fir).
   // With the chip to itself (calls not overlapped) one tile per workgroup is the faster form (0.77
-  // against 0.83 ms): two tiles only beside the serial stage.
+  // against 0.83 ms), and in the throughput-bound regime (> 8192 channels) the faster FIR only
+  // takes from the kernels beside it (32 768 channels: 228 against 236 GS/s): two tiles only beside
+  // the whole-CU serial stage.
   static const int fir_nt_env = getenv("FMD_FIR_NT") ? atoi(getenv("FMD_FIR_NT")) : 0;
-  const int fir_nt = fir_nt_env ? fir_nt_env : (b->concurrency == 2 ? 2 : 1);
+  const int fir_nt = fir_nt_env ? fir_nt_env : (b->concurrency == 2 && b->serial_exclusive ? 2 : 1);
   unsigned nblocks = C * ntiles;
   if (TILE == 64 && E == 0 && pow2 && rounds == 7 && fir_nt > 1)
   {
