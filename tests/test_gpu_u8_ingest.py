@@ -127,3 +127,38 @@ def test_device_entry_u8_rejects_misaligned_stride(pkg):
     with pytest.raises(pkg.FmdError):
         b.process_device(iq.data_ptr() + 2, N, N, audio.data_ptr(), b.max_audio_floats(N), u8=True)
     b.close()
+
+
+def test_u8_batch_overlapped_whole_cu_form(pkg, oracle, fmsig):
+    """Byte input through a 1030-channel batch with overlapped calls: the byte instantiation of the
+    two-tile FIR workgroups beside the whole-CU serial stage.  Eight distinct stations repeated over
+    the channels: one channel of each against ReadAsyncCB + ProcessStream of the oracle, all the
+    others against their twin."""
+    import torch
+    fs, D, C, nblk, K = 2.4e6, 11, 1030, 4, 8
+    ps = [fmsig.default_params(fs, noise_sigma=0.01, seed=31 + s) for s in range(K)]
+    refs = [oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for _ in range(K)]
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
+    b.set_concurrency(2)
+    st = torch.cuda.current_stream().cuda_stream
+    stride = (b.max_audio_floats(N) + 63) // 64 * 64
+    idx = torch.arange(C, device="cuda") % K
+    base, bufs, outs, nfs = [], [], [], []
+    for k in range(nblk):
+        u8 = np.stack([fmsig.generate_u8(ps[s], k * N, N) for s in range(K)])  # [K, 2N] bytes
+        base.append(u8)
+        d_iq = torch.from_numpy(u8).cuda()[idx].contiguous()
+        d_out = torch.zeros((C, stride), dtype=torch.float32, device="cuda")
+        bufs.append(d_iq)
+        outs.append(d_out)
+        nfs.append(b.process_device(d_iq.data_ptr(), N, N, d_out.data_ptr(), stride, st, u8=True))
+    b.wait(stream=st)
+    torch.cuda.synchronize()
+    for k in range(nblk):
+        a = outs[k][:, :nfs[k]].cpu().numpy()
+        for s in range(K):
+            r = refs[s].process_stream(oracle.convert_u8(base[k][s]))
+            assert _bits_equal(a[s], r), (k, s)
+            twins = a[s::K]
+            assert np.array_equal(twins.view(np.uint32), np.broadcast_to(a[s], twins.shape).view(np.uint32)), (k, s)
+    b.close()
