@@ -33,54 +33,54 @@ N = 65536
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(seconds=8.0):
-    """The CPU oracle (a port of the reference path, see oracle/fmd_oracle.h) timed on this host
-    (SURVEY 8(d)): (a) 1 thread, 1 stereo+RDS channel at 2.4 MS/s; (b) one decoder per hardware
-    thread, every thread its own channel state on the same 32 input blocks, replayed in a loop.
-    `value` is (b), the whole host; the per-core figure of (a) is reported beside it."""
-    import threading
+def _cpu_topology():
+    """(model name, logical CPUs usable by this process, physical cores among them)."""
+    model, phys = "unknown", set()
+    try:
+        usable = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = list(range(os.cpu_count() or 1))
+    try:
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+                if k == "model name" and model == "unknown":
+                    model = v
+            elif not line.strip() and cur:
+                if int(cur.get("processor", -1)) in usable:
+                    phys.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+    except OSError:
+        pass
+    return model, len(usable), (len(phys) or len(usable))
+
+
+def cpu_baseline(seconds=6.0, if_filter_order=0):
+    """The CPU oracle (a port of the reference path, oracle/fmd_oracle.h; what it restates:
+    cFmDecoder::ProcessStream, /root/reference/src/FmDecode.cpp:417-502) timed on this host
+     with NATIVE threads (oracle/fmd_oracle_bench.c: pthreads, no Python and no
+    allocation in the timed loops): (a) 1 thread, 1 stereo+RDS channel; (b) one decoder per
+    logical CPU, every thread its own channel state on the same 16 input blocks replayed in a
+    loop.  `value` is (b), the whole host; `per_core` is (a)."""
     from oracle import oracle_py
     from tools import fmsig_py
     p = fmsig_py.default_params(FS, noise_sigma=0.01)
-    blocks = [fmsig_py.generate_f32(p, b * N, N) for b in range(32)]
-
-    def run(stop_at, out, idx):
-        dec = oracle_py.OracleDecoder(FS, -0.15 * FS, 48000.0, 15000.0, D)
-        for b in blocks[:4]:
-            dec.process_stream(b)
-        n = 0
-        t0 = time.perf_counter()
-        while time.perf_counter() < stop_at:
-            dec.process_stream(blocks[n % len(blocks)])
-            n += 1
-        out[idx] = (n, time.perf_counter() - t0)
-
-    one = [None]
-    run(time.perf_counter() + seconds / 2, one, 0)
-    per_core = one[0][0] * N / one[0][1] / 1e6
-    T = os.cpu_count() or 1
-    res = [None] * T
-    stop_at = time.perf_counter() + seconds / 2 + 1.0
-    th = [threading.Thread(target=run, args=(stop_at, res, i)) for i in range(T)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    whole = sum(r[0] * N / r[1] for r in res) / 1e6
-    model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    calls = sum(r[0] for r in res)
-    return {"value": round(whole, 2), "unit": "MS/s", "cores": T, "kind": "port",
-            "per_core": round(per_core, 3), "cpu_model": model,
-            "sample": "%d threads x one stereo+RDS channel at 2.4 MS/s each (32 distinct blocks of "
-                      "65536 IQ replayed): %d ProcessStream calls in %.1f s; single thread alone: "
-                      "%d calls in %.1f s" % (T, calls, max(r[1] for r in res), one[0][0], one[0][1])}
+    blocks = np.stack([fmsig_py.generate_f32(p, b * N, N) for b in range(16)])
+    params = oracle_py.FmoParams(FS, -0.15 * FS, 48000.0, 15000.0, D, 0, 0, if_filter_order, 0, 0)
+    model, logical, physical = _cpu_topology()
+    one_rate, one_calls, one_s = oracle_py.bench_threads(params, 1, seconds / 2, blocks)
+    rate, calls, worst = oracle_py.bench_threads(params, logical, seconds, blocks)
+    return {"value": round(rate / 1e6, 2), "unit": "MS/s", "cores": logical, "kind": "port",
+            "per_core": round(one_rate / 1e6, 3), "cpu_model": model,
+            "physical_cores": physical, "logical_cpus": logical,
+            "threads": "native (pthreads), one decoder per logical CPU",
+            "scaling_vs_one_thread": round(rate / one_rate, 1),
+            "sample": "%d native threads x one stereo+RDS channel at %.1f MS/s each (16 distinct "
+                      "blocks of 65536 IQ replayed): %d ProcessStream calls in %.1f s; single "
+                      "thread alone: %d calls in %.1f s"
+                      % (logical, FS / 1e6, calls, worst, one_calls, one_s)}
 
 
 def main():
@@ -353,6 +353,7 @@ def main():
         total_groups = int(reduce_scalar(float(total_groups), dist.ReduceOp.SUM))
     stage, calls = batch.stage_ms()
     fir_ms = stage["if_fir"]
+    host_ms = {k: v / K * 1e3 for k, v in host_t.items()}  # the timed region's, before the extra steps
 
     # after the timed region: four more steps with the stages one after the other on one stream and
     # events between them -- every kernel alone on the chip (the FIR's figure alone goes beside the
@@ -398,9 +399,9 @@ def main():
                        "channels_per_gpu": C, "samples_per_call": N, "input_ring_blocks": ring,
                        "audio_floats_per_channel_step": nf, "rds_groups_in_timed_region": total_groups,
                        "gather": "rank-0 RCCL gather of audio+RDS per step" if world > 1 else "none (1 GPU)",
-                       "host_ms_per_step": {"submit": round(host_t["process"] / K * 1e3, 3),
-                                            "wait": round(host_t.get("wait", 0.0) / K * 1e3, 3),
-                                            "collect_rds": round(host_t["collect"] / K * 1e3, 3)}},
+                       "host_ms_per_step": {"submit": round(host_ms["process"], 3),
+                                            "wait": round(host_ms.get("wait", 0.0), 3),
+                                            "collect_rds": round(host_ms["collect"], 3)}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "k_if_fir (cFineTuner + cDownsampleFilter complex)",
@@ -431,7 +432,7 @@ def main():
                                                     "beside the serial stage); avg_ms / achieved / frac above "
                                                     "are inside the overlapped pipeline"}
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(if_filter_order=order)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -32,8 +32,8 @@ typedef float RealType;                  // Definitions.h:45
  *   bool AddUECPDataFrame(uint8_t* frame, unsigned int len);
  *   bool SetChannelName(std::string name);
  *   bool IsSettingActive();
- * i.e. cRadioReceiver's members.  The non-template alias at the bottom expects a class
- * named cRadioReceiver to be declared by the includer, like FmDecode.h does (:27). */
+ * i.e. cRadioReceiver's members.  The class cFmDecoder at the bottom binds it to the class named
+ * cRadioReceiver, like FmDecode.h does (:27). */
 template <class Receiver>
 class cFmDecoderT
 {
@@ -118,6 +118,16 @@ private:
 };
 
 #ifndef FMD_NO_CFMDECODER_ALIAS
+/* The reference's name, as a real class: RadioReceiver.h:23 forward-declares `class cFmDecoder;`
+ * and keeps a `cFmDecoder*` member (:124) before any decoder header is seen, so the name must be
+ * a class (a typedef would conflict with that declaration).  cRadioReceiver may still be
+ * incomplete here (FmDecode.h:27 only forward-declares it too): the base template's members that
+ * call into it are instantiated where they are used -- `new cFmDecoder(this, ...)` at
+ * RadioReceiver.cpp:296-300, where the class is complete. */
 class cRadioReceiver; // FmDecode.h:27
-typedef cFmDecoderT<cRadioReceiver> cFmDecoder;
+class cFmDecoder : public cFmDecoderT<cRadioReceiver>
+{
+public:
+  using cFmDecoderT<cRadioReceiver>::cFmDecoderT;
+};
 #endif

@@ -145,6 +145,13 @@ unsigned fmo_get_rds_hb_lengths(const fmo_decoder* d, int* out, unsigned cap);
 /* scalar constants in a fixed order, see fmd_oracle.c */
 unsigned fmo_get_constants(const fmo_decoder* d, double* out, unsigned cap);
 
+/* bench.py's cpu_baseline: `threads` decoders on native POSIX threads for `seconds` each, all
+ * replaying the same nblocks x samples complex<float> blocks; returns IQ samples per second over
+ * the whole host (fmd_oracle_bench.c). */
+double fmo_bench_threads(const fmo_params* p, unsigned threads, double seconds, const float* blocks,
+                         unsigned nblocks, unsigned samples, unsigned long long* total_calls,
+                         double* max_elapsed);
+
 /* libm helpers exported for device-math parity tests */
 float fmo_atan2f(float y, float x);
 void fmo_sincos_x87(float phase, float* s, float* c);

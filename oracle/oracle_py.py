@@ -125,6 +125,10 @@ def lib():
                                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.fmo_receiver_audio_level.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 3
         L.fmo_sincos_x87.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.fmo_bench_threads.restype = C.c_double
+        L.fmo_bench_threads.argtypes = [C.POINTER(FmoParams), C.c_uint, C.c_double, C.c_void_p,
+                                        C.c_uint, C.c_uint, C.POINTER(C.c_ulonglong),
+                                        C.POINTER(C.c_double)]
         _LIB = L
     return _LIB
 
@@ -136,6 +140,20 @@ CONST_NAMES = [
     "rds_rate", "rds_nco_inc", "rds_osc_cos", "rds_osc_sin", "rds_pll_alpha", "rds_pll_beta",
     "rds_nco_hl", "rds_nco_ll", "fs_bb", "rds_mf_len",
 ]
+
+
+def bench_threads(params, threads, seconds, blocks):
+    """fmo_bench_threads: `threads` decoders on native POSIX threads (no Python in the timed loops),
+    each replaying blocks [nblocks, 2*samples] float32 for `seconds`.  Returns (IQ samples per
+    second over all threads, ProcessStream calls made, longest thread time in s)."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.float32)
+    nblocks, samples = blocks.shape[0], blocks.shape[1] // 2
+    calls, worst = C.c_ulonglong(), C.c_double()
+    rate = lib().fmo_bench_threads(C.byref(params), threads, float(seconds), blocks.ctypes.data,
+                                   nblocks, samples, C.byref(calls), C.byref(worst))
+    if rate <= 0.0:
+        raise RuntimeError("fmo_bench_threads failed")
+    return rate, int(calls.value), float(worst.value)
 
 
 def convert_u8(buf):

@@ -157,7 +157,7 @@ struct fmd_batch
   {
     bool pending = false;
     unsigned R = 0, A = 0, mf_g = 0;
-    int q = 0, es = 0;
+    int q = 0, es = 0, sq = 0;
     uint32_t call_index = 0;
     float* d_audio = nullptr;
     size_t audio_stride = 0;
@@ -170,6 +170,14 @@ struct fmd_batch
   uint32_t slot_call[NSLOT] = {}; // call index that last used the slot (0 = never)
   std::vector<hipEvent_t> ev; // [calls][ST_COUNT + 1]
   unsigned prof_calls = 0;
+
+  // Device-side error word (fmd::DevErr bits) in host-mapped memory: kernels OR into it, the host
+  // reads it without a copy or a synchronisation.  `failed`: a call broke off after its first launch
+  // or a kernel reported an error -- the channel state is no longer trustworthy, every later call is
+  // refused until fmd_batch_reset / destroy.
+  unsigned* h_err = nullptr;
+  bool failed = false;
+  std::string fail_msg;
 
   ~fmd_batch()
   {
@@ -225,6 +233,8 @@ struct fmd_batch
     }
     h_iq.release();
     h_audio.release();
+    if (h_err)
+      (void)hipHostFree(h_err);
     for (auto& e : ev)
       (void)hipEventDestroy(e);
   }
@@ -246,6 +256,30 @@ void bind_state(fmd_batch* b)
   b->st.i = b->istate.p;
   b->st.r_data = b->r_data.p;
   b->st.CP = b->CP;
+  void* derr = nullptr;
+  if (b->h_err && hipHostGetDevicePointer(&derr, b->h_err, 0) == hipSuccess)
+    b->st.err = static_cast<unsigned*>(derr);
+  // bound of the serial stage's LDS hand-off waits (~0.1 s); FMD_DEBUG_SPIN_LIMIT=0 makes every wait
+  // time out at once (test knob for the error path)
+  b->st.spin_limit = getenv("FMD_DEBUG_SPIN_LIMIT") ? unsigned(atoi(getenv("FMD_DEBUG_SPIN_LIMIT"))) : (1u << 20);
+}
+
+/* Turns the device-side error word, and an earlier broken-off call, into an error code. */
+int check_device_errors(fmd_batch* b)
+{
+  const unsigned e = b->h_err ? __atomic_load_n(b->h_err, __ATOMIC_ACQUIRE) : 0u;
+  if (e && !b->failed)
+  {
+    b->failed = true;
+    b->fail_msg = "device-side error:";
+    if (e & fmd::DEVERR_SERIAL_HANDSHAKE)
+      b->fail_msg += " serial stage hand-off timed out (results of that call are invalid)";
+    if (e & fmd::DEVERR_RDS_QUEUE_FULL)
+      b->fail_msg += " RDS group queue overflowed (groups lost; collect more often)";
+  }
+  if (b->failed)
+    return fail(FMD_ERR_DEVICE, b->fail_msg);
+  return FMD_OK;
 }
 
 /* state a freshly constructed cFmDecoder has (ctor values that are not zero) */
@@ -284,7 +318,7 @@ int do_reset(fmd_batch* b)
   for (int slot : fz)
     if (hipMemset(s.F(slot), 0, CP * sizeof(float)) != hipSuccess)
       return -1;
-  const int iz[] = {I_STEREO, I_STEREO_Q0, I_STEREO_Q1, I_R_LAST_BIT, I_R_BITPOS, I_R_BLOCK, I_R_STATE, I_R_BOFF};
+  const int iz[] = {I_STEREO, I_STEREO_Q0, I_STEREO_Q1, I_STEREO_Q2, I_STEREO_Q3, I_R_LAST_BIT, I_R_BITPOS, I_R_BLOCK, I_R_STATE, I_R_BOFF};
   for (int slot : iz)
     if (hipMemset(s.I(slot), 0, CP * sizeof(int)) != hipSuccess)
       return -1;
@@ -298,6 +332,10 @@ int do_reset(fmd_batch* b)
   for (auto& g : b->gdec)
     if (g)
       g->reset();
+  if (b->h_err)
+    __atomic_store_n(b->h_err, 0u, __ATOMIC_RELEASE);
+  b->failed = false;
+  b->fail_msg.clear();
   return 0;
 }
 
@@ -511,7 +549,12 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
       hc.e[j] = hc.c[2 * j];
     b->hbcoef.push_back(hc);
   }
+  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_err), sizeof(unsigned), hipHostMallocMapped) != hipSuccess)
+    return fail(FMD_ERR_DEVICE, "host-mapped error word allocation failed");
+  *b->h_err = 0u;
   bind_state(b.get());
+  if (!b->st.err)
+    return fail(FMD_ERR_DEVICE, "host-mapped error word has no device address");
   bad |= init_signal_state(b.get());
   if (bad)
     return fail(FMD_ERR_DEVICE, "upload of constants failed");
@@ -753,8 +796,8 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
                        j.call_index, b->queue[j.es].p, b->queue_count[j.es].p, b->queue_cap,
                        b->tap_sync.p, b->write_taps);
   }
-  if (record)
-    (void)hipEventRecord(b->cev[j.es][fmd_batch::EV_RDS], s);
+  if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_RDS], s) != hipSuccess)
+    b->failed = true, b->fail_msg = "hipEventRecord failed behind the RDS part of a call";
   {
     fmd::AudioConsts k{};
     k.de_alpha = d.de_alpha;
@@ -764,10 +807,10 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     k.n_a1 = d.notch.a1;
     k.n_a2 = d.notch.a2;
     hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, s, b->alp[j.q].p, j.A, C, CP, k,
-                       b->st, j.d_audio, j.audio_stride, unsigned(j.q));
+                       b->st, j.d_audio, j.audio_stride, unsigned(j.sq));
   }
-  if (record)
-    (void)hipEventRecord(b->cev[j.es][fmd_batch::EV_AUD], s);
+  if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_AUD], s) != hipSuccess)
+    b->failed = true, b->fail_msg = "hipEventRecord failed behind the audio tail of a call";
 }
 
 /* Submits a kept-back light part now (its results are wanted, or the batch changes mode). */
@@ -777,7 +820,8 @@ void flush_light(fmd_batch* b)
     return;
   const fmd_batch::LightJob j = b->light_job;
   b->light_job.pending = false;
-  (void)hipStreamWaitEvent(b->s_rds, b->cev[j.es][fmd_batch::EV_HEAVY], 0);
+  if (hipStreamWaitEvent(b->s_rds, b->cev[j.es][fmd_batch::EV_HEAVY], 0) != hipSuccess)
+    b->failed = true, b->fail_msg = "hipStreamWaitEvent failed in front of the light part of a call";
   launch_light(b, j, b->s_rds, true);
 }
 
@@ -805,6 +849,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   const unsigned C = b->C, CP = b->CP, N = samples, D = d.D;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
+  if (int rc = check_device_errors(b)) // a failed batch takes no more calls (fmd_batch_reset clears it)
+    return rc;
 
   /* ---- position plan (batch-uniform, mirrors the reference's bookkeeping) ---- */
   const unsigned pos = b->if_pos;
@@ -848,12 +894,15 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   const unsigned T_mf = unsigned(d.rds_mf_taps.size());
   const unsigned T_alp = unsigned(d.lpf_taps.size());
   const unsigned Hbb = d.rs_order;
-  b->call_index++;
-  const int q = int(b->call_index & 1u);  // buffer parity: demod, br, mix
-  const int es = int(b->call_index % fmd_batch::NSLOT); // event set / RDS queue of this call
+  // The call's index and everything derived from it (buffer parity, event slot) are locals until the
+  // call has been submitted: a call that is refused leaves the batch exactly as it was.
+  const uint32_t ci = b->call_index + 1;
+  const int q = int(ci & 1u);  // buffer parity: demod, br, mix
+  const int es = int(ci % fmd_batch::NSLOT); // event set / RDS queue of this call
+  const int sq = int(ci & 3u); // this call's copy of the stereo flag (see ISlot)
   // call k-2 used the same buffers; its events say when they are free again
-  const bool have_prev2 = b->call_index > 2;
-  hipEvent_t* pe2 = b->cev[(b->call_index + fmd_batch::NSLOT - 2) % fmd_batch::NSLOT];
+  const bool have_prev2 = ci > 2;
+  hipEvent_t* pe2 = b->cev[(ci + fmd_batch::NSLOT - 2) % fmd_batch::NSLOT];
   const bool serial_mode = b->concurrency == 0 || b->profiling >= 2;
   if (b->light_job.pending && (serial_mode || b->split_post || b->concurrency != 2))
     flush_light(b); // leaving the overlapped form: nothing stays kept back
@@ -864,13 +913,19 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   // one-stream form: the light parts of the post chain go to their own stream (see below)
   hipStream_t sL = serial_mode ? stream : b->s_rds;
   hipEvent_t* ce = b->cev[es];
+  // the first failing event operation of the call (checked once, behind the launches)
+  hipError_t herr = hipSuccess;
+  auto note = [&](hipError_t e) {
+    if (e != hipSuccess && herr == hipSuccess)
+      herr = e;
+  };
   auto after = [&](hipStream_t s, hipEvent_t e) {
     if (!serial_mode)
-      (void)hipStreamWaitEvent(s, e, 0);
+      note(hipStreamWaitEvent(s, e, 0));
   };
   auto signal = [&](hipEvent_t e, hipStream_t s) {
     if (!serial_mode)
-      (void)hipEventRecord(e, s);
+      note(hipEventRecord(e, s));
   };
 
   hipEvent_t* evset = nullptr;
@@ -883,14 +938,13 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       HIPCHK(hipEventCreate(&e));
       b->ev.push_back(e);
     }
-    evset = &b->ev[size_t(b->prof_calls) * (ST_COUNT + 1)];
-    b->prof_calls++;
+    evset = &b->ev[size_t(b->prof_calls) * (ST_COUNT + 1)]; // prof_calls advances with call_index
   }
   // level 2: events between all stages (serial mode); level 1: only around the FIR kernel, on
   // the stream that kernel is launched on
   auto mark = [&](int i) { // events 0 and 1 are the FIR kernel's own start and stop (launch_if_stage)
     if (evset && b->profiling >= 2 && i > 1)
-      (void)hipEventRecord(evset[i], sF);
+      note(hipEventRecord(evset[i], sF));
   };
 
   /* ---- K1: tuner + IF decimating FIR  (stream F) ---- */
@@ -919,7 +973,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                        : launch_if_stage<fmd::InF32>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn,
                                                     evset ? evset[0] : nullptr, evset ? evset[1] : nullptr);
     if (rc != FMD_OK)
-      return rc;
+      return rc; // refused before anything was launched: the batch is unchanged
   }
   signal(ce[fmd_batch::EV_INDONE], sF);
 
@@ -955,13 +1009,13 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     if (b->serial_exclusive && !serial_mode)
       hipLaunchKernelGGL((fmd::k_demod_serial<2, true>), dim3((groups + 1) / 2), dim3(256), 0, sS,
                          b->demod[q].p, b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p,
-                         Hmix, b->sctab.p, sct, unsigned(q),
-                         b->serial_probe.p ? b->serial_probe.p + size_t(b->call_index % 8) * 3 * (CP / 64) : nullptr);
+                         Hmix, b->sctab.p, sct, unsigned(sq),
+                         b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : nullptr);
     else
       hipLaunchKernelGGL((fmd::k_demod_serial<1, false>), dim3(groups), dim3(128), 0, sS, b->demod[q].p,
                          b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p, Hmix,
-                         b->sctab.p, sct, unsigned(q),
-                         b->serial_probe.p ? b->serial_probe.p + size_t(b->call_index % 8) * 3 * (CP / 64) : nullptr);
+                         b->sctab.p, sct, unsigned(sq),
+                         b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : nullptr);
   }
   signal(ce[fmd_batch::EV_SER], sS);
   mark(2);
@@ -1056,7 +1110,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                            b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C, CP, 0u);
       hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, sR, b->rpll.p, b->rpll.p, T_mf - 1, R, CP);
       hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, sR, b->rmf.p, R, C, CP, k,
-                         b->st, b->call_index, b->queue[es].p, b->queue_count[es].p, b->queue_cap,
+                         b->st, ci, b->queue[es].p, b->queue_count[es].p, b->queue_cap,
                          b->tap_sync.p, b->write_taps);
     }
   };
@@ -1092,7 +1146,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       k.n_a1 = d.notch.a1;
       k.n_a2 = d.notch.a2;
       hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, sA, b->alp[q].p, A, C, CP, k,
-                         b->st, d_audio, audio_channel_stride, unsigned(q));
+                         b->st, d_audio, audio_channel_stride, unsigned(sq));
     }
   };
   if (serial_mode || b->split_post)
@@ -1128,7 +1182,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     job.mf_g = b->mf_g;
     job.q = q;
     job.es = es;
-    job.call_index = b->call_index;
+    job.sq = sq;
+    job.call_index = ci;
     job.d_audio = d_audio;
     job.audio_stride = audio_channel_stride;
     if (b->concurrency == 2)
@@ -1155,14 +1210,24 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     }
   }
   mark(9);
-  HIPCHK(hipGetLastError());
-  b->slot_call[es] = b->call_index;
   if (!serial_mode && b->concurrency < 2)
   { // order the caller's stream after everything this call launched
-    (void)hipStreamWaitEvent(stream, ce[fmd_batch::EV_AUD], 0);
-    (void)hipStreamWaitEvent(stream, ce[fmd_batch::EV_RDS], 0);
-    (void)hipStreamWaitEvent(stream, ce[fmd_batch::EV_INDONE], 0);
+    note(hipStreamWaitEvent(stream, ce[fmd_batch::EV_AUD], 0));
+    note(hipStreamWaitEvent(stream, ce[fmd_batch::EV_RDS], 0));
+    note(hipStreamWaitEvent(stream, ce[fmd_batch::EV_INDONE], 0));
   }
+  note(hipGetLastError());
+  if (herr != hipSuccess)
+  { // part of the call is on the device, part is not: histories and channel state no longer line up
+    b->failed = true;
+    b->fail_msg = std::string("a call broke off while it was being submitted: ") + hipGetErrorString(herr);
+    return fail(FMD_ERR_DEVICE, b->fail_msg);
+  }
+  /* ---- the call is submitted: commit its index together with the positions ---- */
+  b->call_index = ci;
+  b->slot_call[es] = ci;
+  if (evset)
+    b->prof_calls++;
 
   /* ---- advance the host-tracked positions ---- */
   b->if_pos = pos + M * D - N;                      // DownConvert.cpp:132
@@ -1221,7 +1286,8 @@ int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream_)
       HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_RDS], 0));
       HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_INDONE], 0));
     }
-  return FMD_OK;
+  // asynchronous: reports what the device has flagged so far (calls that have finished)
+  return check_device_errors(b);
 }
 
 int fmd_batch_wait(fmd_batch* b, void* stream_)
@@ -1278,6 +1344,8 @@ int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap,
     if (rc != FMD_OK)
       return rc;
   }
+  if (int rc = check_device_errors(b)) // the stream was synchronised above: covers the drained calls
+    return rc;
   std::sort(recs.begin(), recs.end(), [](const fmd::RdsGroupRec& x, const fmd::RdsGroupRec& y) {
     if (x.call_index != y.call_index)
       return x.call_index < y.call_index;
@@ -1353,6 +1421,12 @@ static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t 
     return rc;
   if (C > 1 && nf > audio_channel_stride)
     return fail(FMD_ERR_ARG, "audio_channel_stride smaller than the audio produced");
+  // Synchronous entry point in every concurrency mode: in mode 2 the call's light part (RDS bit
+  // recovery, audio tail) is still kept back and the null stream is not ordered after the call --
+  // submit it and order the null stream behind the whole call before copying the audio out.
+  rc = fmd_batch_wait(b, nullptr);
+  if (rc != FMD_OK)
+    return rc;
   HIPCHK(hipMemcpy2D(audio, (C > 1 ? audio_channel_stride : size_t(nf)) * sizeof(float), b->h_audio.p,
                      a_stride * sizeof(float), size_t(nf) * sizeof(float), C, hipMemcpyDeviceToHost));
   rc = fmd_batch_collect_rds(b, nullptr, 0, 1, nullptr);
@@ -1550,6 +1624,12 @@ int fmd_batch_set_profiling(fmd_batch* b, int level)
 {
   if (!b)
     return fail(FMD_ERR_ARG, "null batch");
+  // Level 2 moves the next call onto the caller's stream with no event waits at all, and in
+  // concurrency 2 that stream was never ordered behind the calls in flight: like set_concurrency,
+  // a change of execution mode starts from an idle device.
+  HIPCHK(hipSetDevice(b->device));
+  flush_light(b);
+  HIPCHK(hipDeviceSynchronize());
   b->profiling = level < 0 ? 0 : (level > 2 ? 2 : level);
   b->prof_calls = 0; // restart the averaging window
   return FMD_OK;

@@ -65,15 +65,28 @@ enum FSlot
 };
 enum ISlot
 {
-  I_P_LOCK_CNT, I_STEREO, I_STEREO_Q0, I_STEREO_Q1, // _Q0/_Q1: the flag per call parity (audio tail)
+  I_P_LOCK_CNT, I_STEREO,
+  // the flag per call index mod 4, read by that call's audio tail: the serial stage of call k+4 is the
+  // next writer of call k's copy, and it runs behind FIR(k+4), which waits for heavy(k+2), which waits
+  // for the audio tail of call k (EV_AUD) -- the reuse is ordered by events, not by timing
+  I_STEREO_Q0, I_STEREO_Q1, I_STEREO_Q2, I_STEREO_Q3,
   I_R_LAST_BIT, I_R_BITS, I_R_BLOCK, I_R_BITPOS, I_R_STATE, I_R_BOFF,
   I_R_ERRORS, I_R_SEQ, I_SLOTS
+};
+/* Device-side error word of a batch (host-mapped memory: the host reads it without a copy).
+ * Kernels OR a bit in when an invariant fails; fmd_batch_wait / collect_rds turn it into an error. */
+enum DevErr : unsigned
+{
+  DEVERR_SERIAL_HANDSHAKE = 1u, // k_demod_serial: a role wave gave up waiting for its partner
+  DEVERR_RDS_QUEUE_FULL = 2u    // k_rds_bits: a group did not fit into the call's queue (lost)
 };
 struct ChannelState
 {
   float* f;         // [F_SLOTS][CP]
   int* i;           // [I_SLOTS][CP]
   uint16_t* r_data; // [4][CP]   block words of the group being assembled
+  unsigned* err;    // the batch's error word (DevErr bits)
+  unsigned spin_limit; // bound of the LDS hand-off waits (0 = every wait times out: test knob)
   unsigned CP;
   __host__ __device__ float* F(int slot) const { return f + (size_t)slot * CP; }
   __host__ __device__ int* I(int slot) const { return i + (size_t)slot * CP; }
@@ -104,24 +117,36 @@ __device__ __forceinline__ void lds_wave_sync()
 /* Two waves of one workgroup handing LDS buffers to each other without stopping the workgroup's other
  * waves at a barrier: a progress counter in LDS per direction.  LDS operations of a wave execute in
  * order, so the counter written after the data is seen after the data; the asm statements keep the
- * compiler from moving LDS accesses across.  The wait is bounded (~0.1 s): a protocol error shows up as
- * wrong results in the parity tests, not as a hung device. */
+ * compiler from moving LDS accesses across.  The wait is bounded (~0.1 s): a protocol error does not hang
+ * the device, it sets DEVERR_SERIAL_HANDSHAKE in the batch's error word. */
 __device__ __forceinline__ void lds_publish(unsigned lds_addr, unsigned value)
 { // explicit DS instructions on the 32-bit LDS address: a generic pointer would make these FLAT
   // accesses, whose waits also drain the wave's global stores
   asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr), "v"(value) : "memory");
 }
-__device__ __forceinline__ void lds_wait_ge(unsigned lds_addr, unsigned value)
+__device__ __forceinline__ void dev_error(unsigned* err, unsigned bit)
+{ // system scope: the word lives in host-mapped memory
+  __hip_atomic_fetch_or(err, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void lds_wait_ge(unsigned lds_addr, unsigned value, unsigned limit, unsigned* err)
 {
+  bool ok = false;
 #pragma unroll 1
-  for (unsigned spins = 0; spins < (1u << 20); spins++)
+  for (unsigned spins = 0; spins < limit; spins++)
   {
     unsigned seen;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(lds_addr) : "memory");
     if ((unsigned)__builtin_amdgcn_readfirstlane((int)seen) >= value)
+    {
+      ok = true;
       break;
+    }
     __builtin_amdgcn_s_sleep(1);
   }
+  // gave up (~0.1 s with the default limit): the results of this call are wrong from here on; the
+  // host learns it from the batch's error word (FMD_ERR_DEVICE from fmd_batch_wait / collect_rds)
+  if (!ok && __builtin_amdgcn_readfirstlane((int)threadIdx.x) == (int)threadIdx.x)
+    dev_error(err, DEVERR_SERIAL_HANDSHAKE);
 }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
@@ -782,7 +807,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
       { // stage[j & 1] staged and chunk[j & 1] read: the second wave has finished iteration j - 1
         if (j == nchunks)
           break;
-        lds_wait_ge(done_2nd, j);
+        lds_wait_ge(done_2nd, j, st.spin_limit, st.err);
       }
       if (j < nchunks)
       {
@@ -922,7 +947,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
       }
       unsigned stores_behind = 0; // vector stores issued behind those loads
       if (PAIRSYNC && j >= 1) // chunk j - 1 written, stage[(j + 1) & 1] read: FM wave done with j - 1
-        lds_wait_ge(done_fm, j);
+        lds_wait_ge(done_fm, j, st.spin_limit, st.err);
       if (j >= 1)
       {
         const unsigned m0 = (j - 1) * DS;
@@ -1620,6 +1645,8 @@ __global__ __launch_bounds__(64) void k_rds_bits(const float* __restrict__ mf, u
             r.blocks[3] = bd[3];
             queue[slot] = r;
           }
+          else
+            dev_error(st.err, DEVERR_RDS_QUEUE_FULL);
           seq++;
         }
       }

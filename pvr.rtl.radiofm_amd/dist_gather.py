@@ -13,7 +13,9 @@ RDS_REC_WIDTH = 4
 def pack_rds_records(groups, cap, channel_offset=0):
     """groups: structured array (channel, call_index, blocks[4]) -> int32 [cap, 4]."""
     rec = np.zeros((cap, RDS_REC_WIDTH), dtype=np.int32)
-    n = min(int(groups.size), cap)
+    n = int(groups.size)
+    if n > cap:  # a fixed-size message cannot carry them: never drop groups silently
+        raise ValueError("pack_rds_records: %d groups do not fit into %d records" % (n, cap))
     if n:
         g = groups[:n]
         b = g["blocks"].astype(np.int64)

@@ -142,3 +142,22 @@ def test_uecp_byte_stuffing(pkg):
     frame = bytes([0x00, 0xFD, 0x10, 0xFE, 0xFF, 0x7F])
     assert pkg.stuff_uecp_frame(frame) == bytes([0xFE, 0x00, 0xFD, 0x00, 0x10, 0xFD, 0x01, 0xFD, 0x02,
                                                  0x7F, 0xFF])
+
+
+def test_cpp_header_drops_into_reference_declaration_order():
+    """include/fm_decoder.hpp against the reference's own declaration order: `class cFmDecoder;`
+    (RadioReceiver.h:23) and a `cFmDecoder*` member (:124) come BEFORE the decoder header, then
+    `new cFmDecoder(this, ...)` (RadioReceiver.cpp:296-300), Reset, ProcessStream, the getters and
+    `delete` (:373).  Compile-only (g++ -fsyntax-only), C++14 like the reference's CMakeLists."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "cpp", "dropin_decl_order.cpp")
+    for std in ("-std=c++14", "-std=c++17"):
+        out = subprocess.run(["g++", std, "-fsyntax-only", "-Wall", "-Werror",
+                              "-I" + os.path.join(ROOT, "include"), src],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+    # and the same header where cRadioReceiver is only defined AFTER the include (receiver_demo.cpp)
+    out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                          os.path.join(ROOT, "tests", "cpp", "receiver_demo.cpp")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr

@@ -24,7 +24,9 @@ def test_pack_unpack_roundtrip():
     back = dg.unpack_rds_records(rec)
     assert back == [(int(c) + 8192, int(k), tuple(int(x) for x in b))
                     for c, k, b in zip(g["channel"], g["call_index"], g["blocks"])]
-    assert dg.pack_rds_records(g, 3).shape == (3, 4)  # truncation at capacity
+    import pytest
+    with pytest.raises(ValueError):  # more groups than records: refused, never dropped silently
+        dg.pack_rds_records(g, 3)
 
 
 WORKER = textwrap.dedent("""
