@@ -1,0 +1,246 @@
+"""Parity on the dispatch that bench.py times, not only on small batches.
+
+The launch code picks different kernels by batch size: from 1024 channels on the serial stage owns
+whole CUs (k_demod_serial<2, true>), with a channel count that is a multiple of 8 the IF FIR uses
+the XCD-aware block mapping, overlapped calls (concurrency 2) use two-tile FIR workgroups
+(k_if_fir_mt) in the headline geometry and the hand-scheduled tap loop for long filters, and the
+light part of a call is kept back until the next call.  Small-batch tests never reach those forms,
+so these run them at >= 1024 channels with overlapped calls: a handful of channels against the CPU
+oracle bit for bit on the very bytes the device generator produced, and the whole batch through a
+size-independent property (channels c and c + C/2 carry the same station: identical audio, status
+and RDS groups).
+
+Reference being compared: cDownsampleFilter (DownConvert.h:36-39, DownConvert.cpp:98-154) inside
+cFmDecoder::ProcessStream (FmDecode.cpp:417-502); ReadAsyncCB (RTL_SDR_Source.cpp:196-213) for
+byte input.
+"""
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+N = 65536
+
+
+def _bits_equal(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def _run_overlapped(pkg, fmsig, oracle, fs, D, C, sizes, check, u8, order=0, table=0, lag=2):
+    """C channels (c and c + C/2 the same station), calls of the given sizes submitted back to back
+    in concurrency 2 and consumed `lag` calls late, like bench.py.  Returns nothing; asserts."""
+    import torch
+    half = C // 2
+    chans = [fmsig.channel_params(fs, c % half) for c in range(C)]
+    gen = fmsig.DeviceGenerator(chans, "cuda")
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D, table_size=table,
+                                  if_filter_order=order), C, record_callbacks=False)
+    b.set_concurrency(2)
+    a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
+    dt = torch.uint8 if u8 else torch.float32
+    iq, audio, start = [], [], 0
+    for n in sizes:
+        n_al = (n + 1) // 2 * 2  # channel stride: a whole number of sample pairs
+        t = torch.zeros((C, n_al, 2), dtype=dt, device="cuda")
+        if n_al == n:
+            gen.generate(t, start, n)
+        else:  # ragged length: generate compactly, then spread to the padded stride
+            tmp = torch.empty((C, n, 2), dtype=dt, device="cuda")
+            gen.generate(tmp, start, n)
+            t[:, :n] = tmp
+        iq.append((t, n, n_al))
+        audio.append(torch.zeros((C, a_stride), dtype=torch.float32, device="cuda"))
+        start += n
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    nf, groups = [], []
+    for k, (t, n, n_al) in enumerate(iq):
+        nf.append(b.process_device(t.data_ptr(), n_al, n, audio[k].data_ptr(), a_stride, st, u8=u8))
+        if k >= lag:
+            b.wait(stream=st, lag=lag)
+            groups.append(b.collect_rds_array(cap=4 * C, stream=st, lag=lag))
+    b.wait(stream=st)
+    groups.append(b.collect_rds_array(cap=4 * C, stream=st))
+    torch.cuda.synchronize()
+
+    refs = {c: oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D, table_size=table,
+                                    if_filter_order=order) for c in check}
+    for k, (t, n, n_al) in enumerate(iq):
+        a = audio[k][:, :nf[k]].cpu().numpy()
+        for c in check:
+            x = t[c, :n].cpu().numpy().reshape(-1)
+            r = refs[c].process_stream_u8(x) if u8 else refs[c].process_stream(x)
+            assert _bits_equal(a[c], r), (k, c, n)
+        assert np.array_equal(a[:half].view(np.uint32), a[half:].view(np.uint32)), (k, n)
+    g = np.concatenate(groups)
+    lo, hi = g[g["channel"] < half], g[g["channel"] >= half]
+    key = lambda x, off: sorted((int(c) - off, int(k), tuple(int(v) for v in bl))
+                                for c, k, bl in zip(x["channel"], x["call_index"], x["blocks"]))
+    assert key(lo, 0) == key(hi, half)
+    for c in check:
+        mine = sorted((int(k), tuple(int(v) for v in bl)) for ch, k, bl in
+                      zip(g["channel"], g["call_index"], g["blocks"]) if ch == c)
+        assert mine == sorted((k, tuple(bl)) for k, bl in refs[c].rds_groups()), c
+        so, sg = refs[c].status(), b.status(c)
+        assert sg.stereo_detected == so.stereo
+        for f_o, f_g in ((so.if_level, sg.interface_level), (so.baseband_level, sg.baseband_level),
+                         (so.pilot_level, sg.pilot_level), (so.tuning_offset, sg.tuning_offset)):
+            assert np.float32(f_o) == np.float32(f_g), c
+    b.close()
+
+
+@pytest.mark.parametrize("u8", [False, True], ids=["f32", "u8"])
+def test_config5_on_its_benchmarked_dispatch(oracle, fmsig, u8):
+    """BASELINE config 5 (4096-tap cDownsampleFilter, 10 MS/s, D = 46) the way `bench.py --workload
+    config5` runs it: channel count a multiple of 8 and >= 1024 (XCD-aware mapping, TILE 256,
+    hand-scheduled tap loop, whole-CU serial stage), calls overlapped, outputs consumed late."""
+    pkg = load_package()
+    C = 1032
+    _run_overlapped(pkg, fmsig, oracle, 10e6, 46, C, [N] * 4,
+                    check=[0, 1, 7, 8, 515, 516, 1030, 1031], u8=u8, order=4096)
+
+
+@pytest.mark.parametrize("u8", [False, True], ids=["f32", "u8"])
+def test_config4_geometry_overlapped_ragged_two_tile_fir(oracle, fmsig, u8):
+    """The headline geometry (2.4 MS/s, D = 11, 88 taps) at >= 1024 channels with overlapped calls:
+    k_if_fir_mt<., 7, 2> and the whole-CU serial stage, on ragged call sizes -- odd lengths, a
+    partial last tile as the second tile of a workgroup, an odd tile count (the early
+    `tile >= ntiles` exit), a short first-tile history -- and on full blocks."""
+    pkg = load_package()
+    C = 1024
+    # outputs per call ~ n / 11, tiles of 64 outputs, two tiles per workgroup
+    sizes = [N, 10007, 8192, 65535, 33001, 45057, N, 8193, 21120]
+    _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, C, sizes,
+                    check=[0, 63, 64, 511, 512, 1023], u8=u8)
+
+
+def test_config3_shared_capture_overlapped(oracle, fmsig):
+    """BASELINE config 3 (256 channels from ONE capture, table_size 256) with overlapped calls and
+    late consumption, as `bench.py --workload config3` runs it."""
+    import torch
+    pkg = load_package()
+    fs, D, C, T, nblk, lag = 2.4e6, 11, 256, 256, 6, 2
+    stations = [fmsig.default_params(fs, f_offset=f0, amp=0.12, noise_sigma=0.004, seed=50 + i,
+                                     pi=0x5000 + i, ps="CAP%05d" % i, f_left=500.0 + 300 * i)
+                for i, f0 in enumerate((-600e3, -360e3, -150e3, 75e3, 300e3, 600e3))]
+    shifts = np.arange(C, dtype=np.int32) - 128
+    b = pkg.Batch(pkg.make_params(fs, 0.0, 48000.0, 15000.0, D, table_size=T), C,
+                  tuning_shifts=shifts, record_callbacks=False)
+    b.set_concurrency(2)
+    check = [0, 64, 90, 112, 136, 160, 192, 255]
+    refs = {c: oracle.OracleDecoder(fs, 0.0, 48000.0, 15000.0, D, table_size=T,
+                                    tuning_shift=int(shifts[c])) for c in check}
+    caps = []
+    for blk in range(nblk):
+        cap = np.zeros(2 * N, dtype=np.float32)
+        for p in stations:
+            cap += fmsig.generate_f32(p, blk * N, N)
+        caps.append(cap)
+    d_cap = [torch.from_numpy(c).cuda() for c in caps]
+    a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
+    audio = [torch.zeros((C, a_stride), dtype=torch.float32, device="cuda") for _ in range(nblk)]
+    st = torch.cuda.current_stream().cuda_stream
+    nf = []
+    for k in range(nblk):
+        nf.append(b.process_device(d_cap[k].data_ptr(), 0, N, audio[k].data_ptr(), a_stride, st))
+        if k >= lag:
+            b.wait(stream=st, lag=lag)
+    b.wait(stream=st)
+    torch.cuda.synchronize()
+    for k in range(nblk):
+        a = audio[k][:, :nf[k]].cpu().numpy()
+        for c in check:
+            assert _bits_equal(a[c], refs[c].process_stream(caps[k])), (k, c)
+    b.close()
+
+
+def test_process_host_is_synchronous_in_concurrency_2(oracle, fmsig):
+    """fmd_batch_process_host returns finished audio in every concurrency mode: in mode 2 the light
+    part of the call (audio tail) is kept back and the null stream is not ordered behind the call,
+    so the entry point has to submit it and wait before it copies the audio out."""
+    pkg = load_package()
+    fs, D, C = 2.4e6, 11, 3
+    ps = [fmsig.default_params(fs, noise_sigma=0.01, seed=40 + c, pi=0x4400 + c) for c in range(C)]
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C)
+    b.set_concurrency(2)
+    refs = [oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for _ in range(C)]
+    for blk in range(6):
+        iq = np.stack([fmsig.generate_f32(ps[c], blk * N, N) for c in range(C)])
+        audio = b.process_host(iq.view(np.complex64).reshape(C, N))
+        for c in range(C):
+            assert _bits_equal(audio[c], refs[c].process_stream(iq[c])), (blk, c)
+    b.close()
+
+
+def test_profiling_level_change_between_overlapped_calls(oracle, fmsig):
+    """fmd_batch_set_profiling(2) moves the next call onto the caller's stream with no event waits;
+    made between overlapped calls it must first let the calls in flight finish."""
+    import torch
+    pkg = load_package()
+    fs, D, C = 2.4e6, 11, 64
+    chans = [fmsig.channel_params(fs, c) for c in range(C)]
+    gen = fmsig.DeviceGenerator(chans, "cuda")
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
+    b.set_concurrency(2)
+    a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
+    nblk = 8
+    iq = [torch.empty((C, N, 2), dtype=torch.float32, device="cuda") for _ in range(nblk)]
+    audio = [torch.zeros((C, a_stride), dtype=torch.float32, device="cuda") for _ in range(nblk)]
+    for k in range(nblk):
+        gen.generate(iq[k], k * N, N)
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    nf = []
+    for k in range(nblk):
+        if k == 3:
+            b.set_profiling(2)  # no drain by the caller
+        if k == 6:
+            b.set_profiling(0)
+        nf.append(b.process_device(iq[k].data_ptr(), N, N, audio[k].data_ptr(), a_stride, st))
+    b.wait(stream=st)
+    torch.cuda.synchronize()
+    check = [0, 31, 63]
+    refs = {c: oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for c in check}
+    for k in range(nblk):
+        a = audio[k][:, :nf[k]].cpu().numpy()
+        for c in check:
+            assert _bits_equal(a[c], refs[c].process_stream(iq[k][c].cpu().numpy().reshape(-1))), (k, c)
+    b.close()
+
+
+def test_device_error_word_surfaces(monkeypatch, fmsig):
+    """A serial-stage hand-off that times out does not go unnoticed: the kernel sets a bit in the
+    batch's error word, fmd_batch_wait / collect_rds return FMD_ERR_DEVICE, later calls are refused
+    until fmd_batch_reset.  FMD_DEBUG_SPIN_LIMIT=0 makes every hand-off wait time out at once."""
+    import torch
+    pkg = load_package()
+    fs, D, C = 2.4e6, 11, 1024  # >= 1024 channels: the whole-CU serial stage with LDS hand-offs
+    monkeypatch.setenv("FMD_DEBUG_SPIN_LIMIT", "0")
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
+    monkeypatch.delenv("FMD_DEBUG_SPIN_LIMIT")
+    b.set_concurrency(2)
+    a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
+    iq = torch.zeros((C, N, 2), dtype=torch.float32, device="cuda")
+    audio = torch.zeros((C, a_stride), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    b.process_device(iq.data_ptr(), N, N, audio.data_ptr(), a_stride, st)
+    torch.cuda.synchronize()
+    with pytest.raises(pkg.FmdError, match="hand-off timed out"):
+        b.wait(stream=st)
+        torch.cuda.synchronize()
+        b.collect_rds_array(cap=16, stream=st)
+    with pytest.raises(pkg.FmdError, match="hand-off timed out"):
+        b.process_device(iq.data_ptr(), N, N, audio.data_ptr(), a_stride, st)
+    b.reset()  # clears the failure: the batch takes calls again
+    b.close()
+
+    # the same batch size without the knob: no error
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
+    b.set_concurrency(2)
+    b.process_device(iq.data_ptr(), N, N, audio.data_ptr(), a_stride, st)
+    b.wait(stream=st)
+    torch.cuda.synchronize()
+    b.collect_rds_array(cap=16, stream=st)
+    b.close()
