@@ -1810,11 +1810,8 @@ int fmd_receiver_write_iq(fmd_receiver* r, const float* iq, unsigned samples)
 {
   if (!r || (!iq && samples))
     return fail(FMD_ERR_ARG, "fmd_receiver_write_iq: null argument");
-  fmd::Receiver::Block blk;
-  blk.samples = samples;
-  blk.bytes.assign(reinterpret_cast<const uint8_t*>(iq),
-                   reinterpret_cast<const uint8_t*>(iq) + size_t(samples) * 8);
-  r->r.WriteDataBuffer(std::move(blk));
+  if (!r->r.Write(iq, samples, false))
+    return fail(FMD_ERR_DEVICE, "fmd_receiver_write_iq: no page-locked memory for the block");
   return FMD_OK;
 }
 
@@ -1822,23 +1819,20 @@ int fmd_receiver_write_u8(fmd_receiver* r, const uint8_t* buf, unsigned samples)
 {
   if (!r || (!buf && samples))
     return fail(FMD_ERR_ARG, "fmd_receiver_write_u8: null argument");
-  fmd::Receiver::Block blk;
-  blk.samples = samples;
-  blk.u8 = true;
-  blk.bytes.assign(buf, buf + size_t(samples) * 2);
-  r->r.WriteDataBuffer(std::move(blk));
+  if (!r->r.Write(buf, samples, true))
+    return fail(FMD_ERR_DEVICE, "fmd_receiver_write_u8: no page-locked memory for the block");
   return FMD_OK;
 }
 
 void fmd_receiver_end(fmd_receiver* r)
 {
   if (r)
-    r->r.EndDataBuffer();
+    r->r.End();
 }
 
 size_t fmd_receiver_queued_samples(fmd_receiver* r)
 {
-  return r ? r->r.SourceQueuedSamples() : 0;
+  return r ? r->r.QueuedSamples() : 0;
 }
 
 void fmd_receiver_set_stream_change(fmd_receiver* r)
@@ -1851,7 +1845,7 @@ int fmd_receiver_demux_read(fmd_receiver* r, fmd_demux_packet* pkt)
 {
   if (!r || !pkt)
     return fail(FMD_ERR_ARG, "fmd_receiver_demux_read: null argument");
-  return r->r.DemuxRead(pkt);
+  return r->r.NextPacket(pkt);
 }
 
 int fmd_receiver_signal_status(fmd_receiver* r, float* interface_level_db, float* audio_level_db,
@@ -1860,7 +1854,7 @@ int fmd_receiver_signal_status(fmd_receiver* r, float* interface_level_db, float
   if (!r || !interface_level_db || !audio_level_db || !stereo)
     return fail(FMD_ERR_ARG, "fmd_receiver_signal_status: null argument");
   bool st = false;
-  if (!r->r.GetSignalStatus(*interface_level_db, *audio_level_db, st))
+  if (!r->r.Levels(*interface_level_db, *audio_level_db, st))
     return 0;
   *stereo = st ? 1 : 0;
   return 1;
@@ -1870,7 +1864,7 @@ int fmd_receiver_pvr_signal_status(fmd_receiver* r, fmd_pvr_signal_status* out)
 {
   if (!r || !out)
     return fail(FMD_ERR_ARG, "fmd_receiver_pvr_signal_status: null argument");
-  return r->r.GetSignalStatus(*out) ? 1 : 0;
+  return r->r.PvrStatus(*out) ? 1 : 0;
 }
 
 fmd_decoder* fmd_receiver_decoder(fmd_receiver* r)
@@ -1948,26 +1942,14 @@ int fmd_design_tuner_lut(unsigned table_size, int freq_shift, float* out, unsign
 
 int fmd_uecp_stuff_frame(const uint8_t* frame, unsigned len, uint8_t* out, unsigned cap)
 {
-  // cRadioReceiver::AddUECPDataFrame (RadioReceiver.cpp:387-414)
+  if (!frame && len)
+    return -1;
   unsigned k = 0;
-  auto put = [&](uint8_t v) {
+  fmd::uecp_stuff(frame, len, [&](uint8_t v) {
     if (k < cap)
       out[k] = v;
     k++;
-  };
-  put(0xFE);
-  for (unsigned i = 0; i < len; i++)
-  {
-    const uint8_t v = frame[i];
-    if (v < 0xFD)
-      put(v);
-    else
-    {
-      put(0xFD);
-      put(uint8_t((v & 3) - 1));
-    }
-  }
-  put(0xFF);
+  });
   return k <= cap ? int(k) : -1;
 }
 

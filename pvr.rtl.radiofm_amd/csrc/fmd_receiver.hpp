@@ -1,30 +1,42 @@
 /*
- * fmd_receiver.hpp -- the stream side of cRadioReceiver around the decoder (host code).
+ * fmd_receiver.hpp -- a demux session around one GPU decoder (fmd_receiver_* of include/fmd.h).
  *
- * Mirrors, member for member, what the reference does between its RTL-SDR source thread and
- * Kodi's demuxer (all file:line relative to /root/reference/src/):
- *   OpenLiveStream's stream state        RadioReceiver.cpp:296-349
- *   AddUECPDataFrame (byte stuffing)     RadioReceiver.cpp:387-414
- *   SourceQueuedSamples                  RadioReceiver.cpp:420-424
- *   WriteDataBuffer / EndDataBuffer      RadioReceiver.cpp:426-443
- *   SourceGetSamples                     RadioReceiver.cpp:445-460
- *   DemuxRead                            RadioReceiver.cpp:462-542
- *   GetSignalStatus (both)               RadioReceiver.cpp:544-582
- *   SetChannelName                       RadioReceiver.cpp:600-612 (no settings dialog here)
- * The decoder is an fmd_decoder (GPU); the audio level meter of DemuxRead (:526-528) runs on the
- * device with the audio (k_audio_tail) and is read back through fmd_batch_get_audio_level.
+ * What a host that is not Kodi needs between its IQ source thread and its packet consumer, with
+ * the packet stream byte-identical to what cRadioReceiver hands to Kodi.  The design is this
+ * library's own; only the observable behaviour follows the reference (all file:line relative to
+ * /root/reference/src/):
+ *   packet order per read: stream change, else pending RDS bytes, else one decoded IQ block
+ *                                                                 RadioReceiver.cpp:462-542
+ *   audio packet: pcm_f32le, duration = floats * STREAM_TIME_BASE / 2 / 48000, pts running sum
+ *                                                                 RadioReceiver.cpp:531-539
+ *   RDS packet: 0xFE, frame with 0xFD escapes, 0xFF per UECP frame; a frame is refused while more
+ *   than 16384 bytes are pending                                  RadioReceiver.cpp:387-414
+ *   both GetSignalStatus: dB values, Signal / SNR integers, status text
+ *                                                                 RadioReceiver.cpp:544-582
+ *   PS name trimmed of white space                                RadioReceiver.cpp:600-612
+ *
+ * Three parts:
+ *   BlockPool  IQ blocks in page-locked host memory, recycled through a free list: the H2D copy of
+ *              a block is a DMA from pinned memory, and a steady stream allocates nothing.
+ *   UecpBytes  the byte-stuffed RDS stream waiting for its packet.
+ *   Receiver   packet sequencing, the presentation clock, status read-outs.
+ * The audio level meter of the reference's demux loop (SamplesMeanRMS over the packet + EMA,
+ * RadioReceiver.cpp:526-528) is computed on the device together with the audio (k_audio_tail) and
+ * read back through fmd_batch_get_audio_level.
  */
 #pragma once
 
+#include <hip/hip_runtime.h>
+
 #include <algorithm>
-#include <cctype>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
-#include <deque>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -33,253 +45,373 @@
 namespace fmd
 {
 
+/* 0xFE, payload with 0xFD / 0xFE / 0xFF written as 0xFD followed by (v & 3) - 1, 0xFF
+ * (RadioReceiver.cpp:387-414).  emit(byte) receives the stuffed stream. */
+template <class Emit>
+inline void uecp_stuff(const uint8_t* frame, unsigned len, Emit&& emit)
+{
+  emit(uint8_t(0xFE));
+  for (const uint8_t* p = frame; p != frame + len; ++p)
+  {
+    if (*p >= 0xFD)
+    {
+      emit(uint8_t(0xFD));
+      emit(uint8_t((*p & 3u) - 1u));
+    }
+    else
+      emit(*p);
+  }
+  emit(uint8_t(0xFF));
+}
+
+/* One block of IQ as the source delivered it, in pinned host memory. */
+struct IqBlock
+{
+  void* mem = nullptr;  // hipHostMalloc
+  size_t capacity = 0;  // bytes
+  unsigned samples = 0;
+  bool bytes_in = false; // RTL-SDR (I, Q) byte pairs instead of complex<float>
+  IqBlock* next = nullptr;
+};
+
+/* FIFO of filled blocks plus a free list of empty ones.  One producer (the source thread) and one
+ * consumer (the demux thread); the queue is unbounded like the reference's (it warns about a
+ * growing backlog, it never drops), but blocks are reused once the consumer hands them back. */
+class BlockPool
+{
+public:
+  ~BlockPool()
+  {
+    release_chain(m_head);
+    release_chain(m_free);
+  }
+
+  /* copies `bytes` bytes into a recycled (or new) pinned block and appends it; false = out of
+   * memory */
+  bool push(const void* data, size_t bytes, unsigned samples, bool bytes_in)
+  {
+    IqBlock* blk = take_free(bytes);
+    if (!blk)
+      return false;
+    std::memcpy(blk->mem, data, bytes);
+    blk->samples = samples;
+    blk->bytes_in = bytes_in;
+    blk->next = nullptr;
+    {
+      std::lock_guard<std::mutex> g(m_lock);
+      if (m_tail)
+        m_tail->next = blk;
+      else
+        m_head = blk;
+      m_tail = blk;
+      m_backlog += samples;
+    }
+    m_wake.notify_one();
+    return true;
+  }
+
+  void close()
+  {
+    {
+      std::lock_guard<std::mutex> g(m_lock);
+      m_closed = true;
+    }
+    m_wake.notify_all();
+  }
+
+  /* next block in arrival order; waits while the queue is empty and the source has not ended.
+   * nullptr = ended and drained. */
+  IqBlock* pop()
+  {
+    std::unique_lock<std::mutex> g(m_lock);
+    // bounded waits (20 ms, the reference's poll interval): a lost wake-up costs one interval at most
+    while (!m_head && !m_closed)
+      m_wake.wait_for(g, std::chrono::milliseconds(20));
+    IqBlock* blk = m_head;
+    if (blk)
+    {
+      m_head = blk->next;
+      if (!m_head)
+        m_tail = nullptr;
+      m_backlog -= blk->samples;
+      blk->next = nullptr;
+    }
+    return blk;
+  }
+
+  void recycle(IqBlock* blk)
+  {
+    std::lock_guard<std::mutex> g(m_lock);
+    blk->next = m_free;
+    m_free = blk;
+  }
+
+  size_t backlog()
+  {
+    std::lock_guard<std::mutex> g(m_lock);
+    return m_backlog;
+  }
+
+private:
+  IqBlock* take_free(size_t bytes)
+  {
+    IqBlock* blk = nullptr;
+    {
+      std::lock_guard<std::mutex> g(m_lock);
+      blk = m_free;
+      if (blk)
+        m_free = blk->next;
+    }
+    if (blk && blk->capacity >= bytes)
+      return blk;
+    if (!blk)
+      blk = new (std::nothrow) IqBlock;
+    if (!blk)
+      return nullptr;
+    if (blk->mem)
+      (void)hipHostFree(blk->mem);
+    blk->mem = nullptr;
+    // whole blocks of the largest call size, so a recycled block fits the next one
+    const size_t want = std::max(bytes, size_t(FMD_MAX_BLOCK) * 8);
+    if (hipHostMalloc(&blk->mem, want, hipHostMallocDefault) != hipSuccess)
+    {
+      delete blk;
+      return nullptr;
+    }
+    blk->capacity = want;
+    return blk;
+  }
+  static void release_chain(IqBlock* b)
+  {
+    while (b)
+    {
+      IqBlock* n = b->next;
+      if (b->mem)
+        (void)hipHostFree(b->mem);
+      delete b;
+      b = n;
+    }
+  }
+
+  std::mutex m_lock;
+  std::condition_variable m_wake;
+  IqBlock* m_head = nullptr;
+  IqBlock* m_tail = nullptr;
+  IqBlock* m_free = nullptr;
+  size_t m_backlog = 0; // samples queued
+  bool m_closed = false;
+};
+
+/* The RDS byte stream between the group decoder (which appends whole frames from inside the
+ * decode call) and the packet reader (which takes everything that is pending). */
+class UecpBytes
+{
+public:
+  static constexpr size_t kRefuseAbove = 16384; // RadioReceiver.cpp:389
+
+  bool append_frame(const uint8_t* frame, unsigned len)
+  {
+    std::lock_guard<std::mutex> g(m_lock);
+    if (m_pending.size() > kRefuseAbove)
+      return false; // the consumer is not keeping up: the frame is dropped, as in the reference
+    uecp_stuff(frame, len, [this](uint8_t v) { m_pending.push_back(v); });
+    return true;
+  }
+  /* moves the pending bytes into `out`; false = nothing pending */
+  bool take_all(std::vector<uint8_t>& out)
+  {
+    std::lock_guard<std::mutex> g(m_lock);
+    if (m_pending.empty())
+      return false;
+    out.swap(m_pending);
+    m_pending.clear();
+    return true;
+  }
+
+private:
+  std::mutex m_lock;
+  std::vector<uint8_t> m_pending;
+};
+
 class Receiver
 {
 public:
-  struct Block
-  {
-    std::vector<uint8_t> bytes; // complex<float> or (I,Q) byte pairs
-    unsigned samples = 0;
-    bool u8 = false;
-  };
-
   Receiver(const fmd_params& p, double tuner_freq, const char* adapter_name)
-    : m_IfRate(p.sample_rate_if), m_activeTunerFreq(tuner_freq),
-      m_adapterName(adapter_name ? adapter_name : "")
+    : m_if_rate(p.sample_rate_if), m_tuner_hz(tuner_freq), m_adapter(adapter_name ? adapter_name : "")
   {
   }
   ~Receiver()
   {
-    if (m_FMDecoder)
-      fmd_destroy(m_FMDecoder);
+    if (m_decoder)
+      fmd_destroy(m_decoder);
   }
+  Receiver(const Receiver&) = delete;
+  Receiver& operator=(const Receiver&) = delete;
 
-  /* RadioReceiver.cpp:296-300, :345-349 */
+  /* decoder + stream state of a freshly opened live stream (RadioReceiver.cpp:296-349): a stream
+   * change is announced first, the clock starts at one STREAM_TIME_BASE, the decoder is reset */
   int Open(const fmd_params& p)
   {
     fmd_callbacks cb{};
-    cb.add_uecp_frame = &Receiver::OnFrame;
-    cb.set_channel_name = &Receiver::OnName;
-    cb.is_setting_active = &Receiver::OnActive;
-    int rc = fmd_create(&p, &cb, this, &m_FMDecoder);
+    cb.add_uecp_frame = [](void* self, unsigned, const uint8_t* f, unsigned n) -> int {
+      return static_cast<Receiver*>(self)->m_rds.append_frame(f, n) ? 1 : 0;
+    };
+    cb.set_channel_name = [](void* self, unsigned, const char name[9]) -> int {
+      static_cast<Receiver*>(self)->set_station_name(name);
+      return 1; // no settings dialog in this host: the name is always accepted
+    };
+    cb.is_setting_active = [](void*, unsigned) -> int { return 0; };
+    const int rc = fmd_create(&p, &cb, this, &m_decoder);
     if (rc != FMD_OK)
       return rc;
-    m_StreamChange = true;
-    m_PTSNext = FMD_STREAM_TIME_BASE;
-    return fmd_reset(m_FMDecoder);
+    m_announce_change.store(true);
+    m_clock = double(FMD_STREAM_TIME_BASE);
+    return fmd_reset(m_decoder);
   }
 
-  /* :387-414 */
-  bool AddUECPDataFrame(const uint8_t* frame, unsigned length)
+  /* source side */
+  bool Write(const void* data, unsigned samples, bool bytes_in)
   {
-    if (m_UECPOutputBuffer.size() > 16384)
-      return false;
-    std::unique_lock<std::mutex> lock(m_UECPMutex);
-    m_UECPOutputBuffer.push_back(0xFE);
-    for (unsigned i = 0; i < length; i++)
+    if (!samples)
+      return true; // empty deliveries are ignored (RadioReceiver.cpp:428)
+    return m_blocks.push(data, size_t(samples) * (bytes_in ? 2 : 8), samples, bytes_in);
+  }
+  void End() { m_blocks.close(); }
+  size_t QueuedSamples() { return m_blocks.backlog(); }
+  void SetStreamChange() { m_announce_change.store(true); }
+
+  /* consumer side: 1 = packet, 0 = source ended and everything was delivered, < 0 = decoder error */
+  int NextPacket(fmd_demux_packet* pkt)
+  {
+    *pkt = fmd_demux_packet{};
+    if (m_announce_change.exchange(false))
     {
-      const uint8_t value = frame[i];
-      if (value < 0xFD)
-        m_UECPOutputBuffer.push_back(value);
-      else
-      {
-        m_UECPOutputBuffer.push_back(0xFD);
-        m_UECPOutputBuffer.push_back(uint8_t((value & 3) - 1));
-      }
-    }
-    m_UECPOutputBuffer.push_back(0xFF);
-    return true;
-  }
-
-  /* :600-612 with m_SettingsDialog == nullptr; StringUtils::Trim = isspace on both ends */
-  bool SetChannelName(std::string name)
-  {
-    std::unique_lock<std::mutex> lock(m_AudioSignalMutex);
-    auto notspace = [](char c) { return !::isspace((unsigned char)c); };
-    name.erase(name.begin(), std::find_if(name.begin(), name.end(), notspace));
-    name.erase(std::find_if(name.rbegin(), name.rend(), notspace).base(), name.end());
-    m_channelName = name;
-    return true;
-  }
-
-  /* :420-424 */
-  size_t SourceQueuedSamples()
-  {
-    std::unique_lock<std::mutex> lock(m_AudioSourceMutex);
-    return m_AudioSourceSize;
-  }
-
-  /* :426-436 */
-  void WriteDataBuffer(Block&& blk)
-  {
-    if (blk.samples)
-    {
-      std::unique_lock<std::mutex> lock(m_AudioSourceMutex);
-      m_AudioSourceSize += blk.samples;
-      m_AudioSourceBuffer.push_back(std::move(blk));
-      if (m_AudioSourceBuffer.size() > 3)
-        m_AudioSourceEvent.notify_one();
-    }
-  }
-
-  /* :438-443 */
-  void EndDataBuffer()
-  {
-    std::unique_lock<std::mutex> lock(m_AudioSourceMutex);
-    m_AudioSourceEndMarked = true;
-    m_AudioSourceEvent.notify_all();
-  }
-
-  void SetStreamChange() { m_StreamChange = true; }
-
-  /* :462-542.  Returns 1 with *pkt filled, 0 for the reference's nullptr, < 0 on a decoder error. */
-  int DemuxRead(fmd_demux_packet* pkt)
-  {
-    std::memset(pkt, 0, sizeof(*pkt));
-    if (m_StreamChange)
-    { // :471-477
       pkt->stream_id = FMD_STREAM_CHANGE;
-      m_StreamChange = false;
       return 1;
     }
-    {
-      std::unique_lock<std::mutex> lock(m_UECPMutex);
-      if (!m_UECPOutputBuffer.empty())
-      { // :482-503
-        m_packet.assign(m_UECPOutputBuffer.begin(), m_UECPOutputBuffer.end());
-        pkt->data = m_packet.data();
-        pkt->stream_id = FMD_STREAM_RDS;
-        pkt->size = int(m_packet.size());
-        pkt->pts = m_PTSNext;
-        m_UECPOutputBuffer.clear();
-        return 1;
-      }
+    if (m_rds.take_all(m_payload))
+    { // everything the group decoder produced since the last read, stamped with the clock as it is
+      pkt->stream_id = FMD_STREAM_RDS;
+      pkt->data = m_payload.data();
+      pkt->size = int(m_payload.size());
+      pkt->pts = m_clock;
+      return 1;
     }
-    // :510-514 "Input buffer is growing (system too slow)"
-    if (!m_AudioSourceBufferWarning && SourceQueuedSamples() > 10 * m_IfRate)
-      m_AudioSourceBufferWarning = true;
+    // "Input buffer is growing (system too slow)": more than 10 s of IQ waiting (:509-513)
+    if (!m_backlog_warned && double(m_blocks.backlog()) > 10.0 * m_if_rate)
+      m_backlog_warned = true;
 
-    Block blk;
-    if (!SourceGetSamples(blk))
+    IqBlock* blk = m_blocks.pop();
+    if (!blk)
       return 0;
-    m_packet.resize(size_t(blk.samples) * sizeof(float) * 2); // :519-520
-    float* audio = reinterpret_cast<float*>(m_packet.data());
-    const int iSize =
-        blk.u8 ? fmd_process_stream_u8(m_FMDecoder, blk.bytes.data(), blk.samples, audio)
-               : fmd_process_stream(m_FMDecoder, reinterpret_cast<const float*>(blk.bytes.data()),
-                                    blk.samples, audio);
-    if (iSize < 0)
-      return iSize;
-    // :526-528: SamplesMeanRMS over the packet and the level average were computed with the audio
-    const double duration = (double)(iSize)*FMD_STREAM_TIME_BASE / 2 / 48000; // :531
-    pkt->data = m_packet.data();
+    // the caller-visible buffer has the reference's size: 2 floats per IQ sample (:519-520)
+    m_payload.resize(size_t(blk->samples) * 2 * sizeof(float));
+    float* pcm = reinterpret_cast<float*>(m_payload.data());
+    int floats;
+    {
+      std::lock_guard<std::mutex> g(m_status_lock); // status read-outs see whole calls only
+      floats = blk->bytes_in
+                   ? fmd_process_stream_u8(m_decoder, static_cast<const uint8_t*>(blk->mem), blk->samples, pcm)
+                   : fmd_process_stream(m_decoder, static_cast<const float*>(blk->mem), blk->samples, pcm);
+    }
+    m_blocks.recycle(blk);
+    if (floats < 0)
+      return floats;
+    const double span = double(floats) * FMD_STREAM_TIME_BASE / 2 / 48000;
     pkt->stream_id = FMD_STREAM_AUDIO;
-    pkt->size = int(iSize * sizeof(float));
-    pkt->duration = duration;
-    pkt->pts = m_PTSNext;
-    m_PTSNext = m_PTSNext + duration;
+    pkt->data = m_payload.data();
+    pkt->size = int(size_t(floats) * sizeof(float));
+    pkt->duration = span;
+    pkt->pts = m_clock;
+    m_clock += span;
     return 1;
   }
 
-  /* :544-556 */
-  bool GetSignalStatus(float& interfaceLevel, float& audioLevel, bool& stereo)
+  /* the three values of GetSignalStatus(float&, float&, bool&); false while no stream is running
+   * or a stream change is still to be announced */
+  bool Levels(float& if_db, float& audio_db, bool& stereo)
   {
-    std::unique_lock<std::mutex> lock(m_AudioSignalMutex);
-    if (!m_FMDecoder || m_StreamChange)
+    Snapshot s;
+    if (!snapshot(s))
       return false;
-    fmd_status st{};
-    if (fmd_get_status(m_FMDecoder, &st) != FMD_OK)
-      return false;
-    interfaceLevel = 20 * std::log10(st.interface_level);
-    audioLevel = 20 * std::log10(AudioLevel()) + 3.01;
-    stereo = st.stereo_detected != 0;
+    if_db = s.if_db;
+    audio_db = s.audio_db;
+    stereo = s.st.stereo_detected != 0;
     return true;
   }
 
-  /* :558-582.  The format string has five conversions for six arguments, so "IF=" shows the tuned
-   * frequency, "BB=" the interface level and "Audio=" the baseband level; kept as is. */
-  bool GetSignalStatus(fmd_pvr_signal_status& out)
+  /* PVRSignalStatus.  The reference's format string has five conversions for six arguments, so its
+   * "IF=" shows the tuned frequency in MHz, "BB=" the interface level and "Audio=" the baseband
+   * level; hosts parse that text, so it is reproduced as is. */
+  bool PvrStatus(fmd_pvr_signal_status& out)
   {
-    std::unique_lock<std::mutex> lock(m_AudioSignalMutex);
-    if (!m_FMDecoder || m_StreamChange)
+    Snapshot s;
+    if (!snapshot(s))
       return false;
-    fmd_status st{};
-    if (fmd_get_status(m_FMDecoder, &st) != FMD_OK)
-      return false;
-    const float interfaceLevel = 20 * std::log10(st.interface_level);
-    const float audioLevel = 20 * std::log10(AudioLevel()) + 3.01;
-    std::memset(&out, 0, sizeof(out));
+    out = fmd_pvr_signal_status{};
+    const double tuned_mhz = (m_tuner_hz + s.st.tuning_offset) * 1.0e-6;
+    const double bb_db = 20 * std::log10(s.st.baseband_level) + 3.01;
     std::snprintf(out.adapter_status, sizeof(out.adapter_status),
-                  "Freq.=%8.4fMHz - %s - IF=%+5.1fdB  BB=%+5.1fdB  Audio=%+5.1fdB",
-                  m_activeTunerFreq / 1000000, st.stereo_detected ? "Stereo" : "Mono",
-                  (m_activeTunerFreq + st.tuning_offset) * 1.0e-6, interfaceLevel,
-                  20 * std::log10(st.baseband_level) + 3.01);
-    std::snprintf(out.adapter_name, sizeof(out.adapter_name), "%s", m_adapterName.c_str());
-    std::snprintf(out.provider_name, sizeof(out.provider_name), "%s", m_channelName.c_str());
-    out.signal = int(2.5 * (interfaceLevel + 40) * 656);
-    out.snr = int((audioLevel + 100) * 656);
+                  "Freq.=%8.4fMHz - %s - IF=%+5.1fdB  BB=%+5.1fdB  Audio=%+5.1fdB", m_tuner_hz / 1000000,
+                  s.st.stereo_detected ? "Stereo" : "Mono", tuned_mhz, s.if_db, bb_db);
+    std::snprintf(out.adapter_name, sizeof(out.adapter_name), "%s", m_adapter.c_str());
+    std::snprintf(out.provider_name, sizeof(out.provider_name), "%s", s.station.c_str());
+    out.signal = int(2.5 * (s.if_db + 40) * 656);
+    out.snr = int((s.audio_db + 100) * 656);
     return true;
   }
 
-  fmd_decoder* Decoder() { return m_FMDecoder; }
-  bool BufferWarning() const { return m_AudioSourceBufferWarning; }
+  fmd_decoder* Decoder() { return m_decoder; }
+  bool BacklogWarned() const { return m_backlog_warned; }
 
 private:
-  /* :445-460 */
-  bool SourceGetSamples(Block& samples)
+  struct Snapshot
   {
-    std::unique_lock<std::mutex> lock(m_AudioSourceMutex);
-    while (m_AudioSourceBuffer.empty() && !m_AudioSourceEndMarked)
-      m_AudioSourceEvent.wait_for(lock, std::chrono::milliseconds(20));
-    if (!m_AudioSourceBuffer.empty())
-    {
-      m_AudioSourceSize -= m_AudioSourceBuffer.front().samples;
-      std::swap(samples, m_AudioSourceBuffer.front());
-      m_AudioSourceBuffer.pop_front();
-      return true;
-    }
-    return false;
-  }
-
-  float AudioLevel() // m_AudioLevel
+    fmd_status st{};
+    float if_db = 0, audio_db = 0;
+    std::string station;
+  };
+  bool snapshot(Snapshot& s)
   {
-    fmd_audio_level a{};
-    (void)fmd_batch_get_audio_level(fmd_decoder_batch(m_FMDecoder), 0, &a);
-    return a.level;
+    std::lock_guard<std::mutex> g(m_status_lock);
+    if (!m_decoder || m_announce_change.load())
+      return false;
+    if (fmd_get_status(m_decoder, &s.st) != FMD_OK)
+      return false;
+    fmd_audio_level lvl{};
+    (void)fmd_batch_get_audio_level(fmd_decoder_batch(m_decoder), 0, &lvl);
+    s.if_db = 20 * std::log10(s.st.interface_level);
+    s.audio_db = 20 * std::log10(lvl.level) + 3.01;
+    s.station = m_station;
+    return true;
   }
-
-  static int OnFrame(void* user, unsigned, const uint8_t* frame, unsigned len)
+  /* called from inside the decode call (the status lock is held by this thread's NextPacket) */
+  void set_station_name(const char name[9])
   {
-    return static_cast<Receiver*>(user)->AddUECPDataFrame(frame, len) ? 1 : 0;
+    std::string t(name);
+    const char* ws = " \t\n\v\f\r";
+    const size_t a = t.find_first_not_of(ws);
+    const size_t z = t.find_last_not_of(ws);
+    m_station = a == std::string::npos ? std::string() : t.substr(a, z - a + 1);
   }
-  static int OnName(void* user, unsigned, const char name[9])
-  {
-    return static_cast<Receiver*>(user)->SetChannelName(std::string(name)) ? 1 : 0;
-  }
-  static int OnActive(void*, unsigned) { return 0; } // IsSettingActive: no dialog
 
   static fmd_batch* fmd_decoder_batch(fmd_decoder* d);
 
-  double m_IfRate;
-  double m_activeTunerFreq;
-  std::string m_adapterName;
-  std::string m_channelName;
-  bool m_StreamChange = false;
-  fmd_decoder* m_FMDecoder = nullptr;
+  const double m_if_rate;
+  const double m_tuner_hz;
+  const std::string m_adapter;
 
-  std::mutex m_UECPMutex;
-  std::vector<uint8_t> m_UECPOutputBuffer;
-  std::mutex m_AudioSignalMutex;
-  double m_PTSNext = 0.0;
+  fmd_decoder* m_decoder = nullptr;
+  BlockPool m_blocks;
+  UecpBytes m_rds;
+  std::atomic<bool> m_announce_change{false};
+  double m_clock = 0.0; // pts of the next packet
+  bool m_backlog_warned = false;
 
-  size_t m_AudioSourceSize = 0;
-  std::deque<Block> m_AudioSourceBuffer;
-  std::mutex m_AudioSourceMutex;
-  std::condition_variable m_AudioSourceEvent;
-  bool m_AudioSourceEndMarked = false;
-  bool m_AudioSourceBufferWarning = false;
+  std::mutex m_status_lock; // decode call vs. status read-outs from another thread
+  std::string m_station;    // written inside the decode call, read under m_status_lock
 
-  std::vector<uint8_t> m_packet; // pData of the packet handed out last
+  std::vector<uint8_t> m_payload; // data of the packet handed out last
 };
 
 } // namespace fmd
