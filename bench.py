@@ -105,6 +105,10 @@ def main():
                     help="fmd_batch_set_concurrency mode (2 = calls overlap, the default)")
     ap.add_argument("--stage-profile", action="store_true",
                     help="after the timed region, run 3 extra steps with per-stage events")
+    ap.add_argument("--verify", action="store_true",
+                    help="before the timed region: rank 0 checks the audio and RDS records it gathered "
+                         "from every rank (a few channels each, first steps) bit for bit against its own "
+                         "recomputation of those channels in a small batch; exits 4 on a mismatch")
     ap.add_argument("--watchdog", type=int, default=900,
                     help="seconds after which a run that has not finished kills itself (a hung "
                          "collective or kernel must not keep the box busy)")
@@ -205,62 +209,87 @@ def main():
     a_stride = (batch.max_audio_floats(N) + 63) // 64 * 64
     NBUF = 6  # outputs are consumed three steps after they are produced
     audio = [torch.zeros((C, a_stride), dtype=torch.float32, device=dev) for _ in range(NBUF)]
-    RCAP = C  # RDS records gathered per rank per step (<= 1 group per channel per 27 ms step)
+    RCAP = C  # RDS records per rank per step (a group takes 87.6 ms, a step 27.3 ms: <= 1 per channel)
     rds_dev = [torch.zeros((RCAP, 4), dtype=torch.int32, device=dev) for _ in range(NBUF)]
-    if world > 1 and rank == 0 and backend == "nccl":
-        g_audio = [[torch.empty_like(audio[0]) for _ in range(world)] for _ in range(NBUF)]
-        g_rds = [[torch.empty_like(rds_dev[0]) for _ in range(world)] for _ in range(NBUF)]
+    # N > 1 (and --verify): the RDS groups of a step leave the decoder as fixed-size records in device
+    # memory (fmd_batch_export_rds_device) and go into the gather as they are -- no host round trip.
+    # N = 1: the host pulls them (fmd_batch_collect_rds), like an application that runs the UECP
+    # group decoder would.
+    use_export = world > 1 or args.verify
+    g_audio = g_rds = None
+    if rank == 0 and (world > 1 or args.verify):
+        on = dev if (backend == "nccl" or world == 1) else "cpu"
+        g_audio = [[torch.empty((C, a_stride), dtype=torch.float32, device=on) for _ in range(world)]
+                   for _ in range(NBUF)]
+        g_rds = [[torch.empty((RCAP, 4), dtype=torch.int32, device=on) for _ in range(world)]
+                 for _ in range(NBUF)]
+    group_acc = torch.zeros((), dtype=torch.int64, device=dev)  # groups counted on the device
     stream = torch.cuda.current_stream().cuda_stream
     pending = [None] * NBUF
     total_groups = 0
 
     batch.set_concurrency(args.concurrency)  # 2: FIR of step i+1 overlaps the serial stages of step i
     LAG = 3  # outputs of step i are consumed after step i+3 is submitted: the host never stalls
-    groups_by_call = {}
     state = {"submitted": -1, "finalized": -1}
 
     def pull_groups(lag):
         nonlocal total_groups
         got = batch.collect_rds_array(cap=4 * RCAP, stream=stream, lag=lag)
         total_groups += int(got.size)
-        if world > 1 and got.size:
-            for ci in np.unique(got["call_index"]):
-                groups_by_call.setdefault(int(ci), []).append(got[got["call_index"] == ci])
 
-    def finalize(i):
-        """Outputs of step i (call index i+1): its RDS groups are on the host; with N > 1 its
-        audio and RDS records are gathered to rank 0 over RCCL on the side stream."""
+    def finalize(i, lag):
+        """Outputs of step i (call index i+1), complete on the torch stream: with N > 1 its audio and
+        RDS records are gathered to rank 0 over RCCL on the side stream (overlapping the next steps'
+        compute); rank 0 counts the groups that arrived."""
         slot = i % NBUF
+        if use_export:
+            batch.export_rds_device(rds_dev[slot].data_ptr(), RCAP, channel_offset=rank * C,
+                                    stream=stream, lag=lag)
         if world > 1:
-            parts = groups_by_call.pop(i + 1, [])
-            g = np.concatenate(parts) if parts else np.zeros(0, dtype=pkg.RDS_GROUP_DTYPE)
-            rec = dg.pack_rds_records(g, RCAP, channel_offset=rank * C)
-            rds_dev[slot].copy_(torch.from_numpy(rec), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ev)
-                if backend == "nccl":
-                    w1, w2 = dg.gather_step(audio[slot], rds_dev[slot],
-                                            g_audio[slot] if rank == 0 else None,
-                                            g_rds[slot] if rank == 0 else None, dst=0, async_op=True)
-                else:  # host-staged (development only)
-                    comm_stream.synchronize()
-                    a_h, r_h = audio[slot].cpu(), rds_dev[slot].cpu()
-                    ga = [torch.empty_like(a_h) for _ in range(world)] if rank == 0 else None
-                    gr = [torch.empty_like(r_h) for _ in range(world)] if rank == 0 else None
-                    w1, w2 = dg.gather_step(a_h, r_h, ga, gr, dst=0, async_op=True)
-            pending[slot] = [w1, w2]
+            if backend == "nccl":
+                with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(ev)
+                    # blocking for the side stream only: the host does not wait
+                    dg.gather_step(audio[slot], rds_dev[slot], g_audio[slot] if rank == 0 else None,
+                                   g_rds[slot] if rank == 0 else None, dst=0, async_op=False)
+                    if rank == 0:
+                        for r in range(world):
+                            group_acc.add_((g_rds[slot][r][:, 0] != 0).sum())
+                    done = torch.cuda.Event()
+                    done.record(comm_stream)
+                pending[slot] = done
+            else:  # host-staged over gloo (development aid: several ranks on one GPU)
+                ev.synchronize()
+                a_h, r_h = audio[slot].cpu(), rds_dev[slot].cpu()
+                w = dg.gather_step(a_h, r_h, g_audio[slot] if rank == 0 else None,
+                                   g_rds[slot] if rank == 0 else None, dst=0, async_op=True)
+                pending[slot] = list(w)
+        elif use_export:  # one rank, --verify: "gathered" = this rank's own outputs
+            g_audio[slot][0].copy_(audio[slot], non_blocking=True)
+            g_rds[slot][0].copy_(rds_dev[slot], non_blocking=True)
+            group_acc.add_((rds_dev[slot][:, 0] != 0).sum())
         state["finalized"] = i
+
+    def release(slot):
+        """Before a slot's buffers are written again: its gather must have read them."""
+        if pending[slot] is None:
+            return
+        if isinstance(pending[slot], list):
+            for w in pending[slot]:
+                w.wait()
+            if rank == 0:
+                group_acc.add_(int(sum((t[:, 0] != 0).sum() for t in g_rds[slot])))
+        else:
+            torch.cuda.current_stream().wait_event(pending[slot])  # device-side wait
+        pending[slot] = None
 
     host_t = {"process": 0.0, "collect": 0.0}
 
     def step(i):
         slot = i % NBUF
-        if pending[slot] is not None:  # an old gather still reads this slot's buffers
-            for w in pending[slot]:
-                w.wait()
-            pending[slot] = None
+        release(slot)
         th0 = time.perf_counter()
         nf = batch.process_device(iq[i % ring].data_ptr(), 0 if shared else N, N,
                                   audio[slot].data_ptr(), a_stride, stream, u8=u8)
@@ -271,23 +300,27 @@ def main():
             th0 = time.perf_counter()
             batch.wait(stream=stream, lag=LAG)
             th1 = time.perf_counter()
-            pull_groups(LAG)
+            if not use_export:
+                pull_groups(LAG)
             host_t["collect"] += time.perf_counter() - th1
             host_t["wait"] = host_t.get("wait", 0.0) + (th1 - th0)
             while state["finalized"] < i - LAG:
-                finalize(state["finalized"] + 1)
+                finalize(state["finalized"] + 1, LAG)
         return nf
 
     def drain():
-        batch.wait(stream=stream)
-        pull_groups(0)
+        # the last LAG calls one by one, so that every call's groups land in its own record buffer
         while state["finalized"] < state["submitted"]:
-            finalize(state["finalized"] + 1)
+            lag = state["submitted"] - (state["finalized"] + 1)
+            batch.wait(stream=stream, lag=lag)
+            if not use_export:
+                pull_groups(lag)
+            finalize(state["finalized"] + 1, lag)
+        batch.wait(stream=stream)
         for slot in range(NBUF):
-            if pending[slot] is not None:
-                for w in pending[slot]:
-                    w.wait()
-                pending[slot] = None
+            release(slot)
+        if comm_stream is not None:
+            comm_stream.synchronize()
         torch.cuda.synchronize()
 
     def barrier():
@@ -299,21 +332,85 @@ def main():
         dist.all_reduce(t, op=op)
         return float(t.item())
 
-    for i in range(W):
+    # ---- --verify: what rank 0 received is what a single-rank recomputation gives ----
+    verify = None
+    base = 0
+    if args.verify:
+        V = min(4, NBUF, ring)
+        nfs = [step(i) for i in range(V)]
+        drain()
+        base = V
+        ok = 1.0
+        if rank == 0:
+            picks = sorted({0, 1, C // 2, C - 1})
+            if shared:
+                vshifts = np.concatenate([shifts[picks] for _ in range(world)]).astype(np.int32)
+                vgen = None
+            else:
+                vshifts = None
+                vgen = fmsig_py.DeviceGenerator(
+                    [fmsig_py.channel_params(FS, r * C + c) for r in range(world) for c in picks], dev)
+            nv = world * len(picks)
+            vb = pkg.Batch(pkg.make_params(FS, 0.0 if shared else -0.15 * FS, 48000.0, 15000.0, D,
+                                           table_size=table, if_filter_order=order),
+                           nv, tuning_shifts=vshifts, device=local_rank, record_callbacks=False)
+            viq = torch.empty((nv, N, 2), dtype=in_dtype, device=dev)
+            vaudio = torch.zeros((nv, a_stride), dtype=torch.float32, device=dev)
+            bad = []
+            for i in range(V):
+                if shared:
+                    src, vstride = iq[i % ring], 0
+                else:
+                    vgen.generate(viq, (i % ring) * N, N)
+                    src, vstride = viq, N
+                vnf = vb.process_device(src.data_ptr(), vstride, N, vaudio.data_ptr(), a_stride, stream,
+                                        u8=u8)
+                vb.wait(stream=stream)
+                vg = vb.collect_rds_array(cap=4 * nv, stream=stream)
+                torch.cuda.synchronize()
+                want_a = vaudio[:, :vnf].cpu().numpy().view(np.uint32)
+                slot = i % NBUF
+                for r in range(world):
+                    got_a = g_audio[slot][r][picks, :vnf].cpu().numpy().view(np.uint32)
+                    if vnf != nfs[i] or not np.array_equal(got_a, want_a[r * len(picks):(r + 1) * len(picks)]):
+                        bad.append(("audio", i, r))
+                    got_g = sorted(x for x in dg.unpack_rds_records(g_rds[slot][r].cpu().numpy())
+                                   if x[0] - r * C in picks)
+                    want_g = sorted((r * C + picks[int(ch) - r * len(picks)], int(ci),
+                                     tuple(int(v) for v in bl))
+                                    for ch, ci, bl in zip(vg["channel"], vg["call_index"], vg["blocks"])
+                                    if r * len(picks) <= ch < (r + 1) * len(picks))
+                    if got_g != want_g:
+                        bad.append(("rds", i, r))
+            vb.close()
+            verify = {"steps": V, "channels_per_rank": picks, "ranks": world, "mismatches": bad,
+                      "ok": not bad}
+            ok = 0.0 if bad else 1.0
+            if bad:
+                sys.stderr.write("bench.py --verify: MISMATCH %r\n" % (bad,))
+        if world > 1:
+            ok = reduce_scalar(ok, dist.ReduceOp.MIN)
+        if ok != 1.0:
+            raise SystemExit(4)
+
+    for i in range(base, base + W):
         step(i)
     drain()
     host_t["process"] = host_t["collect"] = host_t["wait"] = 0.0
     batch.set_profiling(1)  # HIP events around the IF FIR kernel of every timed call
     total_groups = 0
+    group_acc.zero_()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(W, W + K):
+    for i in range(base + W, base + W + K):
         nf = step(i)
     drain()
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if use_export:
+        total_groups = int(group_acc.item())  # rank 0: groups that arrived from every rank
     serial_probe = None
     if os.environ.get("FMD_SERIAL_PROBE"):  # dev aid: per-workgroup timing of the serial stage
         pr = batch.debug_serial_probe()
@@ -350,7 +447,6 @@ def main():
             r["start"] = round((r["start"] - t00) / 100.0, 1)
     if world > 1:
         dt = reduce_scalar(dt, dist.ReduceOp.MAX)
-        total_groups = int(reduce_scalar(float(total_groups), dist.ReduceOp.SUM))
     stage, calls = batch.stage_ms()
     fir_ms = stage["if_fir"]
     host_ms = {k: v / K * 1e3 for k, v in host_t.items()}  # the timed region's, before the extra steps
@@ -364,7 +460,7 @@ def main():
         if args.concurrency != 0:
             batch.set_concurrency(0)
         batch.set_profiling(2)
-        for i in range(W + K, W + K + 4):
+        for i in range(base + W + K, base + W + K + 4):
             step(i)
         drain()
         stage_all, _ = batch.stage_ms()
@@ -401,7 +497,9 @@ def main():
                        "gather": "rank-0 RCCL gather of audio+RDS per step" if world > 1 else "none (1 GPU)",
                        "host_ms_per_step": {"submit": round(host_ms["process"], 3),
                                             "wait": round(host_ms.get("wait", 0.0), 3),
-                                            "collect_rds": round(host_ms["collect"], 3)}},
+                                            "collect_rds": round(host_ms["collect"], 3),
+                                            "note": "collect_rds includes waiting for the device (the "
+                                                    "host runs ahead and blocks on the call three steps back)"}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "k_if_fir (cFineTuner + cDownsampleFilter complex)",
@@ -418,6 +516,8 @@ def main():
                     and t.get("samples_per_call") == N):
                 out["roofline"]["traffic"] = t["bytes_per_launch"]
                 out["roofline"]["traffic_source"] = t["source"]
+        if verify is not None:
+            out["verify"] = verify
         if serial_probe is not None:
             out["serial_probe_last_8_launches"] = serial_probe
         if stage_all:

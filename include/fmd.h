@@ -160,6 +160,17 @@ int fmd_batch_collect_rds(fmd_batch* b, fmd_rds_group* out, unsigned cap, int ru
 int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap,
                                  int run_group_decoder, int lag, void* stream);
 
+/* The same drain without a host round trip, for outputs that travel on as device memory (the rank-0
+ * gather of a multi-GPU job): the groups of every call at least `lag` calls old are written to
+ * d_records (device memory, 16-byte aligned, cap rows of 4 x int32: channel + 1 + channel_offset,
+ * call_index, blocks[0] | blocks[1] << 16, blocks[2] | blocks[3] << 16; rows beyond the groups found
+ * are zero, so a fixed-size message can be sent as is) by a kernel on `stream`, and those queues
+ * are emptied.  Asynchronous; rows are in no particular order.  More groups than `cap` rows is a
+ * device-side error (reported by the next wait / collect / process call).  Use either this or
+ * fmd_batch_collect_rds on a batch, not both for the same calls. */
+int fmd_batch_export_rds_device(fmd_batch* b, int32_t* d_records, unsigned cap, unsigned channel_offset,
+                                int lag, void* stream);
+
 /* Internal execution.  A call is four independent kernel chains (FIR -> serial demodulator ->
  * {RDS branch, audio branch}); mode selects where they run:
  *   0  all on the caller's stream, in order

@@ -102,7 +102,8 @@ EXPORTS = [
     "fmd_get_status", "fmd_batch_process_device_u8", "fmd_batch_process_host_u8",
     "fmd_batch_create", "fmd_batch_destroy", "fmd_batch_reset", "fmd_batch_channels",
     "fmd_batch_max_audio_floats", "fmd_batch_process_device", "fmd_batch_process_host",
-    "fmd_batch_collect_rds", "fmd_batch_collect_rds_lagged", "fmd_batch_set_concurrency",
+    "fmd_batch_collect_rds", "fmd_batch_collect_rds_lagged", "fmd_batch_export_rds_device",
+    "fmd_batch_set_concurrency",
     "fmd_batch_wait", "fmd_batch_wait_lagged", "fmd_batch_get_status", "fmd_batch_get_tap", "fmd_batch_get_design",
     "fmd_batch_set_debug_taps", "fmd_batch_set_profiling", "fmd_batch_get_stage_ms", "fmd_stage_name", "fmd_last_error",
     "fmd_version", "fmd_group_decoder_create", "fmd_group_decoder_destroy",
@@ -152,6 +153,7 @@ def lib():
         L.fmd_batch_process_host_u8.argtypes = L.fmd_batch_process_host.argtypes
         L.fmd_batch_collect_rds.argtypes = [vp, vp, u, i, vp]
         L.fmd_batch_collect_rds_lagged.argtypes = [vp, vp, u, i, i, vp]
+        L.fmd_batch_export_rds_device.argtypes = [vp, vp, u, u, i, vp]
         L.fmd_batch_set_concurrency.argtypes = [vp, i]
         L.fmd_batch_wait.argtypes = [vp, vp]
         L.fmd_batch_wait_lagged.argtypes = [vp, i, vp]
@@ -319,6 +321,12 @@ class Batch:
         a = self.collect_rds_array(cap, run_group_decoder, stream, lag)
         return [(int(c), int(k), tuple(int(x) for x in b))
                 for c, k, b in zip(a["channel"], a["call_index"], a["blocks"])]
+
+    def export_rds_device(self, d_records_ptr, cap, channel_offset=0, stream=None, lag=0):
+        """Queued RDS groups of calls at least `lag` old -> [cap, 4] int32 rows in device memory
+        (fmd_batch_export_rds_device), asynchronously on `stream`."""
+        _check(lib().fmd_batch_export_rds_device(self._h, d_records_ptr, cap, channel_offset, lag,
+                                                 stream))
 
     def set_concurrency(self, mode):
         _check(lib().fmd_batch_set_concurrency(self._h, int(mode)))

@@ -124,6 +124,11 @@ struct fmd_batch
   DevBuf<fmd::RdsGroupRec> queue[NSLOT]; // never drained while a call that appends to it is in flight
   DevBuf<unsigned> queue_count[NSLOT];
   unsigned queue_cap = 0;
+  // fmd_batch_export_rds_device drains a queue asynchronously on the caller's stream: the event tells
+  // the next call that appends to the same queue (NSLOT calls later) when it is empty
+  hipEvent_t ev_drained[NSLOT] = {};
+  bool drained_pending[NSLOT] = {};
+  DevBuf<unsigned> export_cursor;
   fmd::ChannelState st{};
   std::vector<fmd::HbCoef> hbcoef;
 
@@ -219,7 +224,10 @@ struct fmd_batch
     {
       queue[q].release();
       queue_count[q].release();
+      if (ev_drained[q])
+        (void)hipEventDestroy(ev_drained[q]);
     }
+    export_cursor.release();
     if (cev_ready)
     {
       for (auto& row : cev)
@@ -530,6 +538,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     bad |= b->queue[q].alloc(b->queue_cap);
     bad |= b->queue_count[q].alloc(1);
   }
+  bad |= b->export_cursor.alloc(1);
   if (bad)
     return fail(FMD_ERR_DEVICE, std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError()));
 
@@ -592,6 +601,8 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   for (auto& row : b->cev)
     for (auto& e : row)
       HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : b->ev_drained)
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   b->cev_ready = true;
   HIPCHK(hipDeviceSynchronize());
   *out = b.release();
@@ -758,6 +769,18 @@ int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, un
   return launch_if_stage_e<IN, 256>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
 }
 
+/* A call appends its RDS groups to queue[es]; if the queue's previous contents were handed to an
+ * asynchronous drain (fmd_batch_export_rds_device), stream s first waits for that drain. */
+void queue_is_free(fmd_batch* b, int es, hipStream_t s)
+{
+  if (b->drained_pending[es])
+  {
+    if (hipStreamWaitEvent(s, b->ev_drained[es], 0) != hipSuccess)
+      b->failed = true, b->fail_msg = "hipStreamWaitEvent failed in front of an RDS queue";
+    b->drained_pending[es] = false;
+  }
+}
+
 /* The light part of one call's post chain on stream s: cRDSRxSignalProcessor's PLL, matched filter
  * and bit recovery, then the audio tail; records the call's EV_RDS / EV_AUD. */
 void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, bool record)
@@ -767,6 +790,7 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
   const unsigned T_mf = unsigned(d.rds_mf_taps.size());
   const dim3 rt(256);
   auto rgrid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
+  queue_is_free(b, j.es, s);
   {
     fmd::RdsConsts k{};
     k.pll_alpha = d.rds_pll_alpha;
@@ -1085,6 +1109,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     mark(4);
   };
   auto rds_light = [&]() {
+    queue_is_free(b, es, sR);
     {
       fmd::RdsConsts k{};
       k.pll_alpha = d.rds_pll_alpha;
@@ -1379,6 +1404,32 @@ int fmd_batch_collect_rds(fmd_batch* b, fmd_rds_group* out, unsigned cap, int ru
                           void* stream_)
 {
   return fmd_batch_collect_rds_lagged(b, out, cap, run_group_decoder, 0, stream_);
+}
+
+int fmd_batch_export_rds_device(fmd_batch* b, int32_t* d_records, unsigned cap, unsigned channel_offset,
+                                int lag, void* stream_)
+{
+  if (!b || !d_records || cap == 0 || lag < 0 || lag > 4)
+    return fail(FMD_ERR_ARG, "fmd_batch_export_rds_device: bad argument (lag must be 0..4)");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIPCHK(hipSetDevice(b->device));
+  if (lag == 0)
+    flush_light(b);
+  HIPCHK(hipMemsetAsync(d_records, 0, size_t(cap) * 4 * sizeof(int32_t), stream));
+  HIPCHK(hipMemsetAsync(b->export_cursor.p, 0, sizeof(unsigned), stream));
+  for (int q = 0; q < fmd_batch::NSLOT; q++)
+  {
+    if (!slot_eligible(b, q, lag))
+      continue;
+    HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_RDS], 0));
+    hipLaunchKernelGGL(fmd::k_rds_export, dim3(1), dim3(256), 0, stream, b->queue[q].p, b->queue_count[q].p,
+                       b->queue_cap, reinterpret_cast<int4*>(d_records), cap, b->export_cursor.p,
+                       channel_offset, b->st.err);
+    HIPCHK(hipEventRecord(b->ev_drained[q], stream));
+    b->drained_pending[q] = true;
+  }
+  HIPCHK(hipGetLastError());
+  return check_device_errors(b);
 }
 
 static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t iq_channel_stride,

@@ -1942,6 +1942,42 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* RDS groups of one call's queue -> fixed-size records in device memory (the N > 1 gather of    */
+/* bench.py sends them to rank 0 as they are: no host round trip).  Row = 4 x int32:            */
+/* channel + 1 + channel_offset, call index, b0 | b1 << 16, b2 | b3 << 16; rows nobody writes    */
+/* stay zero (the host zeroes the buffer first).  One workgroup per queue; `cursor` is the      */
+/* running row count over the queues drained into the same buffer.  Empties the queue.          */
+/* ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_rds_export(const RdsGroupRec* __restrict__ queue,
+                                                    unsigned* __restrict__ queue_count, unsigned queue_cap,
+                                                    int4* __restrict__ rec, unsigned cap,
+                                                    unsigned* __restrict__ cursor, unsigned channel_offset,
+                                                    unsigned* __restrict__ err)
+{
+  __shared__ unsigned base_s;
+  const unsigned n = min(*queue_count, queue_cap);
+  if (threadIdx.x == 0)
+    base_s = atomicAdd(cursor, n);
+  __syncthreads();
+  const unsigned base = base_s;
+  for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
+  {
+    const RdsGroupRec r = queue[i];
+    if (base + i < cap)
+      rec[base + i] = make_int4((int)(r.channel + 1u + channel_offset), (int)r.call_index,
+                                (int)((unsigned)r.blocks[0] | ((unsigned)r.blocks[1] << 16)),
+                                (int)((unsigned)r.blocks[2] | ((unsigned)r.blocks[3] << 16)));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    if (base + n > cap)
+      dev_error(err, DEVERR_RDS_QUEUE_FULL); // more groups than the caller's record buffer holds
+    *queue_count = 0;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Stream probe (fmd_batch_create): one wave that stays busy for `cycles`, and a no-op.         */
 /* ------------------------------------------------------------------------------------------ */
 __global__ void k_probe_spin(long long cycles, int* sink)
