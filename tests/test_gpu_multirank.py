@@ -31,7 +31,7 @@ def _run_bench(world, extra, port):
 
 
 def test_two_ranks_one_gpu_gather_verified():
-    d = _run_bench(2, ["--channels", "192", "--steps", "30", "--warmup", "3", "--ring", "4"], 29541)
+    d = _run_bench(2, ["--channels", "192", "--steps", "30", "--warmup", "3", "--ring", "24"], 29541)
     assert d["n_gpus"] == 2 and d["verify"]["ok"] and d["verify"]["ranks"] == 2
     assert d["verify"]["channels_per_rank"] == [0, 1, 96, 191]
     assert d["config"]["rds_groups_in_timed_region"] > 0  # counted on rank 0 from the gathered records
