@@ -105,6 +105,9 @@ def main():
                     help="fmd_batch_set_concurrency mode (2 = calls overlap, the default)")
     ap.add_argument("--stage-profile", action="store_true",
                     help="after the timed region, run 3 extra steps with per-stage events")
+    ap.add_argument("--fir-reduction", type=int, default=0, choices=[0, 1],
+                    help="0: sequential tap order, bit-exact (default, what every reported figure uses); "
+                         "1: opt-in shuffle-reduced tap sum (not bit-exact; measured for DESIGN.md only)")
     ap.add_argument("--verify", action="store_true",
                     help="before the timed region: rank 0 checks the audio and RDS records it gathered "
                          "from every rank (a few channels each, first steps) bit for bit against its own "
@@ -204,7 +207,8 @@ def main():
                      for _ in range(int(os.environ.get("FMD_BENCH_EXTRA_STREAMS", "0")))]
     shifts = (np.arange(C, dtype=np.int32) % table) - table // 2 if shared else None
     batch = pkg.Batch(pkg.make_params(FS, 0.0 if shared else -0.15 * FS, 48000.0, 15000.0, D,
-                                      table_size=table, if_filter_order=order),
+                                      table_size=table, if_filter_order=order,
+                                      fir_reduction=args.fir_reduction),
                       C, tuning_shifts=shifts, device=local_rank, record_callbacks=False)
     a_stride = (batch.max_audio_floats(N) + 63) // 64 * 64
     NBUF = 6  # outputs are consumed three steps after they are produced
@@ -492,6 +496,8 @@ def main():
                 + (" -- input as RTL-SDR u8 byte pairs, ReadAsyncCB conversion fused into the IF "
                    "kernel (SURVEY 8(f)-2; not the BASELINE metric's input format)" if u8 else ""),
                        "input_format": args.input,
+                       "fir_reduction": "sequential (bit-exact)" if args.fir_reduction == 0
+                       else "shuffle (opt-in, NOT bit-exact)",
                        "channels_per_gpu": C, "samples_per_call": N, "input_ring_blocks": ring,
                        "audio_floats_per_channel_step": nf, "rds_groups_in_timed_region": total_groups,
                        "gather": "rank-0 RCCL gather of audio+RDS per step" if world > 1 else "none (1 GPU)",

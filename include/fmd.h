@@ -52,6 +52,13 @@ typedef struct fmd_params
   int us_version;
   unsigned table_size;
   unsigned if_filter_order;
+  /* How the IF FIR adds up an output's taps.  0 (default): one lane per output, taps in the
+   * reference's order (DownConvert.cpp:117-121) -- bit-identical results.  1: the sum split over four
+   * lanes and combined with wavefront shuffles (the reduction BASELINE's north star names): a
+   * different order of float additions, so results are close to but not identical with the
+   * reference's (audio ~1e-6..1e-5 RMS apart); opt-in, headline window
+   * layout (odd downsample, power-of-two tuner table) only, other geometries ignore it. */
+  int fir_reduction;
 } fmd_params;
 
 /* Upward callbacks = the three cRadioReceiver members the RDS group decoder calls

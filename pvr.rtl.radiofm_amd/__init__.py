@@ -45,6 +45,7 @@ class FmdParams(C.Structure):
         ("us_version", C.c_int),
         ("table_size", C.c_uint),
         ("if_filter_order", C.c_uint),
+        ("fir_reduction", C.c_int),
     ]
 
 
@@ -205,9 +206,9 @@ def _check(rc):
 
 
 def make_params(sample_rate_if, tuning_offset, sample_rate_pcm=48000.0, bandwidth_pcm=15000.0,
-                downsample=1, us_version=False, table_size=0, if_filter_order=0):
+                downsample=1, us_version=False, table_size=0, if_filter_order=0, fir_reduction=0):
     return FmdParams(sample_rate_if, tuning_offset, sample_rate_pcm, bandwidth_pcm, downsample,
-                     int(us_version), table_size, if_filter_order)
+                     int(us_version), table_size, if_filter_order, fir_reduction)
 
 
 class _CallbackSink:

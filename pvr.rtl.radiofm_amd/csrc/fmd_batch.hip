@@ -436,6 +436,9 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   b->params.us_version = params->us_version != 0;
   b->params.table_size = params->table_size;
   b->params.if_filter_order = params->if_filter_order;
+  b->params.fir_reduction = params->fir_reduction;
+  if (params->fir_reduction != 0 && params->fir_reduction != 1)
+    return fail(FMD_ERR_ARG, "fmd_batch_create: fir_reduction must be 0 (sequential) or 1 (shuffle)");
   try
   {
     b->des = fmd::make_design(b->params);
@@ -447,9 +450,6 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   const fmd::Design& d = b->des;
   if (d.if_order > FMD_MIN_BLOCK)
     return fail(FMD_ERR_ARG, "if_filter_order larger than the minimum block");
-  for (const auto& h : d.hb)
-    if (h.len == 11)
-      return fail(FMD_ERR_ARG, "baseband rate >= 320 kHz needs the 11-tap half-band class (unsupported)");
   if (cb)
     b->cb = *cb;
   b->user = user;
@@ -684,6 +684,10 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
                       : &fmd::k_if_fir<IN, TILE, 8, true, E>;
   if (pow2 && longasm)
     kfn = &fmd::k_if_fir<IN, TILE, 8, true, E, TILE == 256 && E == 1>;
+  // opt-in shuffle-reduced tap sum (not bit-exact): headline window layout only
+  const bool shfl = b->params.fir_reduction == 1 && TILE == 64 && E == 0 && pow2 && rounds <= 8;
+  if (shfl)
+    kfn = &fmd::k_if_fir<IN, TILE, 8, true, E, false, TILE == 64 && E == 0>;
   // several tiles per workgroup with the next tile's loads in flight during the tap loop
   // (k_if_fir_mt): the headline geometry only.  Two tiles: 0.94-0.95 ms inside the pipeline against
   // 0.98-1.00 (one tile per workgroup) on the same box, the same alone; 3, 4, 8 tiles: no better
@@ -695,7 +699,7 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   static const int fir_nt_env = getenv("FMD_FIR_NT") ? atoi(getenv("FMD_FIR_NT")) : 0;
   const int fir_nt = fir_nt_env ? fir_nt_env : (b->concurrency == 2 && b->serial_exclusive ? 2 : 1);
   unsigned nblocks = C * ntiles;
-  if (TILE == 64 && E == 0 && pow2 && rounds == 7 && fir_nt > 1)
+  if (TILE == 64 && E == 0 && pow2 && rounds == 7 && fir_nt > 1 && !shfl)
   {
     const unsigned nt = fir_nt >= 8 ? 8u : fir_nt >= 4 ? 4u : fir_nt == 3 ? 3u : 2u;
     kfn = nt == 8 ? &fmd::k_if_fir_mt<IN, 7, 8>
@@ -892,7 +896,9 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     hb_in[s] = R;
     if (R < 2u * unsigned(d.hb[s].len - 1))
       return fail(FMD_ERR_SIZE, "block too short for the RDS half-band chain at this rate");
-    R = (R + 1) / 2; // DownConvert.cpp:526
+    // the generic class returns one output per even input index (DownConvert.cpp:526-543), the
+    // 11-tap class InLength / 2 (:688)
+    R = d.hb[s].len == 11 ? R / 2 : (R + 1) / 2;
   }
   // fractional resampler walk (DownConvert.cpp:203-232), float arithmetic as written there
   const float p = b->rs_pos;
@@ -1071,12 +1077,15 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       const float2* in = b->mix[q].p;
       for (size_t s = 0; s < d.hb.size(); s++)
       {
-        const unsigned n_out = (hb_in[s] + 1) / 2;
+        const unsigned n_out = d.hb[s].len == 11 ? hb_in[s] / 2 : (hb_in[s] + 1) / 2;
         const bool last = (s + 1 == d.hb.size());
         float2* outp = last ? b->rdsraw.p : b->hbbuf[s].p;
         const unsigned Hout = last ? (T_lpf - 1) : unsigned(d.hb[s + 1].len - 1);
         static const int hb4 = getenv("FMD_HB4") ? atoi(getenv("FMD_HB4")) : 1;
-        if (hb4 && (d.hb[s].len - 1) / 2 >= 4 && d.hb[s].len <= 55)
+        if (d.hb[s].len == 11)
+          hipLaunchKernelGGL(fmd::k_halfband11, dim3(CP / 64, (n_out + 3) / 4), dim3(64, 4), 0, sR, in, outp,
+                             n_out, b->hbcoef[s], C, CP, Hout);
+        else if (hb4 && (d.hb[s].len - 1) / 2 >= 4 && d.hb[s].len <= 55)
           hipLaunchKernelGGL(fmd::k_halfband4, dim3(CP / 64, (n_out + 15) / 16), dim3(64, 4), 0, sR, in, outp,
                              n_out, d.hb[s].len, b->hbcoef[s], C, CP, Hout);
         else

@@ -358,7 +358,13 @@ struct InU8
  * i >> E.  All lanes read the same region at a given tap (their offsets lane*D are multiples of
  * 2^E), and inside a region the lane stride is D >> E, which is odd: conflict-free.  Consecutive
  * taps walk the regions round robin, each region contiguously.  E = 0 is the plain window. */
-template <class IN, int TILE, int UNROLL, bool POW2, int E = 0, bool LONGASM = false>
+/* SHFL (opt-in, fmd_params::fir_reduction = 1; plain window, one wave per workgroup only): the tap
+ * sum of an output is split over the four lanes of a quad -- lane q takes taps 1+q, 5+q, ... -- and
+ * the four partial sums are combined with two wavefront shuffles.  This is the reduction BASELINE's
+ * north star describes; it changes the order of the float additions, so its output is NOT
+ * bit-identical to the reference's sequential sum (measured against the parity mode in
+ * tests/test_gpu_fast_mode.py, figures in DESIGN.md section 3).  Not the default. */
+template <class IN, int TILE, int UNROLL, bool POW2, int E = 0, bool LONGASM = false, bool SHFL = false>
 __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __restrict__ iq,
                                                  size_t chan_stride, unsigned N,
                                                  const float2* __restrict__ hist_in,
@@ -459,7 +465,35 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
   else
     __syncthreads();
 
-  if (tid < nout)
+  if (SHFL && E == 0 && TILE == 64)
+  {
+    const unsigned q = tid & 3u, og = tid >> 2; // quad lane, output within a pass of 16
+#pragma unroll 1
+    for (unsigned pass = 0; pass < TILE / 16; pass++)
+    {
+      const unsigned o = pass * 16 + og;
+      float2 acc = make_float2(0.0f, 0.0f);
+      if (o < nout)
+      {
+        const float2* w = win + (k_lo - k_al) + o * D + order;
+#pragma unroll 4
+        for (unsigned j = 1 + q; j <= order; j += 4)
+        {
+          const float k = coeff[j]; // per-lane tap: a vector load (L1), not a scalar one
+          const float2 s = w[-(int)j];
+          acc.x += s.x * k;
+          acc.y += s.y * k;
+        }
+      }
+      acc.x += __shfl_xor(acc.x, 1);
+      acc.y += __shfl_xor(acc.y, 1);
+      acc.x += __shfl_xor(acc.x, 2);
+      acc.y += __shfl_xor(acc.y, 2);
+      if (q == 0 && o < nout)
+        out[(size_t)c * Mstride + m0 + o] = acc;
+    }
+  }
+  else if (tid < nout)
   {
     float2 acc = make_float2(0.0f, 0.0f);
     if (E == 0)
@@ -1155,6 +1189,36 @@ __global__ __launch_bounds__(256) void k_halfband(const float2* __restrict__ in,
       out[(size_t)(Hout + k0 + r) * CP + c] = make_float2(ar[r], ai[r]);
     }
   }
+}
+
+/* CHalfBand11TapDecimateBy2::DecBy2 (DownConvert.cpp:589-688), the first stage when the baseband
+ * rate is 320 kHz or more (SetDataRate, :340-341).  Same window indexing as above with L = 11
+ * (10 history rows = the class's d0..d9), but a different sum: seven products H0 x0 + H2 x2 + H4 x4 +
+ * H5 x5 + H6 x6 + H8 x8 + H10 x10 added left to right as written (:596-661), the centre tap in its
+ * place, no tap counted twice; InLength / 2 outputs (an odd last input is only kept as history). */
+__global__ __launch_bounds__(256) void k_halfband11(const float2* __restrict__ in,
+                                                    float2* __restrict__ out, unsigned n_out, HbCoef hc,
+                                                    unsigned C, unsigned CP, unsigned Hout)
+{
+  const unsigned c = blockIdx.x * 64 + threadIdx.x;
+  const unsigned wy = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
+  const unsigned o = blockIdx.y * blockDim.y + wy;
+  if (c >= C || o >= n_out)
+    return;
+  const float2* __restrict__ p = in + (size_t)(2 * o) * CP + c;
+  const int T[7] = {0, 2, 4, 5, 6, 8, 10};
+  float2 x[7];
+#pragma unroll
+  for (int t = 0; t < 7; t++)
+    x[t] = p[(size_t)T[t] * CP];
+  float ar = hc.c[0] * x[0].x, ai = hc.c[0] * x[0].y;
+#pragma unroll
+  for (int t = 1; t < 7; t++)
+  {
+    ar = ar + hc.c[T[t]] * x[t].x;
+    ai = ai + hc.c[T[t]] * x[t].y;
+  }
+  out[(size_t)(Hout + o) * CP + c] = make_float2(ar, ai);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -95,9 +95,38 @@ def test_call_size_limits(fmsig):
     assert d1.ProcessStream(fmsig.generate_f32(p1, 0, 32000).view(np.complex64)).size > 10000
     # unsupported configurations fail at construction, loudly
     with pytest.raises(pkg.FmdError):
-        pkg.FmDecoder(400e3, 0.0, 48000.0, 15000.0, 1)  # baseband 400 kHz needs the 11-tap half-band
+        pkg.FmDecoder(16.2e6, 0.0, 48000.0, 15000.0, 3)  # baseband 5.4 MHz would need the CIC stage
     with pytest.raises(pkg.FmdError):
         pkg.Batch(pkg.make_params(0.0, 0.0), 1)
+
+
+@pytest.mark.parametrize("fs,D,sizes", [(400e3, 1, [32000, 32001, 20000, 8193, 32700]),
+                                        (644e3, 2, [60000, 65001, 8192, 33333]),
+                                        (330e3, 1, [30000, 30001])])
+def test_eleven_tap_half_band_first_stage(oracle, fmsig, fs, D, sizes):
+    """Baseband rates of 320 kHz and more -- IF rates in [320, 430) kHz and [640, 645) kHz under the
+    reference's own downsample rule (RadioReceiver.cpp:285) -- start the RDS decimator with
+    CHalfBand11TapDecimateBy2 (DownConvert.cpp:340-341, :589-688): seven products summed as
+    written, InLength / 2 outputs, also for odd input lengths.  RDS stage taps and audio bit for bit."""
+    pkg = load_package()
+    p = fmsig.default_params(fs, noise_sigma=0.01, seed=17)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    assert o.rds_hb_lengths()[0] == 11
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 2)
+    b.enable_taps()
+    start = 0
+    for k, n in enumerate(sizes * 2):
+        iq = fmsig.generate_f32(p, start, n)
+        start += n
+        ref = o.process_stream(iq)
+        a = b.process_host(np.stack([iq, iq]).view(np.complex64))
+        t = o.taps()
+        for name in ("rds_lpf", "rds_pll", "rds_mf", "rds_sync"):
+            assert _bits_equal(b.tap(name, 1).view(np.float32), t[name].view(np.float32)), (k, n, name)
+        assert _bits_equal(a[0], ref) and _bits_equal(a[1], ref), (k, n)
+    so, sg = o.status(), b.status(1)
+    assert sg.rds_state == so.rds_state and np.float32(sg.pilot_level) == np.float32(so.pilot_level)
+    b.close()
 
 
 @pytest.mark.parametrize("fs,D,order,n", [(1.4e6, 6, 1000, 65536), (1.4e6, 6, 520, 33333),
