@@ -290,6 +290,8 @@ def main():
         pending[slot] = None
 
     host_t = {"process": 0.0, "collect": 0.0}
+    # dev aid (FMD_BENCH_STEPTIMES=1): an event on the torch stream behind every call's completion
+    step_events = [] if os.environ.get("FMD_BENCH_STEPTIMES") else None
 
     def step(i):
         slot = i % NBUF
@@ -310,6 +312,10 @@ def main():
             host_t["wait"] = host_t.get("wait", 0.0) + (th1 - th0)
             while state["finalized"] < i - LAG:
                 finalize(state["finalized"] + 1, LAG)
+                if step_events is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    step_events.append((state["finalized"], e))
         return nf
 
     def drain():
@@ -320,6 +326,10 @@ def main():
             if not use_export:
                 pull_groups(lag)
             finalize(state["finalized"] + 1, lag)
+            if step_events is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                step_events.append((state["finalized"], e))
         batch.wait(stream=stream)
         for slot in range(NBUF):
             release(slot)
@@ -406,6 +416,10 @@ def main():
     group_acc.zero_()
     barrier()
     torch.cuda.synchronize()
+    if step_events is not None:
+        step_events.clear()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     t0 = time.perf_counter()
     for i in range(base + W, base + W + K):
         nf = step(i)
@@ -413,6 +427,11 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if step_events is not None and rank == 0:
+        ts = [e0.elapsed_time(e) for _, e in step_events]
+        sys.stderr.write("STEPTIMES wall %.3f ms; call completion (ms since t0): %s\n  intervals: %s\n" % (
+            dt * 1e3, " ".join("%.2f" % t for t in ts),
+            " ".join("%.2f" % (b - a) for a, b in zip([0.0] + ts[:-1], ts))))
     if use_export:
         total_groups = int(group_acc.item())  # rank 0: groups that arrived from every rank
     serial_probe = None
