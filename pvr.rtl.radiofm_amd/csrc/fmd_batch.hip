@@ -666,8 +666,9 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   const size_t region = ((size_t(TILE - 1) * D + d.if_order + 2u * (1u << E) + 2u) >> E) + 1u;
   // long filter in the two-region window: one workgroup per CU, hand-scheduled tap loop
   // (k_if_fir LONGASM)
-  const bool longasm = TILE == 256 && E == 1 && d.if_order >= 512;
-  const size_t lds = (region << E) * sizeof(float2);
+  const bool longasm = TILE == 256 && (E == 1 || (E == 0 && D % 4 == 2)) && d.if_order >= 512;
+  // + 32 slots in front of the plain window for the b128 tap loop's dummy prefetch (k_if_fir WIN_PAD)
+  const size_t lds = (region << E) * sizeof(float2) + (longasm && E == 0 ? 32 * sizeof(float2) : 0);
   if (lds > 160 * 1024)
     return fail(FMD_ERR_ARG, "IF filter window does not fit in LDS");
   // fast staging: the tuner table is a power of two that divides a tile's sample span, so a lane
@@ -683,7 +684,7 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
         : rounds <= 7 ? &fmd::k_if_fir<IN, TILE, 7, true, E>
                       : &fmd::k_if_fir<IN, TILE, 8, true, E>;
   if (pow2 && longasm)
-    kfn = &fmd::k_if_fir<IN, TILE, 8, true, E, TILE == 256 && E == 1>;
+    kfn = &fmd::k_if_fir<IN, TILE, 8, true, E, TILE == 256 && (E == 1 || E == 0)>;
   // opt-in shuffle-reduced tap sum (not bit-exact): headline window layout only
   const bool shfl = b->params.fir_reduction == 1 && TILE == 64 && E == 0 && pow2 && rounds <= 8;
   if (shfl)
@@ -744,7 +745,16 @@ int launch_if_stage_e(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   if (D % 2 != 0)
     return launch_if_stage_t<IN, TILE, 0>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
   if (D % 4 != 0)
+  { // D = 2 * odd.  Long filters: plain window read two samples at a time (fir_long_b128_asm: the b128
+    // lane groups are conflict-free at this stride); otherwise the two-region window.  FMD_FIR_B128=0
+    // keeps the two-region form for long filters too (fir_long_e1_asm).
+    static const int b128 = getenv("FMD_FIR_B128") ? atoi(getenv("FMD_FIR_B128")) : 1;
+    const unsigned T = b->des.table_size;
+    const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
+    if (b128 && TILE == 256 && b->des.if_order >= 512 && pow2)
+      return launch_if_stage_t<IN, TILE, 0>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
     return launch_if_stage_t<IN, TILE, 1>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
+  }
   return launch_if_stage_t<IN, TILE, 2>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
 }
 

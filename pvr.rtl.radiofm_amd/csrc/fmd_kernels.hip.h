@@ -300,6 +300,151 @@ __device__ __forceinline__ void fir_long_e1_asm(fmd_f2v& acc2, unsigned& a1, uns
         "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "scc", "memory");
 }
 
+/* Long filters in the PLAIN window (E = 0) with D = 2 * odd, two taps per LDS instruction.  With such
+ * a window only ONE wave fits a SIMD, and a lone wave issues a packed f32 instruction every 8 cycles
+ * whatever depends on what (tools/ubench/pk_rate, profiles/r2_pk_rate.txt): the v_pk_mul_f32 and the
+ * v_pk_add_f32 a tap needs without FMA cost 16 cycles, every other instruction comes on top -- the
+ * loop is issue-bound, and the fewest instructions per tap win.  ds_read_b128 fetches the samples of
+ * taps (j + 1, j) -- consecutive window slots, the lower one 16-byte aligned -- at 256 B/clk/CU where
+ * ds_read2_b64 delivers 128 (MI355X_MICROARCH.md, LDS table).  The 16 lanes of a b128 lane group sit
+ * 2 D dwords apart = 4 * odd banks (mod 64): 16 different 4-bank groups, conflict-free without
+ * de-interleaving.  Batches of 16 taps (8 reads + one s_load_dwordx16) in two register sets,
+ * products two ahead of the sum, the sum ONE chain in tap order.  a = LDS byte address of the
+ * batch's lowest pair (taps j + 14, j + 15), 128 bytes lower per batch; klo / khi = address of tap
+ * j; cnt = pairs of batches (32 taps each, >= 1).  The last batch load is a dummy (16 taps past the
+ * table: padded; 16 slots below the last pair: the window sits 32 slots into the LDS allocation).
+ * Measured (4096 taps, D = 46): 3.35 ms per launch against 3.51 ms for fir_long_e1_asm on the same
+ * box = 19.3 cycles per tap, of which 16 are the two packed instructions.
+ * Body generated by tools/gen_fir_long_b128_asm.py. */
+__device__ __forceinline__ void fir_long_b128_asm(fmd_f2v& acc2, unsigned& a, unsigned klo, unsigned khi,
+                                                  unsigned& cnt)
+{
+  asm volatile(
+      "s_mov_b32 s72, %3\n\t"
+      "s_mov_b32 s73, %4\n\t"
+      "s_load_dwordx16 s[40:55], s[72:73], 0x0\n\t"
+      "ds_read_b128 v[64:67], %1 offset:112\n\t"
+      "ds_read_b128 v[68:71], %1 offset:96\n\t"
+      "ds_read_b128 v[72:75], %1 offset:80\n\t"
+      "ds_read_b128 v[76:79], %1 offset:64\n\t"
+      "ds_read_b128 v[80:83], %1 offset:48\n\t"
+      "ds_read_b128 v[84:87], %1 offset:32\n\t"
+      "ds_read_b128 v[88:91], %1 offset:16\n\t"
+      "ds_read_b128 v[92:95], %1 offset:0\n\t"
+      "v_subrev_u32 %1, 128, %1\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "1:\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[56:71], s[72:73], 0x0\n\t"
+      "ds_read_b128 v[96:99], %1 offset:112\n\t"
+      "ds_read_b128 v[100:103], %1 offset:96\n\t"
+      "ds_read_b128 v[104:107], %1 offset:80\n\t"
+      "ds_read_b128 v[108:111], %1 offset:64\n\t"
+      "ds_read_b128 v[112:115], %1 offset:48\n\t"
+      "ds_read_b128 v[116:119], %1 offset:32\n\t"
+      "ds_read_b128 v[120:123], %1 offset:16\n\t"
+      "ds_read_b128 v[124:127], %1 offset:0\n\t"
+      "v_subrev_u32 %1, 128, %1\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "v_pk_mul_f32 v[128:129], v[66:67], s[40:41] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 v[130:131], v[64:65], s[40:41] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[70:71], s[42:43] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[68:69], s[42:43] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[74:75], s[44:45] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[72:73], s[44:45] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[78:79], s[46:47] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[76:77], s[46:47] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[82:83], s[48:49] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[80:81], s[48:49] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[86:87], s[50:51] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[84:85], s[50:51] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[90:91], s[52:53] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[88:89], s[52:53] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[94:95], s[54:55] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[92:93], s[54:55] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[40:55], s[72:73], 0x0\n\t"
+      "ds_read_b128 v[64:67], %1 offset:112\n\t"
+      "ds_read_b128 v[68:71], %1 offset:96\n\t"
+      "ds_read_b128 v[72:75], %1 offset:80\n\t"
+      "ds_read_b128 v[76:79], %1 offset:64\n\t"
+      "ds_read_b128 v[80:83], %1 offset:48\n\t"
+      "ds_read_b128 v[84:87], %1 offset:32\n\t"
+      "ds_read_b128 v[88:91], %1 offset:16\n\t"
+      "ds_read_b128 v[92:95], %1 offset:0\n\t"
+      "v_subrev_u32 %1, 128, %1\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "v_pk_mul_f32 v[128:129], v[98:99], s[56:57] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 v[130:131], v[96:97], s[56:57] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[102:103], s[58:59] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[100:101], s[58:59] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[106:107], s[60:61] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[104:105], s[60:61] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[110:111], s[62:63] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[108:109], s[62:63] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[114:115], s[64:65] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[112:113], s[64:65] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[118:119], s[66:67] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[116:117], s[66:67] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[122:123], s[68:69] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[120:121], s[68:69] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[126:127], s[70:71] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[124:125], s[70:71] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "s_sub_u32 %2, %2, 1\n\t"
+      "s_cmp_lg_u32 %2, 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      : "+v"(acc2), "+v"(a), "+s"(cnt)
+      : "s"(klo), "s"(khi)
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76",
+        "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89",
+        "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101",
+        "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
+        "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+        "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134",
+        "v135", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+        "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",
+        "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "scc", "memory"
+  );
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* K1: cFineTuner (FmDecode.cpp:66-82) fused into cDownsampleFilter::Process(complex)           */
 /*     (DownConvert.cpp:98-154), optionally with the RTL-SDR byte -> float conversion           */
@@ -377,7 +522,10 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
 {
   typedef typename IN::pair pair_t;
   constexpr int G = 1 << E; // regions of the de-interleaved window
-  extern __shared__ __attribute__((aligned(16))) float2 win[];
+  extern __shared__ __attribute__((aligned(16))) float2 smem_win[];
+  // the b128 tap loop's last (dummy) prefetch reaches 16 slots below the window: keep them inside
+  constexpr int WIN_PAD = (LONGASM && E == 0) ? 32 : 0;
+  float2* const win = smem_win + WIN_PAD;
   __builtin_amdgcn_s_setprio(1); // ahead of the post-chain kernels it may share a SIMD with
   // region size in slots: the window spans (TILE-1)*D + order samples plus alignment slack
   const unsigned H = (((unsigned)(TILE - 1) * D + order + 2u * G + 2u) >> E) + 1u;
@@ -460,6 +608,12 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
     for (int k = max(k_al, 0) + (int)tid; k < k_hi; k += TILE)
       win[slot(k - k_al)] = cmul(IN::one(x, k), l[(lut_idx0 + (unsigned)k) % T]);
   }
+  // fir_long_b128_asm takes pairs of taps (j, j + 1) whose lower slot -- tap j + 1's -- is even.  The
+  // slot of tap j is (k_lo - k_al) + tid * D + order - j; D is even, so its parity is the same for
+  // every lane: the pairs start at the first j whose slot is odd, at most one tap goes in front.
+  const bool b128 = LONGASM && E == 0 && (D & 3u) == 2u;
+  const unsigned jb = (((unsigned)(k_lo - k_al) + order - 1u) & 1u) ? 1u : 2u;
+  const unsigned nb128 = (b128 && order + 1u > jb) ? ((order + 1u - jb) >> 5) : 0u; // pairs of batches
   if (TILE == 64)
     lds_wave_sync(); // one wave: its LDS operations execute in order
   else
@@ -499,8 +653,30 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
     if (E == 0)
     {
       const float2* w = win + (k_lo - k_al) + tid * D + order; // w[-j] = x[p - j]
+      unsigned j = 1;
+      if (b128 && nb128)
+      {
+        if (jb == 2u)
+        { // one tap in front of the pairs
+          const float k = coeff[1];
+          const float2 s1 = w[-1];
+          acc.x += s1.x * k;
+          acc.y += s1.y * k;
+        }
+        j = jb;
+        unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)nb128);
+        unsigned a = (unsigned)(size_t)(w - (int)j - 15); // slot of tap j + 15: the batch's lowest pair
+        const size_t ka = (size_t)(coeff + j);
+        const unsigned klo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ka);
+        const unsigned khi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ka >> 32));
+        fmd_f2v acc2 = {acc.x, acc.y};
+        fir_long_b128_asm(acc2, a, klo, khi, cnt);
+        acc.x = acc2.x;
+        acc.y = acc2.y;
+        j += nb128 << 5;
+      }
 #pragma unroll 8
-      for (unsigned j = 1; j <= order; j++)
+      for (; j <= order; j++)
       {
         const float k = coeff[j];
         const float2 s = w[-(int)j];
