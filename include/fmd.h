@@ -26,14 +26,20 @@ extern "C" {
 #define FMD_OK 0
 #define FMD_ERR_ARG (-1)     /* invalid argument / unsupported configuration */
 #define FMD_ERR_DEVICE (-2)  /* HIP runtime error or no usable device */
-#define FMD_ERR_SIZE (-3)    /* samples outside [FMD_MIN_BLOCK, FMD_MAX_BLOCK] */
+#define FMD_ERR_SIZE (-3)    /* samples outside [fmd_batch_min_samples(), FMD_MAX_BLOCK] */
 #define FMD_ERR_STATE (-4)
 
 /* cRtlSdrSource::default_block_length (RTL_SDR_Source.h:25): the reference's internal buffers
  * are hard-sized to it (FmDecode.cpp:277-282), so samples <= 65536 is its precondition too. */
 #define FMD_MAX_BLOCK 65536u
-/* Below this the reference's half-band stages stop filtering (DownConvert.cpp:519-520) and
- * its level meters divide by zero; the GPU path rejects such calls instead of imitating it. */
+/* Calls of at least this size are taken by every geometry the reference itself constructs
+ * (downsample = int(fs / 215e3), IF filter order 8 * downsample).  The exact lower bound depends on
+ * the geometry -- fmd_batch_min_samples(): every stage of the RDS half-band chain needs 2 (L - 1)
+ * inputs per call (with fewer the reference's in-place history copy picks up outputs instead of
+ * inputs, DownConvert.cpp:546-547; below L it stops filtering, :519-520), and the IF filter's history
+ * is taken from one block: 3663 samples at 2.4 MS/s / downsample 11, 15318 for a 4096-tap filter at
+ * downsample 46.  Shorter calls are rejected (FMD_ERR_SIZE) instead of imitating those regimes; the
+ * reference's only caller hands over blocks of 65536 (RTL_SDR_Source.h:25). */
 #define FMD_MIN_BLOCK 8192u
 /* A further limit inherited from the reference: samples / downsample (the baseband length of a
  * call) must stay below 32768 - 51, the size of its half-band delay lines (DownConvert.cpp:267,
@@ -126,6 +132,8 @@ int fmd_batch_reset(fmd_batch* b);
 
 /* upper bounds for sizing caller buffers */
 unsigned fmd_batch_channels(const fmd_batch* b);
+/* smallest `samples` a process call of this batch accepts (see FMD_MIN_BLOCK) */
+unsigned fmd_batch_min_samples(const fmd_batch* b);
 unsigned fmd_batch_max_audio_floats(const fmd_batch* b, unsigned samples);
 
 /* Device-resident call, asynchronous on `stream` (hipStream_t, NULL = default stream).

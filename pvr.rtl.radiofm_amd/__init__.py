@@ -102,6 +102,7 @@ EXPORTS = [
     "fmd_create", "fmd_destroy", "fmd_reset", "fmd_process_stream", "fmd_process_stream_u8",
     "fmd_get_status", "fmd_batch_process_device_u8", "fmd_batch_process_host_u8",
     "fmd_batch_create", "fmd_batch_destroy", "fmd_batch_reset", "fmd_batch_channels",
+    "fmd_batch_min_samples",
     "fmd_batch_max_audio_floats", "fmd_batch_process_device", "fmd_batch_process_host",
     "fmd_batch_collect_rds", "fmd_batch_collect_rds_lagged", "fmd_batch_export_rds_device",
     "fmd_batch_set_concurrency",
@@ -145,6 +146,8 @@ def lib():
         L.fmd_batch_reset.argtypes = [vp]
         L.fmd_batch_channels.restype = u
         L.fmd_batch_channels.argtypes = [vp]
+        L.fmd_batch_min_samples.restype = u
+        L.fmd_batch_min_samples.argtypes = [vp]
         L.fmd_batch_max_audio_floats.restype = u
         L.fmd_batch_max_audio_floats.argtypes = [vp, u]
         L.fmd_batch_process_device.argtypes = [vp, vp, C.c_size_t, u, vp, C.c_size_t,
@@ -259,6 +262,10 @@ class Batch:
 
     def reset(self):
         _check(lib().fmd_batch_reset(self._h))
+
+    def min_samples(self):
+        """Smallest call size this batch's geometry accepts (fmd_batch_min_samples)."""
+        return lib().fmd_batch_min_samples(self._h)
 
     def max_audio_floats(self, samples):
         return lib().fmd_batch_max_audio_floats(self._h, samples)

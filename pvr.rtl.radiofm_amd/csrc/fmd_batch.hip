@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <memory>
@@ -102,6 +103,7 @@ struct fmd_batch
   uint32_t call_index = 0;
 
   // geometry
+  unsigned min_samples = 0; // smallest call this geometry takes (fmd_batch_min_samples)
   unsigned Mmax = 0, Mstride = 0, Amax = 0, Rmax = 0;
   std::vector<unsigned> hb_nmax; // max input length per HB stage
   // last call
@@ -448,8 +450,28 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     return fail(FMD_ERR_ARG, e.what());
   }
   const fmd::Design& d = b->des;
-  if (d.if_order > FMD_MIN_BLOCK)
-    return fail(FMD_ERR_ARG, "if_filter_order larger than the minimum block");
+  { // Smallest call: every stage of the RDS half-band chain must see at least 2 (L - 1) inputs (below
+    // that the reference's in-place history copy reads outputs instead of inputs, DownConvert.cpp:
+    // 546-547, and below L it stops filtering, :519-520), whatever phase the decimator is in; and the
+    // IF filter's history is taken from one block.
+    unsigned mmin = 1;
+    for (;; mmin++)
+    {
+      unsigned n = mmin;
+      bool ok = true;
+      for (const auto& h : d.hb)
+      {
+        ok = ok && n >= 2u * unsigned(h.len - 1);
+        n = h.len == 11 ? n / 2 : (n + 1) / 2;
+      }
+      if (ok)
+        break;
+    }
+    const unsigned long long need = std::max<unsigned long long>(1ull * mmin * d.D, d.if_order);
+    if (need > FMD_MAX_BLOCK)
+      return fail(FMD_ERR_ARG, "this geometry needs calls longer than FMD_MAX_BLOCK (if_filter_order too large)");
+    b->min_samples = unsigned(need);
+  }
   if (cb)
     b->cb = *cb;
   b->user = user;
@@ -632,6 +654,11 @@ int fmd_batch_reset(fmd_batch* b)
 unsigned fmd_batch_channels(const fmd_batch* b)
 {
   return b ? b->C : 0;
+}
+
+unsigned fmd_batch_min_samples(const fmd_batch* b)
+{
+  return b ? b->min_samples : 0;
 }
 
 unsigned fmd_batch_max_audio_floats(const fmd_batch* b, unsigned samples)
@@ -875,8 +902,9 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
 {
   if (!b || !d_iq || !d_audio)
     return fail(FMD_ERR_ARG, "fmd_batch_process_device: null argument");
-  if (samples > FMD_MAX_BLOCK || samples < FMD_MIN_BLOCK)
-    return fail(FMD_ERR_SIZE, "samples must be within [FMD_MIN_BLOCK, FMD_MAX_BLOCK]");
+  if (samples > FMD_MAX_BLOCK || samples < b->min_samples)
+    return fail(FMD_ERR_SIZE, "samples must be within [fmd_batch_min_samples(), FMD_MAX_BLOCK] = [" +
+                                  std::to_string(b->min_samples) + ", 65536]");
   // a lane loads two IQ samples at a time: every channel's stream has to start on a pair boundary
   {
     const size_t pair = fmt == IQ_U8 ? 4 : 16;
@@ -1714,6 +1742,18 @@ int fmd_batch_get_stage_ms(fmd_batch* b, float* out, unsigned cap)
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
   const int nst = b->profiling >= 2 ? ST_COUNT : 1;
+  if (getenv("FMD_PROF_DUMP")) // dev aid: the IF FIR's duration call by call
+  {
+    fprintf(stderr, "FMD_PROF_DUMP if_fir ms per call:");
+    for (unsigned c = 0; c < b->prof_calls; c++)
+    {
+      float ms = 0;
+      hipEvent_t* es = &b->ev[size_t(c) * (ST_COUNT + 1)];
+      if (hipEventElapsedTime(&ms, es[0], es[1]) == hipSuccess)
+        fprintf(stderr, " %.3f", ms);
+    }
+    fprintf(stderr, "\n");
+  }
   for (int i = 0; i < ST_COUNT; i++)
   {
     double sum = 0;

@@ -83,7 +83,7 @@ def test_call_size_limits(fmsig):
     p = fmsig.default_params(fs)
     assert d.ProcessStream(fmsig.generate_f32(p, 0, 65536).view(np.complex64)).size in (2620, 2622)
     assert d.ProcessStream(fmsig.generate_f32(p, 65536, 8192).view(np.complex64)).size > 300
-    for bad in (0, 1, 8191, 65537):
+    for bad in (0, 1, 3662, 65537):  # 3663 = 333 * 11: the smallest call at this geometry
         with pytest.raises(pkg.FmdError):
             d.ProcessStream(np.zeros(bad, np.complex64))
     # downsample = 1: a 65536-sample call would overrun the reference's 32768-entry half-band
@@ -98,6 +98,36 @@ def test_call_size_limits(fmsig):
         pkg.FmDecoder(16.2e6, 0.0, 48000.0, 15000.0, 3)  # baseband 5.4 MHz would need the CIC stage
     with pytest.raises(pkg.FmdError):
         pkg.Batch(pkg.make_params(0.0, 0.0), 1)
+
+
+def test_smallest_calls_bit_exact(oracle, fmsig):
+    """Calls down to the geometry's own minimum (fmd_batch_min_samples: 2 (L - 1) inputs for every
+    half-band stage in every decimator phase) against the oracle, mixed with full blocks."""
+    pkg = load_package()
+    fs, D = 2.4e6, 11
+    p = fmsig.default_params(fs, noise_sigma=0.01, seed=23)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 2)
+    # half-bands of 15, 23 and 43 taps: 84 inputs for the last one <- 167 <- 333 baseband samples
+    nmin = b.min_samples()
+    assert nmin == 333 * 11
+    b.enable_taps()
+    start = 0
+    for k, n in enumerate([N, nmin, nmin + 1, 4001, nmin, N, 5000, nmin + 4, nmin, 8191, nmin + 3, N]):
+        iq = fmsig.generate_f32(p, start, n)
+        start += n
+        ref = o.process_stream(iq)
+        a = b.process_host(np.stack([iq, iq]).view(np.complex64))
+        t = o.taps()
+        for name in ("demod", "rds_lpf", "rds_mf", "mono_rs"):
+            assert _bits_equal(b.tap(name, 1).view(np.float32), t[name].view(np.float32)), (k, n, name)
+        assert _bits_equal(a[0], ref) and _bits_equal(a[1], ref), (k, n)
+    with pytest.raises(pkg.FmdError):
+        b.process_host(np.zeros((2, nmin - 1), np.complex64))
+    c5 = pkg.Batch(pkg.make_params(10e6, -1.5e6, 48000.0, 15000.0, 46, if_filter_order=4096), 1)
+    assert c5.min_samples() == 333 * 46
+    b.close()
+    c5.close()
 
 
 @pytest.mark.parametrize("fs,D,sizes", [(400e3, 1, [32000, 32001, 20000, 8193, 32700]),
