@@ -147,11 +147,18 @@ def main():
     # development aid: several ranks on ONE GPU with a host-staged gather, to exercise the N > 1
     # control flow where only one GPU exists.
     backend = os.environ.get("FMD_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # FMD_BENCH_FORCE_DIST=1: run the N > 1 code path (communicator, side stream, gather to rank 0,
+    # group counting from the gathered records) with a world of ONE rank -- what a box with a single
+    # GPU can exercise of the RCCL path: the communicator is initialised and every gather call is made.
+    dist_on = world > 1 or os.environ.get("FMD_BENCH_FORCE_DIST") == "1"
+    if dist_on and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29549")
+    if dist_on:
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     global FS, D
     order = 0
@@ -199,9 +206,9 @@ def main():
 
     # the communicator (and its streams) first: the decoder picks its internal streams by a probe
     # when the batch is created and should see everything else that uses hardware queues
-    if world > 1:
+    if dist_on:
         dg.gather_preflight(dev if backend == "nccl" else "cpu")
-    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    comm_stream = torch.cuda.Stream(device=dev) if dist_on else None
     # development aid: other users of hardware queues in the process, created first
     extra_streams = [torch.cuda.Stream(device=dev)
                      for _ in range(int(os.environ.get("FMD_BENCH_EXTRA_STREAMS", "0")))]
@@ -219,10 +226,10 @@ def main():
     # memory (fmd_batch_export_rds_device) and go into the gather as they are -- no host round trip.
     # N = 1: the host pulls them (fmd_batch_collect_rds), like an application that runs the UECP
     # group decoder would.
-    use_export = world > 1 or args.verify
+    use_export = dist_on or args.verify
     g_audio = g_rds = None
-    if rank == 0 and (world > 1 or args.verify):
-        on = dev if (backend == "nccl" or world == 1) else "cpu"
+    if rank == 0 and (dist_on or args.verify):
+        on = dev if (backend == "nccl" or not dist_on) else "cpu"
         g_audio = [[torch.empty((C, a_stride), dtype=torch.float32, device=on) for _ in range(world)]
                    for _ in range(NBUF)]
         g_rds = [[torch.empty((RCAP, 4), dtype=torch.int32, device=on) for _ in range(world)]
@@ -249,7 +256,7 @@ def main():
         if use_export:
             batch.export_rds_device(rds_dev[slot].data_ptr(), RCAP, channel_offset=rank * C,
                                     stream=stream, lag=lag)
-        if world > 1:
+        if dist_on:
             ev = torch.cuda.Event()
             ev.record()
             if backend == "nccl":
@@ -338,7 +345,7 @@ def main():
         torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     def reduce_scalar(x, op):
@@ -402,7 +409,7 @@ def main():
             ok = 0.0 if bad else 1.0
             if bad:
                 sys.stderr.write("bench.py --verify: MISMATCH %r\n" % (bad,))
-        if world > 1:
+        if dist_on:
             ok = reduce_scalar(ok, dist.ReduceOp.MIN)
         if ok != 1.0:
             raise SystemExit(4)
@@ -468,7 +475,7 @@ def main():
         t00 = serial_probe[0]["start"] if serial_probe else 0
         for r in serial_probe:
             r["start"] = round((r["start"] - t00) / 100.0, 1)
-    if world > 1:
+    if dist_on:
         dt = reduce_scalar(dt, dist.ReduceOp.MAX)
     stage, calls = batch.stage_ms()
     fir_ms = stage["if_fir"]
@@ -519,7 +526,9 @@ def main():
                        else "shuffle (opt-in, NOT bit-exact)",
                        "channels_per_gpu": C, "samples_per_call": N, "input_ring_blocks": ring,
                        "audio_floats_per_channel_step": nf, "rds_groups_in_timed_region": total_groups,
-                       "gather": "rank-0 RCCL gather of audio+RDS per step" if world > 1 else "none (1 GPU)",
+                       "gather": ("rank-0 gather of audio + RDS records per step over %s (%d rank%s)"
+                                  % ("RCCL" if backend == "nccl" else backend, world, "" if world == 1 else "s"))
+                       if dist_on else "none (1 GPU)",
                        "host_ms_per_step": {"submit": round(host_ms["process"], 3),
                                             "wait": round(host_ms.get("wait", 0.0), 3),
                                             "collect_rds": round(host_ms["collect"], 3),
@@ -559,7 +568,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(if_filter_order=order)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -49,3 +49,21 @@ def test_single_rank_verify_full_shard():
     batch of the same stations (first, second, middle, last channel)."""
     d = _run_bench(1, ["--steps", "12", "--warmup", "2", "--ring", "4"], 29543)
     assert d["n_gpus"] == 1 and d["verify"]["ok"] and d["verify"]["channels_per_rank"] == [0, 1, 4096, 8191]
+
+
+def test_rccl_path_with_a_world_of_one():
+    """What one GPU can run of the RCCL path: FMD_BENCH_FORCE_DIST=1 initialises the nccl (= RCCL)
+    communicator with a single rank and makes every call of the N > 1 path -- pre-flight gather,
+    side stream, per-step gather of device tensors, group counting from the gathered records -- and
+    --verify compares what "arrived" with a recomputation."""
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    env.update(FMD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29544",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("FMD_BENCH_BACKEND", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline",
+                          "--verify", "--channels", "256", "--steps", "30", "--warmup", "3", "--ring", "24",
+                          "--watchdog", "240"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "RCCL" in d["config"]["gather"] and d["verify"]["ok"]
+    assert d["config"]["rds_groups_in_timed_region"] > 0
