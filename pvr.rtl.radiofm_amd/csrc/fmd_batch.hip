@@ -157,7 +157,10 @@ struct fmd_batch
   //   concurrency 2: as 1, but the caller's stream is only ordered after a call by fmd_batch_wait /
   //                  fmd_batch_collect_rds; lets call k+1's FIR overlap call k's serial stages
   int concurrency = 1;
-  hipStream_t s_fir = nullptr, s_ser = nullptr, s_post = nullptr, s_rds = nullptr;
+  hipStream_t s_fir = nullptr, s_ser = nullptr, s_post = nullptr, s_rds = nullptr, s_aud = nullptr;
+  // The two heavy chains behind the serial stage -- RDS decimator (bandwidth-bound) and resampler +
+  // audio low-pass (issue-bound) -- side by side on s_post and s_aud instead of one after the other
+  bool heavy_par = false;
   // The light part of a call's post chain (RDS PLL, matched filter, bit recovery, audio tail), kept
   // back until the next call is submitted (or its results are asked for): see process_device_impl.
   struct LightJob
@@ -171,7 +174,7 @@ struct fmd_batch
   } light_job;
   bool split_post = false;
   bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
-  enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_N };
+  enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_HEAVY_A, EV_N };
   hipEvent_t cev[NSLOT][EV_N] = {};
   bool cev_ready = false;
   uint32_t slot_call[NSLOT] = {}; // call index that last used the slot (0 = never)
@@ -240,6 +243,8 @@ struct fmd_batch
       (void)hipStreamDestroy(s_post);
       if (s_rds)
         (void)hipStreamDestroy(s_rds);
+      if (s_aud)
+        (void)hipStreamDestroy(s_aud);
     }
     h_iq.release();
     h_audio.release();
@@ -597,14 +602,16 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     // post chain has slack every call and goes last
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi)); // lo = least, hi = greatest priority
-    const int prio[4] = {hi, hi, lo, lo};
-    hipStream_t st4[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (pick_independent_streams(4, prio, st4) != 0)
+    const int prio[5] = {hi, hi, lo, lo, lo};
+    hipStream_t st4[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (pick_independent_streams(5, prio, st4) != 0)
       return fail(FMD_ERR_DEVICE, "could not create the internal streams");
     b->s_fir = st4[0];
     b->s_ser = st4[1];
     b->s_post = st4[2];
     b->s_rds = st4[3];
+    b->s_aud = st4[4];
+    b->heavy_par = getenv("FMD_HEAVY_PAR") ? atoi(getenv("FMD_HEAVY_PAR")) != 0 : false;
     // RDS chain and audio chain behind the serial stage are independent.  With more channels than
     // the chip holds serial-stage workgroups (256 CUs x 64 channels) the batch is throughput-bound
     // and they run side by side on two streams (+10 % at 24 576, +12 % at 32 768 channels); below
@@ -977,7 +984,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   hipStream_t sF = serial_mode ? stream : b->s_fir;
   hipStream_t sS = serial_mode ? stream : b->s_ser;
   hipStream_t sP = serial_mode ? stream : b->s_post;
-  hipStream_t sA = sP, sR = (!serial_mode && b->split_post) ? b->s_rds : sP;
+  const bool heavy_par = !serial_mode && !b->split_post && b->heavy_par;
+  hipStream_t sA = heavy_par ? b->s_aud : sP, sR = (!serial_mode && b->split_post) ? b->s_rds : sP;
   // one-stream form: the light parts of the post chain go to their own stream (see below)
   hipStream_t sL = serial_mode ? stream : b->s_rds;
   hipEvent_t* ce = b->cev[es];
@@ -1190,6 +1198,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
 
     /* ---- audio branch  (stream A): resamplers, 15 kHz LPF, de-emphasis / notch / matrix ---- */
     after(sA, ce[fmd_batch::EV_SER]);
+    if (heavy_par)
+      post_delay(sA);
     hipLaunchKernelGGL(fmd::k_rs_table, dim3(A), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p,
                        pstep, A, b->ktab.p, b->rs_row, b->rs_margin, b->pidx.p);
     hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
@@ -1242,11 +1252,16 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     if (have_prev2)
     {
       after(sP, pe2[fmd_batch::EV_RDS]);
-      after(sP, pe2[fmd_batch::EV_AUD]);
+      after(sA, pe2[fmd_batch::EV_AUD]);
     }
     rds_heavy();
     audio_heavy();
-    signal(ce[fmd_batch::EV_HEAVY], sA);
+    if (heavy_par)
+    { // EV_HEAVY = both chains done
+      signal(ce[fmd_batch::EV_HEAVY_A], sA);
+      after(sP, ce[fmd_batch::EV_HEAVY_A]);
+    }
+    signal(ce[fmd_batch::EV_HEAVY], sP);
     fmd_batch::LightJob job;
     job.pending = true;
     job.R = R;

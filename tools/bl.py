@@ -11,5 +11,6 @@ for line in sys.stdin:
     d = json.loads(line)
     r = d["roofline"]
     print(tag, "value", d["value"], "ms/step", d["ms_per_step"], "| fir in-pipe ms", r["avg_ms"], "GB/s", r["achieved"],
-          "frac", r["frac"], "TF", r["valu_tflops_nofma"], "| alone", r.get("alone", {}).get("avg_ms"),
-          "|", " ".join("%s=%.3f" % (k[:9], v) for k, v in d.get("stage_ms", {}).items()))
+          "frac", r["frac"], "TF", r["valu_tflops_nofma"], "| alone", r.get("alone", {}).get("avg_ms"))
+    if d.get("stage_ms"):
+        print("   stages:", " ".join("%s=%.3f" % (k, v) for k, v in d["stage_ms"].items()))

@@ -83,7 +83,7 @@ void run(const char* name, int nops, int threads)
 }
 int main()
 {
-  for (int th : {64, 256, 512})
+  for (int th : {64, 256, 512, 1024})
   {
     run<2>("v_mul_f32 x8", 8, th);
     run<0>("v_pk_mul_f32 x8", 8, th);
