@@ -8,6 +8,10 @@ cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -1 gpurun_out/${TAG}_bench.json
+# the driver's own flags (20 timed steps: the pipeline's fill and drain are ~10 % of the region)
+python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_flags.json 2>/dev/null
+# the N > 1 code path with a world of one rank (RCCL initialised, per-step gather to rank 0 = self)
+FMD_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --verify > gpurun_out/${TAG}_bench_rccl_world1.json 2>/dev/null
 python bench.py --concurrency 0 --stage-profile --no-cpu-baseline > gpurun_out/${TAG}_bench_serialised.json 2>/dev/null
 # the other BASELINE configurations and the byte-input workload (parity-test cases, not the bench line)
 python bench.py --workload config5 --no-cpu-baseline --stage-profile > gpurun_out/${TAG}_bench_config5.json 2>/dev/null

@@ -12,7 +12,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(pr, exist_ok=True)
-for name in ("bench", "bench_serialised", "bench_config5", "bench_config3", "bench_u8", "bench_32768ch"):
+for name in ("bench", "bench_serialised", "bench_config5", "bench_config3", "bench_u8", "bench_32768ch",
+             "bench_driver_flags", "bench_rccl_world1"):
     src = os.path.join(go, "%s_%s.json" % (tag, name))
     if os.path.exists(src):
         line = open(src).read().strip().splitlines()[-1]
