@@ -16,7 +16,7 @@ for name in ("bench", "bench_serialised", "bench_config5", "bench_config3", "ben
              "bench_driver_flags", "bench_rccl_world1"):
     src = os.path.join(go, "%s_%s.json" % (tag, name))
     if os.path.exists(src):
-        line = open(src).read().strip().splitlines()[-1]
+        line = [l for l in open(src).read().splitlines() if l.startswith('{"metric"')][-1]
         json.loads(line)
         open(os.path.join(pr, "%s_%s.json" % (tag, name)), "w").write(line + "\n")
 # the bench line printed by the very runs rocprofv3 traced (its event-based FIR time belongs beside
