@@ -131,6 +131,9 @@ def main():
                     help="fmd_batch_set_concurrency mode (2 = calls overlap, the default)")
     ap.add_argument("--stage-profile", action="store_true",
                     help="after the timed region, run 3 extra steps with per-stage events")
+    ap.add_argument("--lag", type=int, default=3, choices=[1, 2, 3, 4],
+                    help="steps between submitting a call and consuming its outputs (host never blocks "
+                         "on a call younger than this)")
     ap.add_argument("--fir-reduction", type=int, default=0, choices=[0, 1],
                     help="0: sequential tap order, bit-exact (default, what every reported figure uses); "
                          "1: opt-in shuffle-reduced tap sum (not bit-exact; measured for DESIGN.md only)")
@@ -244,7 +247,7 @@ def main():
                                       fir_reduction=args.fir_reduction),
                       C, tuning_shifts=shifts, device=local_rank, record_callbacks=False)
     a_stride = (batch.max_audio_floats(N) + 63) // 64 * 64
-    NBUF = 6  # outputs are consumed three steps after they are produced
+    NBUF = args.lag + 3  # outputs are consumed LAG steps after they are produced, then gathered
     audio = [torch.zeros((C, a_stride), dtype=torch.float32, device=dev) for _ in range(NBUF)]
     RCAP = C  # RDS records per rank per step (a group takes 87.6 ms, a step 27.3 ms: <= 1 per channel)
     rds_dev = [torch.zeros((RCAP, 4), dtype=torch.int32, device=dev) for _ in range(NBUF)]
@@ -266,7 +269,9 @@ def main():
     total_groups = 0
 
     batch.set_concurrency(args.concurrency)  # 2: FIR of step i+1 overlaps the serial stages of step i
-    LAG = 3  # outputs of step i are consumed after step i+3 is submitted: the host never stalls
+    # outputs of step i are consumed after step i+LAG is submitted: the host blocks on nothing younger
+    # (3 and 4 measure the same, 244 GS/s on one box: the period is set by the device's work)
+    LAG = args.lag
     state = {"submitted": -1, "finalized": -1}
 
     def pull_groups(lag):
