@@ -32,14 +32,15 @@ extern "C" {
 /* cRtlSdrSource::default_block_length (RTL_SDR_Source.h:25): the reference's internal buffers
  * are hard-sized to it (FmDecode.cpp:277-282), so samples <= 65536 is its precondition too. */
 #define FMD_MAX_BLOCK 65536u
-/* Calls of at least this size are taken by every geometry the reference itself constructs
- * (downsample = int(fs / 215e3), IF filter order 8 * downsample).  The exact lower bound depends on
- * the geometry -- fmd_batch_min_samples(): every stage of the RDS half-band chain needs 2 (L - 1)
- * inputs per call (with fewer the reference's in-place history copy picks up outputs instead of
- * inputs, DownConvert.cpp:546-547; below L it stops filtering, :519-520), and the IF filter's history
- * is taken from one block: 3663 samples at 2.4 MS/s / downsample 11, 15318 for a 4096-tap filter at
- * downsample 46.  Shorter calls are rejected (FMD_ERR_SIZE) instead of imitating those regimes; the
- * reference's only caller hands over blocks of 65536 (RTL_SDR_Source.h:25). */
+/* Calls of at least this size are taken by every geometry.  The exact lower bound of a batch is
+ * fmd_batch_min_samples() and is far smaller (88 samples at 2.4 MS/s / downsample 11): short blocks
+ * are decoded the way the reference decodes them -- a half-band stage with fewer than L inputs
+ * passes them on unfiltered (DownConvert.cpp:519-520), with fewer than 2 (L - 1) it refills its delay
+ * line from its own outputs (:546-547, the in-place array), a block shorter than a filter keeps part
+ * of the old history (:137-145, :236-253).  Refused (FMD_ERR_SIZE) are only blocks so short that some
+ * stage would get no sample at all -- the reference's level meters divide by zero there
+ * (FmDecode.cpp:522-539) -- or fewer than the 20 inputs its unrolled 11-tap stage reads
+ * unconditionally (:596-661). */
 #define FMD_MIN_BLOCK 8192u
 /* A further limit inherited from the reference: samples / downsample (the baseband length of a
  * call) must stay below 32768 - 51, the size of its half-band delay lines (DownConvert.cpp:267,

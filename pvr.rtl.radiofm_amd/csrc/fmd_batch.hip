@@ -455,26 +455,36 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     return fail(FMD_ERR_ARG, e.what());
   }
   const fmd::Design& d = b->des;
-  { // Smallest call: every stage of the RDS half-band chain must see at least 2 (L - 1) inputs (below
-    // that the reference's in-place history copy reads outputs instead of inputs, DownConvert.cpp:
-    // 546-547, and below L it stops filtering, :519-520), whatever phase the decimator is in; and the
-    // IF filter's history is taken from one block.
-    unsigned mmin = 1;
+  { // Smallest call.  Short blocks are decoded like the reference decodes them (a half-band stage
+    // below L inputs passes its input on unfiltered, below 2 (L - 1) it refills its delay line from
+    // outputs, a block shorter than a filter keeps part of the old history: process_device_impl);
+    // what is refused are only blocks so short that a stage would be left with NO sample -- there the
+    // reference divides by zero in its level meters (FmDecode.cpp:522-539, RadioReceiver.cpp:584-598)
+    // -- and blocks that give the unrolled 11-tap class fewer inputs than it reads unconditionally.
+    // The bound holds in every phase of the decimator: baseband samples M >= N / D rounded down.
+    unsigned mmin = 5; // an audio frame falls into every block of >= ceil(step) + 1 baseband samples
+    while (double(mmin) < double(d.rs_step) + 1.0)
+      mmin++;
     for (;; mmin++)
     {
       unsigned n = mmin;
       bool ok = true;
       for (const auto& h : d.hb)
       {
-        ok = ok && n >= 2u * unsigned(h.len - 1);
-        n = h.len == 11 ? n / 2 : (n + 1) / 2;
+        if (h.len == 11)
+        {
+          ok = ok && n >= 20;
+          n = n / 2;
+        }
+        else
+          n = n < unsigned(h.len) ? n / 2 : (n + 1) / 2;
       }
-      if (ok)
+      if (ok && n >= 1)
         break;
     }
-    const unsigned long long need = std::max<unsigned long long>(1ull * mmin * d.D, d.if_order);
+    const unsigned long long need = 1ull * mmin * d.D;
     if (need > FMD_MAX_BLOCK)
-      return fail(FMD_ERR_ARG, "this geometry needs calls longer than FMD_MAX_BLOCK (if_filter_order too large)");
+      return fail(FMD_ERR_ARG, "this geometry needs calls longer than FMD_MAX_BLOCK");
     b->min_samples = unsigned(need);
   }
   if (cb)
@@ -934,17 +944,35 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   // baseband blocks overrun its heap, so they are outside the contract here too
   if ((N + D - 1) / D + 51 > 32768)
     return fail(FMD_ERR_SIZE, "baseband block longer than the reference's half-band buffers (32768)");
+  // Per stage of the half-band chain: how many inputs it sees and which of the reference's regimes
+  // that is (see k_hb_pass / k_roll_hb_mixed): HB_PASS below L inputs, HB_MIXED below 2 (L - 1).
+  enum HbMode { HB_NORMAL, HB_MIXED, HB_PASS };
   std::vector<unsigned> hb_in(d.hb.size());
+  std::vector<HbMode> hb_mode(d.hb.size(), HB_NORMAL);
   unsigned R = M;
   for (size_t s = 0; s < d.hb.size(); s++)
   {
     hb_in[s] = R;
-    if (R < 2u * unsigned(d.hb[s].len - 1))
-      return fail(FMD_ERR_SIZE, "block too short for the RDS half-band chain at this rate");
-    // the generic class returns one output per even input index (DownConvert.cpp:526-543), the
-    // 11-tap class InLength / 2 (:688)
-    R = d.hb[s].len == 11 ? R / 2 : (R + 1) / 2;
+    const unsigned L = unsigned(d.hb[s].len);
+    if (L == 11)
+    { // the unrolled class reads InLength - 10 .. and its first nine outputs unconditionally (:596-661)
+      if (R < 20)
+        return fail(FMD_ERR_SIZE, "block too short for the 11-tap half-band stage");
+      R = R / 2; // :688
+    }
+    else if (R < L)
+    {
+      hb_mode[s] = HB_PASS;
+      R = R / 2; // :519-520
+    }
+    else
+    { // one output per even input index (:526-543)
+      hb_mode[s] = R >= 2u * (L - 1u) ? HB_NORMAL : HB_MIXED;
+      R = (R + 1) / 2;
+    }
   }
+  if (R == 0)
+    return fail(FMD_ERR_SIZE, "block too short: no sample reaches the RDS rate");
   // fractional resampler walk (DownConvert.cpp:203-232), float arithmetic as written there
   const float p = b->rs_pos;
   const float pstep = d.rs_step;
@@ -962,6 +990,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     new_rs_pos = 0;
   if (A > b->Amax || M > b->Mmax)
     return fail(FMD_ERR_STATE, "internal: plan exceeds buffer geometry");
+  if (A == 0)
+    return fail(FMD_ERR_SIZE, "block too short: no audio frame falls into it");
   if (size_t(2) * A > audio_channel_stride && C > 1)
     return fail(FMD_ERR_ARG, "audio_channel_stride smaller than the audio produced");
 
@@ -1123,11 +1153,22 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       const float2* in = b->mix[q].p;
       for (size_t s = 0; s < d.hb.size(); s++)
       {
-        const unsigned n_out = d.hb[s].len == 11 ? hb_in[s] / 2 : (hb_in[s] + 1) / 2;
+        const unsigned n_out =
+            (d.hb[s].len == 11 || hb_mode[s] == HB_PASS) ? hb_in[s] / 2 : (hb_in[s] + 1) / 2;
         const bool last = (s + 1 == d.hb.size());
         float2* outp = last ? b->rdsraw.p : b->hbbuf[s].p;
         const unsigned Hout = last ? (T_lpf - 1) : unsigned(d.hb[s + 1].len - 1);
         static const int hb4 = getenv("FMD_HB4") ? atoi(getenv("FMD_HB4")) : 1;
+        const unsigned Hs = unsigned(d.hb[s].len - 1);
+        float2* const hist_dst = s == 0 ? b->mix[q ^ 1].p : b->hbbuf[s - 1].p; // where the delay line lives
+        if (hb_mode[s] == HB_PASS)
+        { // unfiltered; the delay line stays (stage 0 keeps it in the other parity's buffer: copy it over)
+          hipLaunchKernelGGL(fmd::k_hb_pass, rgrid(n_out), rt, 0, sR, in, Hs, outp, Hout, n_out, CP);
+          if (s == 0)
+            hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->mix[q].p, b->mix[q ^ 1].p, Hs, 0u, CP);
+          in = outp;
+          continue;
+        }
         if (d.hb[s].len == 11)
           hipLaunchKernelGGL(fmd::k_halfband11, dim3(CP / 64, (n_out + 3) / 4), dim3(64, 4), 0, sR, in, outp,
                              n_out, b->hbcoef[s], C, CP, Hout);
@@ -1138,8 +1179,10 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
         hipLaunchKernelGGL(fmd::k_halfband, dim3(CP / 64, (n_out + 4 * fmd::HB_R - 1) / (4 * fmd::HB_R)),
                            dim3(64, 4), 0, sR, in, outp, n_out, d.hb[s].len, b->hbcoef[s], C, CP, Hout);
         // keep the last L-1 input rows of this stage for the next call, then its input is free
-        const unsigned Hs = unsigned(d.hb[s].len - 1);
-        if (s == 0)
+        if (hb_mode[s] == HB_MIXED)
+          hipLaunchKernelGGL(fmd::k_roll_hb_mixed, dim3((CP + 255) / 256), rt, 0, sR, in, (const float2*)outp,
+                             hist_dst, Hs, hb_in[s], n_out, Hout, CP);
+        else if (s == 0)
         { // tail of mix[q] -> history rows of mix[q^1], which the next call's half-band reads
           hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->mix[q].p, b->mix[q ^ 1].p, Hs,
                              hb_in[0], CP);

@@ -744,14 +744,22 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
     out[(size_t)c * Mstride + m0 + tid] = acc;
   }
 
-  // the workgroup of the last tile also saves the last `order` tuned samples (:146-151)
+  // the workgroup of the last tile also saves the last `order` tuned samples (:135-151); a block
+  // shorter than the filter keeps the newest part of the old history in front of it (:137-145)
   if (tile == ntiles - 1)
   {
     float2* __restrict__ ho = hist_out + (size_t)c * order;
+    const float2* __restrict__ hi = hist_in + (size_t)c * order;
+    const unsigned keep = N < order ? order - N : 0u;
     for (unsigned i = tid; i < order; i += TILE)
     {
-      const unsigned k = N - order + i;
-      ho[i] = cmul(IN::one(x, k), l[(lut_idx0 + k) % T]);
+      if (i < keep)
+        ho[i] = hi[i + N];
+      else
+      {
+        const unsigned k = N + i - order;
+        ho[i] = cmul(IN::one(x, k), l[(lut_idx0 + k) % T]);
+      }
     }
   }
 }
@@ -890,10 +898,17 @@ __global__ __launch_bounds__(64) void k_if_fir_mt(const typename IN::elem* __res
     if (tile == ntiles - 1)
     {
       float2* __restrict__ ho = hist_out + (size_t)c * order;
+      const float2* __restrict__ hi = hist_in + (size_t)c * order;
+      const unsigned keep = N < order ? order - N : 0u;
       for (unsigned q = tid; q < order; q += TILE)
       {
-        const unsigned k = N - order + q;
-        ho[q] = cmul(IN::one(x, k), l[(lut_idx0 + k) % T]);
+        if (q < keep)
+          ho[q] = hi[q + N];
+        else
+        {
+          const unsigned k = N + q - order;
+          ho[q] = cmul(IN::one(x, k), l[(lut_idx0 + k) % T]);
+        }
       }
     }
     lds_wave_sync(); // this tile's window reads are done before the next tile's staging
@@ -1364,6 +1379,39 @@ __global__ __launch_bounds__(256) void k_halfband(const float2* __restrict__ in,
       ai[r] = ai[r] + x.y * hc.c[mid];
       out[(size_t)(Hout + k0 + r) * CP + c] = make_float2(ar[r], ai[r]);
     }
+  }
+}
+
+/* Short blocks.  CHalfBandDecimateBy2::DecBy2 works in place (pInData == pOutData, DownConvert.cpp:
+ * 480) and has two regimes below 2 (L - 1) inputs that are part of what the reference computes:
+ *  - InLength < L (:519-520): nothing is filtered, the call returns InLength / 2 and the "outputs" are
+ *    the first InLength / 2 INPUTS; the delay line is left alone           -> k_hb_pass, no roll
+ *  - L <= InLength < 2 (L - 1): filtered as usual, but the delay line is refilled from the in / out
+ *    array after the outputs were written over its front (:546-547): entry i is array element
+ *    InLength - L + 1 + i, which is an OUTPUT when that index is below the output count
+ *                                                                           -> k_roll_hb_mixed */
+__global__ void k_hb_pass(const float2* __restrict__ in, unsigned H, float2* __restrict__ out, unsigned Hout,
+                          unsigned n_out, unsigned CP)
+{
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= CP)
+    return;
+  for (unsigned k = blockIdx.y; k < n_out; k += gridDim.y)
+    out[(size_t)(Hout + k) * CP + c] = in[(size_t)(H + k) * CP + c];
+}
+
+/* dst rows [0, H) <- array elements n - H + r: outputs (rows Hout + idx of `outp`) below n_out, else
+ * inputs (rows H + idx of `in`).  dst may be `in` (rows move towards the front: ascending order). */
+__global__ void k_roll_hb_mixed(const float2* in, const float2* __restrict__ outp, float2* dst, unsigned H,
+                                unsigned n, unsigned n_out, unsigned Hout, unsigned CP)
+{
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= CP)
+    return;
+  for (unsigned r = 0; r < H; r++)
+  {
+    const unsigned idx = n - H + r;
+    dst[(size_t)r * CP + c] = idx < n_out ? outp[(size_t)(Hout + idx) * CP + c] : in[(size_t)(H + idx) * CP + c];
   }
 }
 

@@ -83,7 +83,7 @@ def test_call_size_limits(fmsig):
     p = fmsig.default_params(fs)
     assert d.ProcessStream(fmsig.generate_f32(p, 0, 65536).view(np.complex64)).size in (2620, 2622)
     assert d.ProcessStream(fmsig.generate_f32(p, 65536, 8192).view(np.complex64)).size > 300
-    for bad in (0, 1, 3662, 65537):  # 3663 = 333 * 11: the smallest call at this geometry
+    for bad in (0, 1, 87, 65537):  # 88 = 8 * 11: the smallest call at this geometry
         with pytest.raises(pkg.FmdError):
             d.ProcessStream(np.zeros(bad, np.complex64))
     # downsample = 1: a 65536-sample call would overrun the reference's 32768-entry half-band
@@ -100,34 +100,63 @@ def test_call_size_limits(fmsig):
         pkg.Batch(pkg.make_params(0.0, 0.0), 1)
 
 
-def test_smallest_calls_bit_exact(oracle, fmsig):
-    """Calls down to the geometry's own minimum (fmd_batch_min_samples: 2 (L - 1) inputs for every
-    half-band stage in every decimator phase) against the oracle, mixed with full blocks."""
+def test_short_calls_bit_exact(oracle, fmsig):
+    """Calls far below the usual 65536 samples, decoded like the reference decodes them: half-band
+    stages that pass their input on unfiltered (fewer than L inputs, DownConvert.cpp:519-520), stages
+    whose delay line is refilled from outputs (fewer than 2 (L - 1) inputs, :546-547), blocks shorter
+    than the resampler's history (:236-253), mixed with full blocks so that every history matters.
+    2.4 MS/s, D = 11: half-bands of 15, 23 and 43 taps."""
     pkg = load_package()
     fs, D = 2.4e6, 11
     p = fmsig.default_params(fs, noise_sigma=0.01, seed=23)
     o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
     b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 2)
-    # half-bands of 15, 23 and 43 taps: 84 inputs for the last one <- 167 <- 333 baseband samples
     nmin = b.min_samples()
-    assert nmin == 333 * 11
+    assert nmin == 8 * 11  # 8 baseband samples: 8 -> 4 -> 2 -> 1 through three passing stages
     b.enable_taps()
     start = 0
-    for k, n in enumerate([N, nmin, nmin + 1, 4001, nmin, N, 5000, nmin + 4, nmin, 8191, nmin + 3, N]):
+    sizes = [N, nmin, nmin + 1, 100, 150, 170, 171, 200, 330, 500, 1000, 1900, N, 3000, 3662, 3663, 160, 5000,
+             nmin, 97, 8191, 640, 2222, N, 310, 320, 460, 470, 930, 940]
+    for k, n in enumerate(sizes):
         iq = fmsig.generate_f32(p, start, n)
         start += n
         ref = o.process_stream(iq)
         a = b.process_host(np.stack([iq, iq]).view(np.complex64))
         t = o.taps()
-        for name in ("demod", "rds_lpf", "rds_mf", "mono_rs"):
+        for name in ("demod", "baseband", "rds_lpf", "rds_pll", "rds_mf", "mono_rs", "stereo_rs"):
             assert _bits_equal(b.tap(name, 1).view(np.float32), t[name].view(np.float32)), (k, n, name)
         assert _bits_equal(a[0], ref) and _bits_equal(a[1], ref), (k, n)
+        so, sg = o.status(), b.status(0)
+        for f_o, f_g in ((so.if_level, sg.interface_level), (so.baseband_level, sg.baseband_level),
+                         (so.pilot_level, sg.pilot_level)):
+            assert np.float32(f_o) == np.float32(f_g), (k, n)
     with pytest.raises(pkg.FmdError):
         b.process_host(np.zeros((2, nmin - 1), np.complex64))
-    c5 = pkg.Batch(pkg.make_params(10e6, -1.5e6, 48000.0, 15000.0, 46, if_filter_order=4096), 1)
-    assert c5.min_samples() == 333 * 46
     b.close()
-    c5.close()
+
+
+def test_short_calls_long_filter_and_eleven_tap(oracle, fmsig):
+    """Blocks shorter than the IF filter (4096 taps: the history keeps part of the previous one,
+    DownConvert.cpp:137-145) and short blocks into the 11-tap first stage (needs 20 inputs)."""
+    pkg = load_package()
+    for fs, D, order, sizes in ((10e6, 46, 4096, [N, 2000, 3000, 4095, 4097, 1000, N, 700, 40000]),
+                                (400e3, 1, 0, [32000, 20, 21, 64, 500, 33, 2000, 32000, 25])):
+        p = fmsig.default_params(fs, noise_sigma=0.01, seed=29)
+        o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D, if_filter_order=order)
+        b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D, if_filter_order=order), 1)
+        assert min(sizes) >= b.min_samples()
+        b.enable_taps()
+        start = 0
+        for k, n in enumerate(sizes):
+            iq = fmsig.generate_f32(p, start, n)
+            start += n
+            ref = o.process_stream(iq)
+            a = b.process_host(iq.view(np.complex64), shared=True)
+            t = o.taps()
+            for name in ("demod", "rds_lpf", "rds_mf", "mono_rs"):
+                assert _bits_equal(b.tap(name).view(np.float32), t[name].view(np.float32)), (fs, k, n, name)
+            assert _bits_equal(a[0], ref), (fs, k, n)
+        b.close()
 
 
 @pytest.mark.parametrize("fs,D,sizes", [(400e3, 1, [32000, 32001, 20000, 8193, 32700]),

@@ -217,7 +217,7 @@ def test_ragged_block_sizes_and_reset(pkg, oracle, fmsig):
         assert a.shape == r.shape, (i, n)
         assert _bits_equal(a, r), (i, n, _rms(a, r))
     with pytest.raises(pkg.FmdError):
-        d.ProcessStream(np.zeros(100, np.complex64))  # below FMD_MIN_BLOCK: rejected loudly
+        d.ProcessStream(np.zeros(50, np.complex64))  # below fmd_batch_min_samples(): rejected loudly
 
 
 def test_concurrency_modes_agree(pkg, fmsig):
