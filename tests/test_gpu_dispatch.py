@@ -111,7 +111,7 @@ def test_config4_geometry_overlapped_ragged_two_tile_fir(oracle, fmsig, u8):
     pkg = load_package()
     C = 1024
     # outputs per call ~ n / 11, tiles of 64 outputs, two tiles per workgroup
-    sizes = [N, 10007, 8192, 65535, 33001, 45057, N, 8193, 21120]
+    sizes = [N, 10007, 8192, 65535, 150, 33001, 1001, 45057, N, 8193, 330, 21120]  # incl. short calls
     _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, C, sizes,
                     check=[0, 63, 64, 511, 512, 1023], u8=u8)
 
