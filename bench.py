@@ -140,7 +140,10 @@ def main():
     ap.add_argument("--verify", action="store_true",
                     help="before the timed region: rank 0 checks the audio and RDS records it gathered "
                          "from every rank (a few channels each, first steps) bit for bit against its own "
-                         "recomputation of those channels in a small batch; exits 4 on a mismatch")
+                         "recomputation of those channels in a small batch; exits 4 on a mismatch.  "
+                         "On by default with more than one rank (a multi-GPU number is only reported for "
+                         "a gather that was checked); --no-verify turns it off")
+    ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--watchdog", type=int, default=900,
                     help="seconds after which a run that has not finished kills itself (a hung "
                          "collective or kernel must not keep the box busy)")
@@ -180,6 +183,8 @@ def main():
     # group counting from the gathered records) with a world of ONE rank -- what a box with a single
     # GPU can exercise of the RCCL path: the communicator is initialised and every gather call is made.
     dist_on = world > 1 or os.environ.get("FMD_BENCH_FORCE_DIST") == "1"
+    if world > 1 and not args.no_verify:
+        args.verify = True
     if dist_on and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29549")

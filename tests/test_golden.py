@@ -69,3 +69,47 @@ def test_hip_path_reproduces_golden(path, fmsig):
         assert np.float32(st.pilot_level) == ref[4] and np.float32(st.interface_level) == ref[2]
     assert [f.hex() for f in b.sink.frames.get(0, [])] == [str(x) for x in g["uecp_frames"]]
     assert b.sink.names.get(0, "") == str(g["channel_name"])
+
+
+RAGGED = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "ragged_*.npz")))
+
+
+def _ragged_calls(g, fmsig):
+    p = fmsig.default_params(float(g["fs"]), noise_sigma=float(g["noise"]), seed=int(g["seed"]))
+    start = 0
+    for k, n in enumerate(int(x) for x in g["sizes"]):
+        u8 = fmsig.generate_u8(p, start, n)
+        start += n
+        assert sha(u8) == str(g["iq_sha256"][k]), "generator drift in call %d" % k
+        yield k, n, fmsig.u8_to_f32(u8)
+
+
+@pytest.mark.parametrize("path", RAGGED, ids=[os.path.basename(f) for f in RAGGED])
+def test_oracle_reproduces_ragged_golden(path, oracle, fmsig):
+    """Call sequences through the short-block regimes (half-band stages below L and below 2 (L - 1)
+    inputs, blocks shorter than a filter's history), the 11-tap first stage and a 4096-tap IF filter."""
+    g = np.load(path)
+    fs, D, order = float(g["fs"]), int(g["D"]), int(g["order"])
+    dec = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D, if_filter_order=order)
+    assert dec.rds_hb_lengths() == [int(x) for x in g["rds_hb_lengths"]]
+    for k, n, iq in _ragged_calls(g, fmsig):
+        audio = dec.process_stream(iq)
+        assert audio.size == int(g["audio_counts"][k]), (k, n)
+        assert sha(audio) == str(g["audio_sha256"][k]), "oracle drift in call %d (%d samples)" % (k, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", RAGGED, ids=[os.path.basename(f) for f in RAGGED])
+def test_hip_path_reproduces_ragged_golden(path, fmsig):
+    pkg = load_package()
+    g = np.load(path)
+    fs, D, order = float(g["fs"]), int(g["D"]), int(g["order"])
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D, if_filter_order=order), 1)
+    for k, n, iq in _ragged_calls(g, fmsig):
+        audio = b.process_host(iq.view(np.complex64), shared=True)[0]
+        assert audio.size == int(g["audio_counts"][k]), (k, n)
+        assert sha(audio) == str(g["audio_sha256"][k]), "call %d (%d samples) differs from the oracle" % (k, n)
+    st, ref = b.status(), g["status"]
+    assert st.stereo_detected == int(ref[0]) and st.rds_state == int(ref[5])
+    assert np.float32(st.pilot_level) == ref[4] and np.float32(st.interface_level) == ref[2]
+    b.close()

@@ -65,6 +65,43 @@ def make(name, fs, D, nblk, noise, keep):
     print(name, os.path.getsize(path), "bytes,", len(g), "groups,", len(frames), "frames")
 
 
+# Sequences of calls of very different sizes: the short-block regimes of the half-band chain (fewer
+# than L / than 2 (L - 1) inputs per stage), blocks shorter than a filter's history, the 11-tap first
+# stage (baseband rate >= 320 kHz), a long IF filter.  One sha256 per call.
+RAGGED = {
+    "ragged_2p4M": dict(fs=2.4e6, D=11, order=0,
+                        sizes=[65536, 88, 89, 100, 150, 170, 171, 200, 330, 500, 1000, 1900, 65536, 3000, 3662,
+                               3663, 160, 5000, 88, 97, 8191, 640, 2222, 65536, 310, 320, 460, 470, 930, 940]),
+    "ragged_hb11_400k": dict(fs=400e3, D=1, order=0,
+                             sizes=[32000, 20, 21, 64, 500, 33, 2000, 32001, 25, 20000, 8193]),
+    "ragged_longfir_10M": dict(fs=10e6, D=46, order=4096, sizes=[65536, 2000, 3000, 4095, 4097, 1000, 40000, 700]),
+}
+
+
+def make_ragged(name, fs, D, order, sizes):
+    p = fmsig_py.default_params(fs, noise_sigma=0.01, seed=13)
+    dec = oracle_py.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D, if_filter_order=order)
+    iq_hash, audio_hash, counts = [], [], []
+    start = 0
+    for n in sizes:
+        u8 = fmsig_py.generate_u8(p, start, n)
+        start += n
+        iq_hash.append(sha(u8))
+        audio = dec.process_stream(fmsig_py.u8_to_f32(u8))
+        audio_hash.append(sha(audio))
+        counts.append(audio.size)
+    st = dec.status()
+    out = {"fs": fs, "D": D, "order": order, "seed": 13, "noise": 0.01, "sizes": np.array(sizes, dtype=np.int32),
+           "iq_sha256": np.array(iq_hash), "audio_sha256": np.array(audio_hash),
+           "audio_counts": np.array(counts, dtype=np.int32),
+           "rds_hb_lengths": np.array(dec.rds_hb_lengths(), dtype=np.int32),
+           "status": np.array([st.stereo, st.tuning_offset, st.if_level, st.baseband_level, st.pilot_level,
+                               st.rds_state], dtype=np.float32)}
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, os.path.getsize(path), "bytes,", len(sizes), "calls")
+
+
 def receiver_session(rx, fmsig, p, nblk, u8=False, ahead=2):
     """One demux session written like the reference's two threads run: the source keeps `ahead`
     blocks queued, the demuxer pulls packets until the source ends.  Returns the packet list and
@@ -163,5 +200,7 @@ def make_design(name="design_g1"):
 if __name__ == "__main__":
     for name, kw in CASES.items():
         make(name, **kw)
+    for name, kw in RAGGED.items():
+        make_ragged(name, **kw)
     make_receiver()
     make_design()
