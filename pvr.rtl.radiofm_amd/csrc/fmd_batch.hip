@@ -279,6 +279,17 @@ void bind_state(fmd_batch* b)
   b->st.spin_limit = getenv("FMD_DEBUG_SPIN_LIMIT") ? unsigned(atoi(getenv("FMD_DEBUG_SPIN_LIMIT"))) : (1u << 20);
 }
 
+/* A step that cannot report through its return value (stream bookkeeping inside a launch helper)
+ * failed: the batch refuses further calls (see check_device_errors). */
+void mark_failed(fmd_batch* b, const char* what)
+{
+  if (!b->failed)
+  {
+    b->failed = true;
+    b->fail_msg = what;
+  }
+}
+
 /* Turns the device-side error word, and an earlier broken-off call, into an error code. */
 int check_device_errors(fmd_batch* b)
 {
@@ -834,7 +845,7 @@ void queue_is_free(fmd_batch* b, int es, hipStream_t s)
   if (b->drained_pending[es])
   {
     if (hipStreamWaitEvent(s, b->ev_drained[es], 0) != hipSuccess)
-      b->failed = true, b->fail_msg = "hipStreamWaitEvent failed in front of an RDS queue";
+      mark_failed(b, "hipStreamWaitEvent failed in front of an RDS queue");
     b->drained_pending[es] = false;
   }
 }
@@ -879,7 +890,7 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
                        b->tap_sync.p, b->write_taps);
   }
   if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_RDS], s) != hipSuccess)
-    b->failed = true, b->fail_msg = "hipEventRecord failed behind the RDS part of a call";
+    mark_failed(b, "hipEventRecord failed behind the RDS part of a call");
   {
     fmd::AudioConsts k{};
     k.de_alpha = d.de_alpha;
@@ -892,7 +903,7 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
                        b->st, j.d_audio, j.audio_stride, unsigned(j.sq));
   }
   if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_AUD], s) != hipSuccess)
-    b->failed = true, b->fail_msg = "hipEventRecord failed behind the audio tail of a call";
+    mark_failed(b, "hipEventRecord failed behind the audio tail of a call");
 }
 
 /* Submits a kept-back light part now (its results are wanted, or the batch changes mode). */
@@ -903,7 +914,7 @@ void flush_light(fmd_batch* b)
   const fmd_batch::LightJob j = b->light_job;
   b->light_job.pending = false;
   if (hipStreamWaitEvent(b->s_rds, b->cev[j.es][fmd_batch::EV_HEAVY], 0) != hipSuccess)
-    b->failed = true, b->fail_msg = "hipStreamWaitEvent failed in front of the light part of a call";
+    mark_failed(b, "hipStreamWaitEvent failed in front of the light part of a call");
   launch_light(b, j, b->s_rds, true);
 }
 
