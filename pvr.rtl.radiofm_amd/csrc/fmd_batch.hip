@@ -623,16 +623,19 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     // post chain has slack every call and goes last
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi)); // lo = least, hi = greatest priority
+    // FMD_HEAVY_PAR=1 (measured slower, off by default) needs a fifth stream; without it none is
+    // created: every extra stream competes for the few hardware queues (GPU_MAX_HW_QUEUES)
+    b->heavy_par = getenv("FMD_HEAVY_PAR") ? atoi(getenv("FMD_HEAVY_PAR")) != 0 : false;
+    const int nstreams = b->heavy_par ? 5 : 4;
     const int prio[5] = {hi, hi, lo, lo, lo};
     hipStream_t st4[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (pick_independent_streams(5, prio, st4) != 0)
+    if (pick_independent_streams(nstreams, prio, st4) != 0)
       return fail(FMD_ERR_DEVICE, "could not create the internal streams");
     b->s_fir = st4[0];
     b->s_ser = st4[1];
     b->s_post = st4[2];
     b->s_rds = st4[3];
     b->s_aud = st4[4];
-    b->heavy_par = getenv("FMD_HEAVY_PAR") ? atoi(getenv("FMD_HEAVY_PAR")) != 0 : false;
     // RDS chain and audio chain behind the serial stage are independent.  With more channels than
     // the chip holds serial-stage workgroups (256 CUs x 64 channels) the batch is throughput-bound
     // and they run side by side on two streams (+10 % at 24 576, +12 % at 32 768 channels); below
