@@ -603,6 +603,13 @@ def main():
                                                     "are inside the overlapped pipeline"}
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(if_filter_order=order)
+        # RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would
+        # otherwise come out at exit, behind the JSON line: flush it first so that the line is the last one
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()
