@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- IQ MS/s demodulated by the MI355X FM decoder, whole job, with the FIR-stage roofline.
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python bench.py --gpus N --steps K --warmup W          (any N: with N > 1 and no WORLD_SIZE in the
+                                                            environment it starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[3], per-GPU shard): 8192 independent synthetic FM stereo+RDS
@@ -109,6 +110,55 @@ def cpu_baseline(seconds=6.0, if_filter_order=0):
                       % (threads, FS / 1e6, calls, worst, one_calls, one_s)}
 
 
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher: this process becomes the launcher.  It has
+    not imported torch and has not touched HIP (a process that has must never exec or fork workers on
+    this pool); it starts N children of this same script, one per GPU, with the rendezvous variables
+    torch.distributed.run would set, passes rank 0's stdout through (its JSON line stays the last line
+    of stdout; the other ranks' stdout goes to stderr) and exits with the worst child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    base = {k: v for k, v in os.environ.items()}
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=str(port), FMD_BENCH_SPAWNED="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0", ROLE_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=None))
+    import threading
+    chunks = []
+    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    # a rank that dies leaves its peers inside a rendezvous or a collective: give them a grace period,
+    # then end exactly the processes started here
+    deadline = None
+    while any(p.poll() is None for p in procs):
+        if deadline is None and any(p.poll() not in (None, 0) for p in procs):
+            deadline = time.time() + 20.0
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    rcs = [p.wait() for p in procs]
+    rd.join(timeout=10.0)
+    out0 = b"".join(c for c in chunks if c)
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %r\n" % (bad,))
+        # a signal's negative code would wrap around: report it as a plain failure
+        raise SystemExit(max(rc if rc > 0 else 1 for _, rc in bad))
+    raise SystemExit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +198,10 @@ def main():
                     help="seconds after which a run that has not finished kills itself (a hung "
                          "collective or kernel must not keep the box busy)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _spawn_ranks(args.gpus)  # does not return
 
     import threading
 
@@ -169,7 +223,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)"
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (either let bench.py start its own ranks: no "
+                         "WORLD_SIZE in the environment, or launch it with torch.distributed.run)"
                          % (args.gpus, world))
     if os.environ.get("FMD_BENCH_SHARE_GPU") == "1":
         local_rank = 0  # development aid, see below
@@ -271,6 +326,7 @@ def main():
     group_acc = torch.zeros((), dtype=torch.int64, device=dev)  # groups counted on the device
     stream = torch.cuda.current_stream().cuda_stream
     pending = [None] * NBUF
+    gather_events = []  # (start, stop) on the side stream around every step's gather calls
     total_groups = 0
 
     batch.set_concurrency(args.concurrency)  # 2: FIR of step i+1 overlaps the serial stages of step i
@@ -298,9 +354,14 @@ def main():
             if backend == "nccl":
                 with torch.cuda.stream(comm_stream):
                     comm_stream.wait_event(ev)
+                    g0 = torch.cuda.Event(enable_timing=True)
+                    g0.record(comm_stream)
                     # blocking for the side stream only: the host does not wait
                     dg.gather_step(audio[slot], rds_dev[slot], g_audio[slot] if rank == 0 else None,
                                    g_rds[slot] if rank == 0 else None, dst=0, async_op=False)
+                    g1 = torch.cuda.Event(enable_timing=True)
+                    g1.record(comm_stream)
+                    gather_events.append((g0, g1))  # the two gather calls alone, on the side stream
                     if rank == 0:
                         for r in range(world):
                             group_acc.add_((g_rds[slot][r][:, 0] != 0).sum())
@@ -308,11 +369,13 @@ def main():
                     done.record(comm_stream)
                 pending[slot] = done
             else:  # host-staged over gloo (development aid: several ranks on one GPU)
+                tg0 = time.perf_counter()
                 ev.synchronize()
                 a_h, r_h = audio[slot].cpu(), rds_dev[slot].cpu()
                 w = dg.gather_step(a_h, r_h, g_audio[slot] if rank == 0 else None,
                                    g_rds[slot] if rank == 0 else None, dst=0, async_op=True)
                 pending[slot] = list(w)
+                host_t["gather_host"] = host_t.get("gather_host", 0.0) + (time.perf_counter() - tg0)
         elif use_export:  # one rank, --verify: "gathered" = this rank's own outputs
             g_audio[slot][0].copy_(audio[slot], non_blocking=True)
             g_rds[slot][0].copy_(rds_dev[slot], non_blocking=True)
@@ -362,6 +425,9 @@ def main():
         return nf
 
     def drain():
+        # nothing more is coming: the newest call's kept-back light part goes out now, not when the
+        # loop below reaches it (the device would idle through the two synchronisations before it)
+        batch.flush()
         # the last LAG calls one by one, so that every call's groups land in its own record buffer
         while state["finalized"] < state["submitted"]:
             lag = state["submitted"] - (state["finalized"] + 1)
@@ -453,7 +519,8 @@ def main():
     for i in range(base, base + W):
         step(i)
     drain()
-    host_t["process"] = host_t["collect"] = host_t["wait"] = 0.0
+    host_t["process"] = host_t["collect"] = host_t["wait"] = host_t["gather_host"] = 0.0
+    gather_events.clear()
     batch.set_profiling(1)  # HIP events around the IF FIR kernel of every timed call
     total_groups = 0
     group_acc.zero_()
@@ -511,10 +578,28 @@ def main():
         t00 = serial_probe[0]["start"] if serial_probe else 0
         for r in serial_probe:
             r["start"] = round((r["start"] - t00) / 100.0, 1)
+    dt_own = dt
     if dist_on:
         dt = reduce_scalar(dt, dist.ReduceOp.MAX)
     stage, calls = batch.stage_ms()
     fir_ms = stage["if_fir"]
+    # what makes an N > 1 run explain itself: every rank's own time per step and FIR time, and what the
+    # gather costs on the side stream (on rank 0: receiving from every peer; elsewhere: sending)
+    gather_ms = None
+    if gather_events:
+        torch.cuda.synchronize()
+        gather_ms = sum(a.elapsed_time(b) for a, b in gather_events) / len(gather_events)
+    elif host_t.get("gather_host"):
+        gather_ms = host_t["gather_host"] / K * 1e3
+    per_rank = None
+    if dist_on:
+        mine = torch.tensor([dt_own / K * 1e3, fir_ms, -1.0 if gather_ms is None else gather_ms],
+                            dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "ms_per_step": round(float(t[0]), 4), "if_fir_ms": round(float(t[1]), 4),
+                     "gather_ms_per_step": None if float(t[2]) < 0 else round(float(t[2]), 4)}
+                    for r, t in enumerate(allr)]
     host_ms = {k: v / K * 1e3 for k, v in host_t.items()}  # the timed region's, before the extra steps
 
     # after the timed region: four more steps with the stages one after the other on one stream and
@@ -579,15 +664,26 @@ def main():
         }
         # HBM bytes per launch from the PMC counters of the committed profile (same workload only;
         # PMC needs its own rocprofv3 passes, it cannot be collected inside this run)
+        # the file is keyed by the kernel form: two tiles per workgroup (k_if_fir_mt) is what runs when
+        # calls overlap beside the whole-CU serial stage, one tile (k_if_fir) otherwise
+        form = "k_if_fir_mt" if (args.concurrency == 2 and 1024 <= (C + 63) // 64 * 64 <= 8192
+                                 and args.workload == "config4" and args.fir_reduction == 0) else "k_if_fir"
+        out["roofline"]["kernel"] = ("%s (cFineTuner + cDownsampleFilter complex%s)"
+                                     % (form, ", ReadAsyncCB byte conversion" if u8 else ""))
         tpath = os.path.join(ROOT, "profiles", "traffic_k_if_fir.json")
         if os.path.exists(tpath):
-            t = json.load(open(tpath))
-            if (args.workload == "config4" and not u8 and t.get("channels") == C
+            t = json.load(open(tpath)).get(form)
+            if (t and args.workload == "config4" and not u8 and t.get("channels") == C
                     and t.get("samples_per_call") == N):
                 out["roofline"]["traffic"] = t["bytes_per_launch"]
                 out["roofline"]["traffic_source"] = t["source"]
         if verify is not None:
             out["verify"] = verify
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+            out["per_rank_note"] = ("ms_per_step: each rank's own clock around the timed region (value uses "
+                                    "the max); gather_ms_per_step: the two gather calls of a step on the "
+                                    "side stream (device events; host time of the staging copies with gloo)")
         if serial_probe is not None:
             out["serial_probe_last_8_launches"] = serial_probe
         if stage_all:

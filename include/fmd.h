@@ -28,6 +28,12 @@ extern "C" {
 #define FMD_ERR_DEVICE (-2)  /* HIP runtime error or no usable device */
 #define FMD_ERR_SIZE (-3)    /* samples outside [fmd_batch_min_samples(), FMD_MAX_BLOCK] */
 #define FMD_ERR_STATE (-4)
+/* Not an error (positive): RDS groups were lost since the last report -- a call's group queue or the
+ * record buffer of fmd_batch_export_rds_device was full.  Audio and channel state are intact and the
+ * batch stays usable.  Returned once by fmd_batch_wait[_lagged] / fmd_batch_export_rds_device (or
+ * queried with fmd_batch_take_rds_lost), then cleared.  The reference has no such condition: its
+ * group decoder runs inside ProcessStream (RDSProcess.cpp:312,355), nothing is ever queued. */
+#define FMD_WARN_RDS_LOST 1
 
 /* cRtlSdrSource::default_block_length (RTL_SDR_Source.h:25): the reference's internal buffers
  * are hard-sized to it (FmDecode.cpp:277-282), so samples <= 65536 is its precondition too. */
@@ -143,7 +149,10 @@ unsigned fmd_batch_max_audio_floats(const fmd_batch* b, unsigned samples);
  *  d_audio         channel c's interleaved L/R floats at d_audio + c*audio_channel_stride.
  *  out_floats      (host, optional) floats written per channel -- the same for every
  *                  channel of a batch, known when the call returns.
- * RDS groups produced by the call stay queued on the device until fmd_batch_collect_rds. */
+ * RDS groups produced by the call stay queued on the device until fmd_batch_collect_rds /
+ * fmd_batch_export_rds_device drains them.  A call appends to one of 8 queues in rotation (call index
+ * mod 8), each holding max(4096, 8 x channels) groups; a caller that never drains loses the groups
+ * beyond that (FMD_WARN_RDS_LOST) and nothing else. */
 int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_stride,
                              unsigned samples, float* d_audio, size_t audio_channel_stride,
                              unsigned* out_floats, void* stream);
@@ -181,9 +190,10 @@ int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap,
  * d_records (device memory, 16-byte aligned, cap rows of 4 x int32: channel + 1 + channel_offset,
  * call_index, blocks[0] | blocks[1] << 16, blocks[2] | blocks[3] << 16; rows beyond the groups found
  * are zero, so a fixed-size message can be sent as is) by a kernel on `stream`, and those queues
- * are emptied.  Asynchronous; rows are in no particular order.  More groups than `cap` rows is a
- * device-side error (reported by the next wait / collect / process call).  Use either this or
- * fmd_batch_collect_rds on a batch, not both for the same calls. */
+ * are emptied.  Asynchronous; rows are in no particular order.  More groups than `cap` rows: the
+ * surplus is lost and FMD_WARN_RDS_LOST is reported once (by a later wait / export call); the batch
+ * stays usable.  Use either this or fmd_batch_collect_rds on a batch, not both for the same calls.
+ * One stream at a time: concurrent exports of one batch on different streams are not supported. */
 int fmd_batch_export_rds_device(fmd_batch* b, int32_t* d_records, unsigned cap, unsigned channel_offset,
                                 int lag, void* stream);
 
@@ -205,8 +215,24 @@ int fmd_batch_wait(fmd_batch* b, void* stream);
  * light tail of a call's post chain finishes beside the FIR of the call after next, so a host that
  * must never block consumes outputs three calls late). */
 int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream);
+/* Concurrency 2: submits the kept-back tail of the newest call now (nothing is waited for).  For the
+ * moment a caller knows that no further call follows soon; wait / collect with lag 0 do the same. */
+int fmd_batch_flush(fmd_batch* b);
+/* 1 if RDS groups were lost since the last report (see FMD_WARN_RDS_LOST; clears the flag), else 0. */
+int fmd_batch_take_rds_lost(fmd_batch* b);
 
+/* The getters of cFmDecoder for one channel (FmDecode.h:140-165).  They return the status the
+ * newest COMPLETED call left behind (all zero before the first call; Reset zeroes what
+ * cFmDecoder::Reset zeroes): the last kernel of every call writes a small record per channel into
+ * host-mapped memory, and the getters only read that record -- no device synchronisation, no stream
+ * operation, nothing of the batch is modified.  They may be called from any thread at any time,
+ * also while another thread is inside a process call on the same batch (Kodi's status thread does
+ * that: RadioReceiver.cpp:544-572 against :524).  A record is always one call's values, never a mix
+ * of two writes.  With overlapped calls (concurrency 2) the interface / baseband meters in it may
+ * already include the following call. */
 int fmd_batch_get_status(fmd_batch* b, unsigned channel, fmd_status* st);
+/* index (1-based) of the call whose status the getters return at this moment, 0 = none yet */
+int fmd_batch_status_call_index(fmd_batch* b, unsigned channel, uint32_t* call_index);
 
 /* cRadioReceiver's audio level meter over the audio a call produced (RadioReceiver.cpp:526-528,
  * SamplesMeanRMS :584-598): float sums over the interleaved samples of the packet, then
@@ -265,7 +291,8 @@ const char* fmd_stage_name(unsigned idx);
 /* Test aid: evaluates the device build of one math helper of csrc/fmd_math.h on n arguments
  * (host arrays).  what: 0 atan2f table form (a = y, b = x), 1 atan2f literal fdlibm, 2 sin/cos
  * table form (a = phase; out0 = sin, out1 = cos), 3 sin/cos series form, 4 mid-range division
- * a / b, 5 RTL-SDR byte -> float (a = byte value), 6 the RDS PLL's polynomial arctan2. */
+ * a / b, 5 RTL-SDR byte -> float (a = byte value), 6 the RDS PLL's polynomial arctan2, 7 sin/cos of a
+ * phase in [0, 8) with the exact float reduction (the serial stage's two NCOs). */
 int fmd_debug_math(int what, unsigned n, const float* a, const float* b, float* out0, float* out1);
 
 /* Dev aid, only with FMD_SERIAL_PROBE=1 in the environment at batch creation: per workgroup of the
@@ -274,6 +301,9 @@ int fmd_debug_math(int what, unsigned n, const float* a, const float* b, float* 
  * records of workgroups that did not exist stay zero.  Returns the number of records written (0
  * when the probe is off).  Synchronises the device. */
 int fmd_batch_debug_serial_probe(fmd_batch* b, long long* out, unsigned cap_workgroups);
+/* Test aid: bound (in polls) of the serial stage's LDS hand-off waits for the calls that follow;
+ * 0 makes every wait time out at once, which exercises the device-side error path. */
+int fmd_batch_debug_set_spin_limit(fmd_batch* b, unsigned limit);
 
 const char* fmd_last_error(void);
 const char* fmd_version(void);

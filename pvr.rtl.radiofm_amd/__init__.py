@@ -19,6 +19,7 @@ _LIB = None
 
 FMD_MAX_BLOCK = 65536
 FMD_MIN_BLOCK = 8192
+FMD_WARN_RDS_LOST = 1
 
 TAPS = {"demod": 0, "baseband": 1, "pilot38": 2, "mono_rs": 3, "stereo_rs": 4, "rds_lpf": 5,
         "rds_pll": 6, "rds_mf": 7, "rds_sync": 8}
@@ -110,6 +111,8 @@ EXPORTS = [
     "fmd_batch_set_debug_taps", "fmd_batch_set_profiling", "fmd_batch_get_stage_ms", "fmd_stage_name", "fmd_last_error",
     "fmd_version", "fmd_group_decoder_create", "fmd_group_decoder_destroy",
     "fmd_group_decoder_reset", "fmd_group_decoder_push", "fmd_uecp_stuff_frame",
+    "fmd_batch_flush", "fmd_batch_take_rds_lost", "fmd_batch_status_call_index",
+    "fmd_batch_debug_set_spin_limit",
 ]
 
 
@@ -194,6 +197,10 @@ def lib():
         L.fmd_group_decoder_reset.argtypes = [vp]
         L.fmd_group_decoder_push.argtypes = [vp, vp]
         L.fmd_uecp_stuff_frame.argtypes = [vp, u, vp, u]
+        L.fmd_batch_flush.argtypes = [vp]
+        L.fmd_batch_take_rds_lost.argtypes = [vp]
+        L.fmd_batch_status_call_index.argtypes = [vp, u, C.POINTER(C.c_uint32)]
+        L.fmd_batch_debug_set_spin_limit.argtypes = [vp, u]
         _LIB = L
     return _LIB
 
@@ -332,15 +339,32 @@ class Batch:
 
     def export_rds_device(self, d_records_ptr, cap, channel_offset=0, stream=None, lag=0):
         """Queued RDS groups of calls at least `lag` old -> [cap, 4] int32 rows in device memory
-        (fmd_batch_export_rds_device), asynchronously on `stream`."""
-        _check(lib().fmd_batch_export_rds_device(self._h, d_records_ptr, cap, channel_offset, lag,
-                                                 stream))
+        (fmd_batch_export_rds_device), asynchronously on `stream`.  True: groups were lost."""
+        return _check(lib().fmd_batch_export_rds_device(self._h, d_records_ptr, cap, channel_offset, lag,
+                                                        stream)) == FMD_WARN_RDS_LOST
 
     def set_concurrency(self, mode):
         _check(lib().fmd_batch_set_concurrency(self._h, int(mode)))
 
     def wait(self, stream=None, lag=0):
-        _check(lib().fmd_batch_wait_lagged(self._h, lag, stream))
+        """Returns True when RDS groups were lost since the last report (FMD_WARN_RDS_LOST)."""
+        return _check(lib().fmd_batch_wait_lagged(self._h, lag, stream)) == FMD_WARN_RDS_LOST
+
+    def flush(self):
+        """Concurrency 2: submit the kept-back tail of the newest call now (fmd_batch_flush)."""
+        _check(lib().fmd_batch_flush(self._h))
+
+    def take_rds_lost(self):
+        return bool(_check(lib().fmd_batch_take_rds_lost(self._h)))
+
+    def status_call_index(self, channel=0):
+        """Index of the call whose status the getters return right now (0 = none yet)."""
+        ci = C.c_uint32()
+        _check(lib().fmd_batch_status_call_index(self._h, channel, C.byref(ci)))
+        return ci.value
+
+    def debug_set_spin_limit(self, limit):
+        _check(lib().fmd_batch_debug_set_spin_limit(self._h, limit))
 
     def status(self, channel=0):
         st = FmdStatus()

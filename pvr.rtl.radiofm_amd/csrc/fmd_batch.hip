@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -114,7 +115,7 @@ struct fmd_batch
   std::vector<DevBuf<float2>> hbbuf; // input buffers of stages 1..n-1 (stage 0 reads mix)
   DevBuf<float> if_coeff, rs_coeff, rds_lpf_taps, mf_taps2, audio_taps, ktab;
   DevBuf<float> rpll, rmf, tap_sync;
-  DevBuf<double> sctab;
+  DevBuf<double> sctab, sctab256; // fmd_sincos_tab / fmd_sincos_p256 (the serial stage's two NCOs)
   DevBuf<int> pidx;
   float2* brp(int q) const { return br[q].p + size_t(2 * fmd::RS_B) * CP; } // row 0 of br[q]
   unsigned rs_margin = 0, rs_row = 0; // ktab: zero entries around each output's taps, row length
@@ -124,7 +125,16 @@ struct fmd_batch
   DevBuf<uint16_t> r_data;
   static constexpr int NSLOT = 8; // event sets / RDS queues in rotation (call_index % NSLOT)
   DevBuf<fmd::RdsGroupRec> queue[NSLOT]; // never drained while a call that appends to it is in flight
-  DevBuf<unsigned> queue_count[NSLOT];
+  DevBuf<unsigned> queue_counts; // [NSLOT], contiguous: one copy reads them all
+  unsigned* qcount(int q) const { return queue_counts.p + q; }
+  // call whose groups were last taken out of the slot's queue (collect / export): a slot is not
+  // visited again before a newer call has used it
+  uint32_t drained_call[NSLOT] = {};
+  // page-locked staging of fmd_batch_collect_rds: the counts and the records arrive by DMA, no
+  // staging kernel, two synchronisations per collect
+  unsigned* h_counts = nullptr;
+  fmd::RdsGroupRec* h_recs = nullptr;
+  size_t h_recs_cap = 0;
   unsigned queue_cap = 0;
   // fmd_batch_export_rds_device drains a queue asynchronously on the caller's stream: the event tells
   // the next call that appends to the same queue (NSLOT calls later) when it is empty
@@ -185,9 +195,15 @@ struct fmd_batch
   // reads it without a copy or a synchronisation.  `failed`: a call broke off after its first launch
   // or a kernel reported an error -- the channel state is no longer trustworthy, every later call is
   // refused until fmd_batch_reset / destroy.
-  unsigned* h_err = nullptr;
+  unsigned* h_err = nullptr; // [0] fatal bits, [1] recoverable ones (groups lost), see fmd::DevErr
   bool failed = false;
   std::string fail_msg;
+  unsigned spin_limit = 1u << 20; // fmd_batch_debug_set_spin_limit
+  // Status snapshot in host-mapped memory, written by the last kernel of every call
+  // (fmd::HostStatusWord): what the getters read -- no device call, no batch bookkeeping touched,
+  // so they are safe from any thread while another one is inside a process call.
+  unsigned* h_status = nullptr;
+  unsigned host_seq = 0; // tags of snapshot updates made by the host (create, reset)
 
   ~fmd_batch()
   {
@@ -220,6 +236,7 @@ struct fmd_batch
     rmf.release();
     tap_sync.release();
     sctab.release();
+    sctab256.release();
     pidx.release();
     serial_probe.release();
     fstate.release();
@@ -228,11 +245,15 @@ struct fmd_batch
     for (int q = 0; q < NSLOT; q++)
     {
       queue[q].release();
-      queue_count[q].release();
       if (ev_drained[q])
         (void)hipEventDestroy(ev_drained[q]);
     }
     export_cursor.release();
+    queue_counts.release();
+    if (h_counts)
+      (void)hipHostFree(h_counts);
+    if (h_recs)
+      (void)hipHostFree(h_recs);
     if (cev_ready)
     {
       for (auto& row : cev)
@@ -250,6 +271,8 @@ struct fmd_batch
     h_audio.release();
     if (h_err)
       (void)hipHostFree(h_err);
+    if (h_status)
+      (void)hipHostFree(h_status);
     for (auto& e : ev)
       (void)hipEventDestroy(e);
   }
@@ -274,9 +297,50 @@ void bind_state(fmd_batch* b)
   void* derr = nullptr;
   if (b->h_err && hipHostGetDevicePointer(&derr, b->h_err, 0) == hipSuccess)
     b->st.err = static_cast<unsigned*>(derr);
-  // bound of the serial stage's LDS hand-off waits (~0.1 s); FMD_DEBUG_SPIN_LIMIT=0 makes every wait
-  // time out at once (test knob for the error path)
-  b->st.spin_limit = getenv("FMD_DEBUG_SPIN_LIMIT") ? unsigned(atoi(getenv("FMD_DEBUG_SPIN_LIMIT"))) : (1u << 20);
+  void* dhs = nullptr;
+  if (b->h_status && hipHostGetDevicePointer(&dhs, b->h_status, 0) == hipSuccess)
+    b->st.hs = static_cast<unsigned*>(dhs);
+  // bound of the serial stage's LDS hand-off waits (~0.1 s; fmd_batch_debug_set_spin_limit)
+  b->st.spin_limit = b->spin_limit;
+}
+
+/* The host's own updates of the status snapshot (initial values, Reset): same protocol as the
+ * kernel's (fmd::HostStatusWord), with tags no call index ever has.  Only called while no call is in
+ * flight. */
+void host_status_update(fmd_batch* b, const std::function<void(unsigned* rec, size_t stride)>& edit)
+{
+  const size_t CP = b->CP;
+  const unsigned tag = 0x80000000u | ++b->host_seq;
+  for (unsigned c = 0; c < b->C; c++)
+  {
+    unsigned* h = b->h_status + c;
+    __atomic_store_n(&h[fmd::HS_SEQ_BEGIN * CP], tag, __ATOMIC_RELEASE);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    edit(h, CP);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    __atomic_store_n(&h[fmd::HS_SEQ_END * CP], tag, __ATOMIC_RELEASE);
+  }
+}
+
+/* One channel's snapshot, consistent (taken between two equal sequence words). */
+bool host_status_read(const fmd_batch* b, unsigned channel, unsigned out[fmd::HS_WORDS])
+{
+  const size_t CP = b->CP;
+  const unsigned* h = b->h_status + channel;
+  for (int tries = 0; tries < 100000; tries++)
+  {
+    const unsigned e = __atomic_load_n(&h[fmd::HS_SEQ_END * CP], __ATOMIC_ACQUIRE);
+    for (int w = fmd::HS_SEQ_BEGIN + 1; w < fmd::HS_SEQ_END; w++)
+      out[w] = __atomic_load_n(&h[size_t(w) * CP], __ATOMIC_RELAXED);
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const unsigned g = __atomic_load_n(&h[fmd::HS_SEQ_BEGIN * CP], __ATOMIC_ACQUIRE);
+    if (e == g)
+    {
+      out[fmd::HS_SEQ_BEGIN] = out[fmd::HS_SEQ_END] = e;
+      return true;
+    }
+  }
+  return false; // a writer that never finishes: only a hung device
 }
 
 /* A step that cannot report through its return value (stream bookkeeping inside a launch helper)
@@ -293,19 +357,30 @@ void mark_failed(fmd_batch* b, const char* what)
 /* Turns the device-side error word, and an earlier broken-off call, into an error code. */
 int check_device_errors(fmd_batch* b)
 {
-  const unsigned e = b->h_err ? __atomic_load_n(b->h_err, __ATOMIC_ACQUIRE) : 0u;
+  const unsigned e = b->h_err ? __atomic_load_n(&b->h_err[0], __ATOMIC_ACQUIRE) : 0u;
   if (e && !b->failed)
   {
     b->failed = true;
     b->fail_msg = "device-side error:";
     if (e & fmd::DEVERR_SERIAL_HANDSHAKE)
       b->fail_msg += " serial stage hand-off timed out (results of that call are invalid)";
-    if (e & fmd::DEVERR_RDS_QUEUE_FULL)
-      b->fail_msg += " RDS group queue overflowed (groups lost; collect more often)";
   }
   if (b->failed)
     return fail(FMD_ERR_DEVICE, b->fail_msg);
   return FMD_OK;
+}
+
+/* RDS groups that did not fit a queue or the caller's record buffer are lost, nothing else: audio and
+ * channel state are intact and the batch stays usable.  Reported once (FMD_WARN_RDS_LOST), then
+ * cleared; a kernel setting the flag again at the same moment is seen by the next query. */
+int take_lost_groups(fmd_batch* b)
+{
+  if (!b->h_err || !__atomic_load_n(&b->h_err[1], __ATOMIC_ACQUIRE))
+    return FMD_OK;
+  __atomic_store_n(&b->h_err[1], 0u, __ATOMIC_RELEASE);
+  g_err = "RDS groups were lost: a call's group queue or the export buffer was full (drain every call's "
+          "groups with fmd_batch_collect_rds / fmd_batch_export_rds_device, with cap >= the groups queued)";
+  return FMD_WARN_RDS_LOST;
 }
 
 /* state a freshly constructed cFmDecoder has (ctor values that are not zero) */
@@ -359,9 +434,19 @@ int do_reset(fmd_batch* b)
     if (g)
       g->reset();
   if (b->h_err)
-    __atomic_store_n(b->h_err, 0u, __ATOMIC_RELEASE);
+  {
+    __atomic_store_n(&b->h_err[0], 0u, __ATOMIC_RELEASE);
+    __atomic_store_n(&b->h_err[1], 0u, __ATOMIC_RELEASE);
+  }
   b->failed = false;
   b->fail_msg.clear();
+  // the getters' snapshot follows: the meters Reset clears (FmDecode.cpp:326-338) read zero, pilot
+  // level and the receiver's audio meter stay
+  if (b->h_status)
+    host_status_update(b, [](unsigned* h, size_t CP) {
+      for (int w : {fmd::HS_IF_LEVEL, fmd::HS_BB_MEAN, fmd::HS_BB_LEVEL, fmd::HS_STEREO, fmd::HS_R_STATE})
+        __atomic_store_n(&h[size_t(w) * CP], 0u, __ATOMIC_RELAXED);
+    });
   return 0;
 }
 
@@ -577,15 +662,16 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   if (getenv("FMD_SERIAL_PROBE") && atoi(getenv("FMD_SERIAL_PROBE")))
     bad |= b->serial_probe.alloc(size_t(8) * 3 * (b->CP / 64)); // the last 8 launches
   bad |= b->sctab.alloc(d.sincos_tab.size());
+  bad |= b->sctab256.alloc(d.sincos_tab256.size());
   bad |= b->fstate.alloc(size_t(fmd::F_SLOTS) * CP);
   bad |= b->istate.alloc(size_t(fmd::I_SLOTS) * CP);
   bad |= b->r_data.alloc(size_t(4) * CP);
   b->queue_cap = std::max(4096u, 8u * C);
   for (int q = 0; q < fmd_batch::NSLOT; q++)
-  {
     bad |= b->queue[q].alloc(b->queue_cap);
-    bad |= b->queue_count[q].alloc(1);
-  }
+  bad |= b->queue_counts.alloc(fmd_batch::NSLOT);
+  bad |= hipHostMalloc(reinterpret_cast<void**>(&b->h_counts), fmd_batch::NSLOT * sizeof(unsigned),
+                       hipHostMallocDefault) != hipSuccess;
   bad |= b->export_cursor.alloc(1);
   if (bad)
     return fail(FMD_ERR_DEVICE, std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError()));
@@ -596,6 +682,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= upload(b->rds_lpf_taps.p, d.rds_lpf_taps.data(), T_lpf * sizeof(float));
   bad |= upload(b->audio_taps.p, d.lpf_taps.data(), T_alp * sizeof(float));
   bad |= upload(b->sctab.p, d.sincos_tab.data(), d.sincos_tab.size() * sizeof(double));
+  bad |= upload(b->sctab256.p, d.sincos_tab256.data(), d.sincos_tab256.size() * sizeof(double));
   bad |= upload(b->mf_taps2.p, d.rds_mf_taps.data(), T_mf * sizeof(float));
   for (const auto& h : d.hb)
   {
@@ -606,12 +693,19 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
       hc.e[j] = hc.c[2 * j];
     b->hbcoef.push_back(hc);
   }
-  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_err), sizeof(unsigned), hipHostMallocMapped) != hipSuccess)
+  // coherent (fine-grained) host memory: the kernels' system-scope writes are visible to the host
+  // without a synchronisation, whatever HIP_HOST_COHERENT says
+  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_err), 2 * sizeof(unsigned),
+                    hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
     return fail(FMD_ERR_DEVICE, "host-mapped error word allocation failed");
-  *b->h_err = 0u;
+  b->h_err[0] = b->h_err[1] = 0u;
+  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_status), size_t(fmd::HS_WORDS) * CP * sizeof(unsigned),
+                    hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+    return fail(FMD_ERR_DEVICE, "host-mapped status snapshot allocation failed");
+  std::fill_n(b->h_status, size_t(fmd::HS_WORDS) * CP, 0u); // a fresh decoder: all meters zero
   bind_state(b.get());
-  if (!b->st.err)
-    return fail(FMD_ERR_DEVICE, "host-mapped error word has no device address");
+  if (!b->st.err || !b->st.hs)
+    return fail(FMD_ERR_DEVICE, "host-mapped memory has no device address");
   bad |= init_signal_state(b.get());
   if (bad)
     return fail(FMD_ERR_DEVICE, "upload of constants failed");
@@ -889,7 +983,7 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, s, b->rpll.p, b->rpll.p, T_mf - 1, j.R,
                        CP);
     hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, s, b->rmf.p, j.R, C, CP, k, b->st,
-                       j.call_index, b->queue[j.es].p, b->queue_count[j.es].p, b->queue_cap,
+                       j.call_index, b->queue[j.es].p, b->qcount(j.es), b->queue_cap,
                        b->tap_sync.p, b->write_taps);
   }
   if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_RDS], s) != hipSuccess)
@@ -903,7 +997,7 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     k.n_a1 = d.notch.a1;
     k.n_a2 = d.notch.a2;
     hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, s, b->alp[j.q].p, j.A, C, CP, k,
-                       b->st, j.d_audio, j.audio_stride, unsigned(j.sq));
+                       b->st, j.d_audio, j.audio_stride, unsigned(j.sq), j.call_index);
   }
   if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_AUD], s) != hipSuccess)
     mark_failed(b, "hipEventRecord failed behind the audio tail of a call");
@@ -1129,12 +1223,12 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     if (b->serial_exclusive && !serial_mode)
       hipLaunchKernelGGL((fmd::k_demod_serial<2, true>), dim3((groups + 1) / 2), dim3(256), 0, sS,
                          b->demod[q].p, b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p,
-                         Hmix, b->sctab.p, sct, unsigned(sq),
+                         Hmix, FMD_OPT_P256 ? b->sctab256.p : b->sctab.p, sct, unsigned(sq),
                          b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : nullptr);
     else
       hipLaunchKernelGGL((fmd::k_demod_serial<1, false>), dim3(groups), dim3(128), 0, sS, b->demod[q].p,
                          b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p, Hmix,
-                         b->sctab.p, sct, unsigned(sq),
+                         FMD_OPT_P256 ? b->sctab256.p : b->sctab.p, sct, unsigned(sq),
                          b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : nullptr);
   }
   signal(ce[fmd_batch::EV_SER], sS);
@@ -1247,7 +1341,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                            b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C, CP, 0u);
       hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, sR, b->rpll.p, b->rpll.p, T_mf - 1, R, CP);
       hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, sR, b->rmf.p, R, C, CP, k,
-                         b->st, ci, b->queue[es].p, b->queue_count[es].p, b->queue_cap,
+                         b->st, ci, b->queue[es].p, b->qcount(es), b->queue_cap,
                          b->tap_sync.p, b->write_taps);
     }
   };
@@ -1285,7 +1379,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       k.n_a1 = d.notch.a1;
       k.n_a2 = d.notch.a2;
       hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, sA, b->alp[q].p, A, C, CP, k,
-                         b->st, d_audio, audio_channel_stride, unsigned(sq));
+                         b->st, d_audio, audio_channel_stride, unsigned(sq), ci);
     }
   };
   if (serial_mode || b->split_post)
@@ -1295,10 +1389,12 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     signal(ce[fmd_batch::EV_RDS], sR);
     mark(5);
     audio_heavy();
+    // the audio tail closes the call: it publishes the status snapshot, RDS state included, so it
+    // runs behind the RDS chain also when that chain has a stream of its own
+    after(sA, ce[fmd_batch::EV_RDS]);
     audio_light();
     signal(ce[fmd_batch::EV_AUD], sA);
     mark(8);
-    after(sA, ce[fmd_batch::EV_RDS]);
     signal(ce[fmd_batch::EV_HEAVY], sA);
   }
   else
@@ -1431,7 +1527,34 @@ int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream_)
       HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_INDONE], 0));
     }
   // asynchronous: reports what the device has flagged so far (calls that have finished)
+  if (int rc = check_device_errors(b))
+    return rc;
+  return take_lost_groups(b);
+}
+
+int fmd_batch_flush(fmd_batch* b)
+{
+  if (!b)
+    return fail(FMD_ERR_ARG, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  flush_light(b);
   return check_device_errors(b);
+}
+
+int fmd_batch_take_rds_lost(fmd_batch* b)
+{
+  if (!b)
+    return fail(FMD_ERR_ARG, "null batch");
+  return take_lost_groups(b) == FMD_WARN_RDS_LOST ? 1 : 0;
+}
+
+int fmd_batch_debug_set_spin_limit(fmd_batch* b, unsigned limit)
+{
+  if (!b)
+    return fail(FMD_ERR_ARG, "null batch");
+  b->spin_limit = limit;
+  b->st.spin_limit = limit;
+  return FMD_OK;
 }
 
 int fmd_batch_wait(fmd_batch* b, void* stream_)
@@ -1450,23 +1573,10 @@ int fmd_batch_set_concurrency(fmd_batch* b, int mode)
   return FMD_OK;
 }
 
-static int drain_queue(fmd_batch* b, int q, hipStream_t stream, std::vector<fmd::RdsGroupRec>& recs)
+/* slots whose call is at least `lag` calls old and whose groups have not been taken out yet */
+static bool slot_to_drain(const fmd_batch* b, int q, int lag)
 {
-  unsigned n = 0;
-  HIPCHK(hipMemcpyAsync(&n, b->queue_count[q].p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-  HIPCHK(hipStreamSynchronize(stream));
-  if (n > b->queue_cap)
-    n = b->queue_cap; // overflow: the oldest queue_cap groups are kept
-  if (n)
-  {
-    const size_t old = recs.size();
-    recs.resize(old + n);
-    HIPCHK(hipMemcpyAsync(recs.data() + old, b->queue[q].p, size_t(n) * sizeof(fmd::RdsGroupRec),
-                          hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipMemsetAsync(b->queue_count[q].p, 0, sizeof(unsigned), stream));
-    HIPCHK(hipStreamSynchronize(stream));
-  }
-  return FMD_OK;
+  return slot_eligible(b, q, lag) && b->drained_call[q] != b->slot_call[q];
 }
 
 int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap, int run_group_decoder,
@@ -1478,15 +1588,58 @@ int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap,
   HIPCHK(hipSetDevice(b->device));
   if (lag == 0)
     flush_light(b);
-  std::vector<fmd::RdsGroupRec> recs;
+  /* Two synchronisations whatever the number of queues: all counts in one copy, then the records of
+   * the non-empty queues back to back.  Page-locked destinations: the copies are DMA transfers, not
+   * staging kernels that would queue up behind the decoder's own. */
+  int todo[fmd_batch::NSLOT], ntodo = 0;
   for (int q = 0; q < fmd_batch::NSLOT; q++)
+    if (slot_to_drain(b, q, lag)) // never used / already drained / its call may still be appending
+    {
+      HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_RDS], 0));
+      todo[ntodo++] = q;
+    }
+  std::vector<fmd::RdsGroupRec> recs;
+  if (ntodo)
   {
-    if (!slot_eligible(b, q, lag))
-      continue; // never used, or its call may still be appending to this queue
-    HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_RDS], 0));
-    int rc = drain_queue(b, q, stream, recs);
-    if (rc != FMD_OK)
-      return rc;
+    HIPCHK(hipMemcpyAsync(b->h_counts, b->queue_counts.p, fmd_batch::NSLOT * sizeof(unsigned),
+                          hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    size_t total = 0;
+    unsigned cnt[fmd_batch::NSLOT];
+    for (int i = 0; i < ntodo; i++)
+    {
+      cnt[i] = std::min(b->h_counts[todo[i]], b->queue_cap); // overflow: the oldest queue_cap groups are kept
+      total += cnt[i];
+    }
+    if (total > b->h_recs_cap)
+    {
+      if (b->h_recs)
+        (void)hipHostFree(b->h_recs);
+      b->h_recs = nullptr;
+      b->h_recs_cap = 0;
+      const size_t want = std::max<size_t>(total, size_t(2) * b->C + 1024);
+      if (hipHostMalloc(reinterpret_cast<void**>(&b->h_recs), want * sizeof(fmd::RdsGroupRec),
+                        hipHostMallocDefault) != hipSuccess)
+        return fail(FMD_ERR_DEVICE, "fmd_batch_collect_rds: page-locked staging allocation failed");
+      b->h_recs_cap = want;
+    }
+    size_t at = 0;
+    for (int i = 0; i < ntodo; i++)
+    {
+      const int q = todo[i];
+      if (cnt[i])
+      {
+        HIPCHK(hipMemcpyAsync(b->h_recs + at, b->queue[q].p, size_t(cnt[i]) * sizeof(fmd::RdsGroupRec),
+                              hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemsetAsync(b->qcount(q), 0, sizeof(unsigned), stream));
+        at += cnt[i];
+      }
+    }
+    if (total)
+      HIPCHK(hipStreamSynchronize(stream));
+    for (int i = 0; i < ntodo; i++)
+      b->drained_call[todo[i]] = b->slot_call[todo[i]];
+    recs.assign(b->h_recs, b->h_recs + total);
   }
   if (int rc = check_device_errors(b)) // the stream was synchronised above: covers the drained calls
     return rc;
@@ -1538,17 +1691,20 @@ int fmd_batch_export_rds_device(fmd_batch* b, int32_t* d_records, unsigned cap, 
   HIPCHK(hipMemsetAsync(b->export_cursor.p, 0, sizeof(unsigned), stream));
   for (int q = 0; q < fmd_batch::NSLOT; q++)
   {
-    if (!slot_eligible(b, q, lag))
-      continue;
+    if (!slot_to_drain(b, q, lag))
+      continue; // also: already exported for its call -- one launch per call, not one per slot
     HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_RDS], 0));
-    hipLaunchKernelGGL(fmd::k_rds_export, dim3(1), dim3(256), 0, stream, b->queue[q].p, b->queue_count[q].p,
+    hipLaunchKernelGGL(fmd::k_rds_export, dim3(1), dim3(256), 0, stream, b->queue[q].p, b->qcount(q),
                        b->queue_cap, reinterpret_cast<int4*>(d_records), cap, b->export_cursor.p,
                        channel_offset, b->st.err);
     HIPCHK(hipEventRecord(b->ev_drained[q], stream));
     b->drained_pending[q] = true;
+    b->drained_call[q] = b->slot_call[q];
   }
   HIPCHK(hipGetLastError());
-  return check_device_errors(b);
+  if (int rc = check_device_errors(b))
+    return rc;
+  return take_lost_groups(b);
 }
 
 static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t iq_channel_stride,
@@ -1595,7 +1751,7 @@ static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t 
   // recovery, audio tail) is still kept back and the null stream is not ordered after the call --
   // submit it and order the null stream behind the whole call before copying the audio out.
   rc = fmd_batch_wait(b, nullptr);
-  if (rc != FMD_OK)
+  if (rc < 0)
     return rc;
   HIPCHK(hipMemcpy2D(audio, (C > 1 ? audio_channel_stride : size_t(nf)) * sizeof(float), b->h_audio.p,
                      a_stride * sizeof(float), size_t(nf) * sizeof(float), C, hipMemcpyDeviceToHost));
@@ -1622,29 +1778,29 @@ int fmd_batch_process_host_u8(fmd_batch* b, const uint8_t* iq_u8, size_t iq_chan
                            out_floats);
 }
 
+/* The getters read the status snapshot the last kernel of every call leaves in host memory: no HIP
+ * call, no stream operation, nothing of the batch's bookkeeping -- Kodi's status thread polls them
+ * while the demux thread is inside ProcessStream (RadioReceiver.cpp:544-572 against :524). */
 int fmd_batch_get_status(fmd_batch* b, unsigned channel, fmd_status* stt)
 {
   if (!b || !stt || channel >= b->C)
     return fail(FMD_ERR_ARG, "fmd_batch_get_status: bad argument");
-  HIPCHK(hipSetDevice(b->device));
-  flush_light(b);
-  HIPCHK(hipDeviceSynchronize());
-  float if_level = 0, bb_mean = 0, bb_level = 0, p_level = 0;
-  int stereo = 0, rstate = 0;
-  HIPCHK(hipMemcpy(&if_level, b->st.F(fmd::F_IF_LEVEL) + channel, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&bb_mean, b->st.F(fmd::F_BB_MEAN) + channel, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&bb_level, b->st.F(fmd::F_BB_LEVEL) + channel, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&p_level, b->st.F(fmd::F_P_LEVEL) + channel, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&stereo, b->st.I(fmd::I_STEREO) + channel, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&rstate, b->st.I(fmd::I_R_STATE) + channel, 4, hipMemcpyDeviceToHost));
-  stt->stereo_detected = stereo;
+  unsigned w[fmd::HS_WORDS];
+  if (!host_status_read(b, channel, w))
+    return fail(FMD_ERR_DEVICE, "fmd_batch_get_status: the status snapshot is being written and never completes");
+  auto f = [&](int i) {
+    float v;
+    memcpy(&v, &w[i], 4);
+    return v;
+  };
+  stt->stereo_detected = int(w[fmd::HS_STEREO]);
   // FmDecode.h:146-150
   const float tuned = float(-b->shifts[channel]) * b->des.fs_if / float(int(b->des.table_size));
-  stt->tuning_offset = tuned + bb_mean * b->des.freq_dev;
-  stt->interface_level = if_level;
-  stt->baseband_level = bb_level;
-  stt->pilot_level = 2 * p_level; // FmDecode.h:75
-  stt->rds_state = rstate;
+  stt->tuning_offset = tuned + f(fmd::HS_BB_MEAN) * b->des.freq_dev;
+  stt->interface_level = f(fmd::HS_IF_LEVEL);
+  stt->baseband_level = f(fmd::HS_BB_LEVEL);
+  stt->pilot_level = 2 * f(fmd::HS_P_LEVEL); // FmDecode.h:75
+  stt->rds_state = int(w[fmd::HS_R_STATE]);
   return FMD_OK;
 }
 
@@ -1652,12 +1808,23 @@ int fmd_batch_get_audio_level(fmd_batch* b, unsigned channel, fmd_audio_level* o
 {
   if (!b || !out || channel >= b->C)
     return fail(FMD_ERR_ARG, "fmd_batch_get_audio_level: bad argument");
-  HIPCHK(hipSetDevice(b->device));
-  flush_light(b);
-  HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(&out->mean, b->st.F(fmd::F_AUDIO_MEAN) + channel, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&out->rms, b->st.F(fmd::F_AUDIO_RMS) + channel, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&out->level, b->st.F(fmd::F_AUDIO_LEVEL) + channel, 4, hipMemcpyDeviceToHost));
+  unsigned w[fmd::HS_WORDS];
+  if (!host_status_read(b, channel, w))
+    return fail(FMD_ERR_DEVICE, "fmd_batch_get_audio_level: the status snapshot never completes");
+  memcpy(&out->mean, &w[fmd::HS_AUDIO_MEAN], 4);
+  memcpy(&out->rms, &w[fmd::HS_AUDIO_RMS], 4);
+  memcpy(&out->level, &w[fmd::HS_AUDIO_LEVEL], 4);
+  return FMD_OK;
+}
+
+int fmd_batch_status_call_index(fmd_batch* b, unsigned channel, uint32_t* call_index)
+{
+  if (!b || !call_index || channel >= b->C)
+    return fail(FMD_ERR_ARG, "fmd_batch_status_call_index: bad argument");
+  unsigned w[fmd::HS_WORDS];
+  if (!host_status_read(b, channel, w))
+    return fail(FMD_ERR_DEVICE, "fmd_batch_status_call_index: the status snapshot never completes");
+  *call_index = (w[fmd::HS_SEQ_END] & 0x80000000u) ? 0u : w[fmd::HS_SEQ_END];
   return FMD_OK;
 }
 
@@ -1912,8 +2079,9 @@ int fmd_debug_math(int what, unsigned n, const float* a, const float* b, float* 
   p.downsample = 11;
   const fmd::Design d = fmd::make_design(p);
   DevBuf<float> da, db, d0, d1;
-  DevBuf<double> tab;
-  int bad = da.alloc(n) | db.alloc(n) | d0.alloc(n) | d1.alloc(n) | tab.alloc(d.sincos_tab.size());
+  DevBuf<double> tab, tab256;
+  int bad = da.alloc(n) | db.alloc(n) | d0.alloc(n) | d1.alloc(n) | tab.alloc(d.sincos_tab.size()) |
+            tab256.alloc(d.sincos_tab256.size());
   if (!bad)
   {
     bad |= hipMemcpy(da.p, a, size_t(n) * 4, hipMemcpyHostToDevice) != hipSuccess;
@@ -1921,12 +2089,14 @@ int fmd_debug_math(int what, unsigned n, const float* a, const float* b, float* 
       bad |= hipMemcpy(db.p, b, size_t(n) * 4, hipMemcpyHostToDevice) != hipSuccess;
     bad |= hipMemcpy(tab.p, d.sincos_tab.data(), d.sincos_tab.size() * 8, hipMemcpyHostToDevice) !=
            hipSuccess;
+    bad |= hipMemcpy(tab256.p, d.sincos_tab256.data(), d.sincos_tab256.size() * 8, hipMemcpyHostToDevice) !=
+           hipSuccess;
   }
   if (!bad)
   {
     hipLaunchKernelGGL(fmd::k_debug_math, dim3(std::min(4096u, (n + 63) / 64)), dim3(64), 0, nullptr, what,
                        n, da.p, db.p, d0.p, d1.p, tab.p,
-                       FmdSincosTab{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo});
+                       FmdSincosTab{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo}, tab256.p);
     bad |= hipDeviceSynchronize() != hipSuccess;
     bad |= hipMemcpy(out0, d0.p, size_t(n) * 4, hipMemcpyDeviceToHost) != hipSuccess;
     bad |= hipMemcpy(out1, d1.p, size_t(n) * 4, hipMemcpyDeviceToHost) != hipSuccess;
@@ -1936,6 +2106,7 @@ int fmd_debug_math(int what, unsigned n, const float* a, const float* b, float* 
   d0.release();
   d1.release();
   tab.release();
+  tab256.release();
   return bad ? fail(FMD_ERR_DEVICE, "fmd_debug_math: device error") : FMD_OK;
 }
 

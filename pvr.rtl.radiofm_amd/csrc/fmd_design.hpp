@@ -78,6 +78,8 @@ struct Design
   // (sin, cos)(k * 2pi / 1024) for the NCO evaluation (fmd_math.h: fmd_sincos_tab)
   std::vector<double> sincos_tab;
   double sct_inv_h, sct_h_hi, sct_h_lo;
+  // (sin, cos)(k / 256), k = 0 .. 2047 (fmd_math.h: fmd_sincos_p256)
+  std::vector<double> sincos_tab256;
 };
 
 // cFineTuner table (FmDecode.cpp:45-58): 2*(cos, sin) of ((shift*i) % size) * step
@@ -383,6 +385,13 @@ inline Design make_design(const Params& p)
     std::memcpy(&hd, &u, 8);
     d.sct_h_hi = hd;
     d.sct_h_lo = double(h - (long double)hd);
+    d.sincos_tab256.resize(size_t(2) * 2048);
+    for (int k = 0; k < 2048; k++)
+    {
+      const long double a = (long double)k / 256.0L;
+      d.sincos_tab256[size_t(2) * k] = double(sinl(a));
+      d.sincos_tab256[size_t(2) * k + 1] = double(cosl(a));
+    }
   }
   return d;
 }

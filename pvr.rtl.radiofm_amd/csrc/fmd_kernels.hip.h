@@ -73,19 +73,31 @@ enum ISlot
   I_R_LAST_BIT, I_R_BITS, I_R_BLOCK, I_R_BITPOS, I_R_STATE, I_R_BOFF,
   I_R_ERRORS, I_R_SEQ, I_SLOTS
 };
-/* Device-side error word of a batch (host-mapped memory: the host reads it without a copy).
- * Kernels OR a bit in when an invariant fails; fmd_batch_wait / collect_rds turn it into an error. */
+/* Device-side error words of a batch (host-mapped memory: the host reads them without a copy).
+ * Kernels OR a bit in when an invariant fails.  err[0] holds the fatal conditions (the batch refuses
+ * further calls until it is reset), err[1] the recoverable ones (reported once, then cleared). */
 enum DevErr : unsigned
 {
-  DEVERR_SERIAL_HANDSHAKE = 1u, // k_demod_serial: a role wave gave up waiting for its partner
-  DEVERR_RDS_QUEUE_FULL = 2u    // k_rds_bits: a group did not fit into the call's queue (lost)
+  DEVERR_SERIAL_HANDSHAKE = 1u, // err[0], k_demod_serial: a role wave gave up waiting for its partner
+  DEVERR_RDS_QUEUE_FULL = 1u    // err[1], k_rds_bits / k_rds_export: a group did not fit (lost)
+};
+/* Status snapshot of every channel in host-mapped memory, [HS_WORDS][CP] 32-bit words: what the
+ * cFmDecoder getters (FmDecode.h:140-165) and cRadioReceiver's audio meter return, written by the
+ * last kernel of a call (k_audio_tail) so that the host reads them without touching the device.
+ * HS_SEQ_BEGIN is written first and HS_SEQ_END last (both = the call's index); a reader takes END,
+ * the fields, then BEGIN, and has a consistent record when the two are equal. */
+enum HostStatusWord
+{
+  HS_SEQ_BEGIN, HS_IF_LEVEL, HS_BB_MEAN, HS_BB_LEVEL, HS_P_LEVEL, HS_STEREO, HS_R_STATE,
+  HS_AUDIO_MEAN, HS_AUDIO_RMS, HS_AUDIO_LEVEL, HS_SEQ_END, HS_WORDS
 };
 struct ChannelState
 {
   float* f;         // [F_SLOTS][CP]
   int* i;           // [I_SLOTS][CP]
   uint16_t* r_data; // [4][CP]   block words of the group being assembled
-  unsigned* err;    // the batch's error word (DevErr bits)
+  unsigned* err;    // the batch's two error words (DevErr)
+  unsigned* hs;     // [HS_WORDS][CP] status snapshot in host-mapped memory
   unsigned spin_limit; // bound of the LDS hand-off waits (0 = every wait times out: test knob)
   unsigned CP;
   __host__ __device__ float* F(int slot) const { return f + (size_t)slot * CP; }
@@ -969,6 +981,21 @@ __global__ __launch_bounds__(64) void k_if_level(const typename IN::elem* __rest
  * SIMD (half the register file each, 32 CUs owned): the waves do not fit into each other's issue
  * gaps, the stage takes 3.5 ms (151 GS/s). */
 constexpr int DS = 32; // samples per LDS chunk
+#ifndef FMD_OPT_FAR
+#define FMD_OPT_FAR 1
+#endif
+#ifndef FMD_OPT_PKCMUL
+#define FMD_OPT_PKCMUL 1
+#endif
+#ifndef FMD_OPT_PKPLL
+#define FMD_OPT_PKPLL 1
+#endif
+#ifndef FMD_OPT_P256
+#define FMD_OPT_P256 1
+#endif
+#ifndef FMD_OPT_UNROLL
+#define FMD_OPT_UNROLL 2
+#endif
 
 template <int NG, bool EXCL>
 __global__ __launch_bounds__(128 * NG) void k_demod_serial(
@@ -977,6 +1004,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     float2* __restrict__ mix, unsigned Hmix, const double* __restrict__ sctab_g, FmdSincosTab sct,
     unsigned stereo_q, long long* __restrict__ wg_probe)
 {
+  // sctab_g: FMD_OPT_P256 ? (sin, cos)(k / 256), 2048 entries : (sin, cos)(k 2 pi / 1024)
   // dev aid (FMD_SERIAL_PROBE=1): when each workgroup started and ended on the 100 MHz clock, and
   // its shader-clock cycles in between
   const long long probe_r0 = wg_probe ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
@@ -985,7 +1013,12 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
   __shared__ float2 stage_all[NG][2][DS][64]; // IF-FIR output, pilot/RDS role -> FM role
   // the larger alignment puts the tables first in the LDS layout: below 64 KB their base folds
   // into the read's offset field (one instruction less on the path from the phase to its sine)
-  __shared__ __attribute__((aligned(1024))) double sctab[2 * FMD_SINCOS_TAB_SIZE];
+#if FMD_OPT_P256
+  constexpr unsigned SCTAB_N = FMD_SINCOS_P256_SIZE;
+#else
+  constexpr unsigned SCTAB_N = FMD_SINCOS_TAB_SIZE;
+#endif
+  __shared__ __attribute__((aligned(1024))) double sctab[2 * SCTAB_N];
   __shared__ __attribute__((aligned(512))) float atab[FMD_ATAN_TAB_FLOATS];
   /* Chunk hand-off between the two role waves of a group.  One group per workgroup: a barrier per
    * chunk.  Several groups: a barrier would also make the groups wait for each other every chunk
@@ -1000,7 +1033,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
   __builtin_amdgcn_s_setprio(3);
   if (EXCL)
     asm volatile("" ::: "v255", "a255");
-  for (unsigned i = threadIdx.x; i < 2 * FMD_SINCOS_TAB_SIZE; i += 128 * NG)
+  for (unsigned i = threadIdx.x; i < 2 * SCTAB_N; i += 128 * NG)
     sctab[i] = sctab_g[i];
   if (threadIdx.x == 0)
     fmd_atan_table_fill(atab);
@@ -1038,40 +1071,71 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
       {
         const unsigned m0 = j * DS;
         const unsigned cnt = min((unsigned)DS, M - m0);
-#pragma unroll 1
-        for (unsigned u = 0; u < cnt; u++)
-        {
+        /* One sample of the FM PLL (FmDecode.cpp:371-413).  The wave is bound by the number of
+         * instructions it issues (one wave per SIMD): everything below is written for that count. */
+        auto fm_sample = [&](unsigned u) {
           const float2 sin_ = stage[j & 1][u][lane]; // staged one chunk ahead by the other wave
           const float sre = sin_.x, sim = sin_.y;
-          /* ---- FM PLL (FmDecode.cpp:371-413) ---- */
           float sn, cs;
+#if FMD_OPT_P256
+          fmd_sincos_p256(nco_phase, sctab, &sn, &cs);
+#else
           fmd_sincos_tab(nco_phase, sctab, sct, &sn, &cs);
+#endif
+#if FMD_OPT_PKCMUL
+          // ComplexType(Cos, Sin) * signal[i] as three packed operations:
+          // (cs sre, cs sim) + (-(sn sim), sn sre)  [fmd_pk_add_cross: (a.x - b.y, a.y + b.x)]
+          const fmd_v2f dd = fmd_pk_add_cross((fmd_v2f){sre, sim} * cs, (fmd_v2f){sre, sim} * sn);
+          const float dre = dd.x, dim = dd.y;
+#else
           const float dre = cs * sre - sn * sim; // ComplexType(Cos, Sin) * signal[i]
           const float dim = cs * sim + sn * sre;
-          /* One wave-uniform test for both kinds of rare input (arctangent outside the table form's
-           * range; a phase step outside (-2pi, 4pi), impossible with the clamps): the common path
-           * carries no fix-up code, the rare path redoes the update literally. */
+#endif
+          /* One test for the rare inputs (arctangent outside the table form's range): the common
+           * path carries no fix-up code, the rare path redoes the update literally. */
           bool lit;
           const float err = -fmd_atan2f_tab_core(dim, dre, atab, &lit);
           const float incr0 = nco_incr, phase0 = nco_phase;
           /* :399-402 as max / min: the same as the reference's two compares for every number; a
            * NaN state (only ever out of non-finite input) goes through the literal path below */
+#if FMD_OPT_PKPLL
+          const fmd_v2f ba = (fmd_v2f){k.pll_beta, k.pll_alpha} * err;
+          nco_incr += ba.x;
+          nco_incr = fminf(fmaxf(nco_incr, k.nco_ll), k.nco_hl);
+          nco_phase += nco_incr + ba.y;
+#else
           nco_incr += k.pll_beta * err;
           nco_incr = fminf(fmaxf(nco_incr, k.nco_ll), k.nco_hl);
           nco_phase += nco_incr + k.pll_alpha * err;
+#endif
           {
             /* :404-407  if (phase >= 2pi) phase = fmod(phase, 2pi); while (phase < 0) phase += 2pi;
              * For phase in [2pi, 4pi) fmod is the exact difference phase - 2pi, and for
              * [-2pi, 0) the loop runs once. */
             const double pd = (double)nco_phase;
+#if FMD_OPT_FAR
+            /* K_2PI lies between the floats 0x40c90fda and 0x40c90fdb, so (double)phase >= K_2PI is
+             * this float compare */
+            const bool ge = nco_phase >= 6.2831855f;
+#else
             const bool ge = pd >= FMD_K_2PI;
+#endif
             const bool lt = nco_phase < 0;
             const double off = ge ? -FMD_K_2PI : FMD_K_2PI;
             const float moved = (float)(pd + off); // exact difference / sum, rounded once
+#if FMD_OPT_FAR
+            /* The new phase cannot be outside (-2 pi, 4 pi): the old one lies in [0, 2 pi] (by this
+             * very wrap), the increment is clamped to +-0.95 pi and alpha |err| <= 0.67 pi.  A NaN
+             * anywhere (only ever out of non-finite input) makes the quotient inside the arctangent
+             * NaN, i.e. `lit`: the literal path then reproduces what the reference's compares do
+             * with it, and from then on every sample goes that way. */
+            const bool redo = lit;
+#else
             // outside (-2pi, 4pi) (never with the clamps), tested generously: |phase - pi| >= 9.4
             const bool far = !(fabsf(nco_phase - 3.1415927f) < 9.4f) | (incr0 != incr0);
-            nco_phase = (ge | lt) ? moved : nco_phase;
             const bool redo = lit | far;
+#endif
+            nco_phase = (ge | lt) ? moved : nco_phase;
             if (__builtin_expect(redo, 0))
             {
               {
@@ -1090,7 +1154,27 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
               }
             }
           }
-          chunk[j & 1][u][lane] = 2 * nco_incr; // phaseIncr (:409); the output filter runs in wave 1
+          // the NCO increment; phaseIncr = 2 * increment (:409) and the output filter run in wave 1
+          chunk[j & 1][u][lane] = nco_incr;
+        };
+#if FMD_OPT_UNROLL > 1
+        if (cnt == (unsigned)DS)
+        { // full chunks: FMD_OPT_UNROLL samples per trip (no register copies at the back edge, LDS
+          // addresses with immediate offsets)
+#pragma unroll 1
+          for (unsigned u = 0; u < (unsigned)DS; u += FMD_OPT_UNROLL)
+          {
+#pragma unroll
+            for (unsigned v = 0; v < FMD_OPT_UNROLL; v++)
+              fm_sample(u + v);
+          }
+        }
+        else
+#endif
+        {
+#pragma unroll 1
+          for (unsigned u = 0; u < cnt; u++)
+            fm_sample(u);
         }
       }
       if (PAIRSYNC)
@@ -1178,59 +1262,77 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
         const unsigned m0 = (j - 1) * DS;
         const unsigned cnt = min((unsigned)DS, M - m0);
         float pinc_next = chunk[(j - 1) & 1][0][lane];
+        auto second_sample = [&](unsigned u) {
+            /* FM PLL output stage (FmDecode.cpp:409-412): low-pass of the NCO frequency term as
+             * DC offset, off the PLL's own recurrence and therefore done here.  The chunk entry is
+             * read one sample ahead so its LDS latency is not at the head of the iteration. */
+            const float pinc = 2 * pinc_next; // phaseIncr (:409), exact
+            pinc_next = chunk[(j - 1) & 1][min(u + 1, (unsigned)DS - 1)][lane];
+            dc = (float)((1 - 0.0001) * (double)dc + 0.0001 * (double)pinc);
+            const float v = (pinc - dc) * k.demod_gain;
+            vsum += v;
+            vsumsq += v * v;
+            /* ---- pilot PLL (FmDecode.cpp:151-217) ---- */
+            float ps, pc;
+#if FMD_OPT_P256
+            fmd_sincos_p256(p_phase, sctab, &ps, &pc);
+#else
+            fmd_sincos_tab(p_phase, sctab, sct, &ps, &pc);
+#endif
+            const float tone = 2 * ps * pc;
+            float ph_i = ps * v;
+            float ph_q = pc * v;
+            ph_i = k.p_b0 * ph_i - k.p_a1 * p_i1 - k.p_a2 * p_i2;
+            ph_q = k.p_b0 * ph_q - k.p_a1 * p_q1 - k.p_a2 * p_q2;
+            p_i2 = p_i1;
+            p_i1 = ph_i;
+            p_q2 = p_q1;
+            p_q1 = ph_q;
+            /* :194-201 as selects; the quotient is formed unconditionally and only used in lock */
+            const float ratio = ph_q / ph_i;
+            const float sgn = (ph_q > 0) ? 1.0f : -1.0f;
+            const float perr = (ph_i > fabsf(ph_q)) ? ratio : sgn;
+            p_level = (ph_i < p_level) ? ph_i : p_level;
+            p_freq += k.p_lf_b0 * perr + k.p_lf_b1 * p_x1;
+            p_x1 = perr;
+            // :210 std::max(min, std::min(max, freq)): the same as min / max instructions for every
+            // input (a NaN frequency becomes maxfreq either way; the limits are positive, no zero signs)
+            p_freq = fmaxf(k.p_minfreq, fminf(k.p_maxfreq, p_freq));
+            p_phase += p_freq;
+            {
+              const double pd = (double)p_phase;
+              const float down = (float)(pd - FMD_K_2PI);
+              p_phase = (pd > FMD_K_2PI) ? down : p_phase; // :215-216
+            }
+            /* ---- RDS oscillator mix (DownConvert.cpp:436-442, :464-465), imag(input) == 0 ---- */
+            float2 osc;
+            osc.x = o_re * k.osc_cos - o_im * k.osc_sin;
+            osc.y = o_im * k.osc_cos + o_re * k.osc_sin;
+            const float gn = (float)(1.95 - (double)(o_re * o_re + o_im * o_im));
+            o_re = gn * osc.x;
+            o_im = gn * osc.y;
+            const float zero = 0.0f;
+            *reinterpret_cast<float2*>(br_rows + row_off) = make_float2(v, tone * (2 * v)); // FmDecode.cpp:456
+            *reinterpret_cast<float2*>(mix_rows + row_off) =
+                make_float2((v * osc.x) - (zero * osc.y), (v * osc.y) + (zero * osc.x));
+            row_off += row_step;
+        };
+#if FMD_OPT_UNROLL > 1
+        if (cnt == (unsigned)DS)
+        { // full chunks: two samples per trip (no register copies at the back edge)
 #pragma unroll 1
-        for (unsigned u = 0; u < cnt; u++)
+          for (unsigned u = 0; u < (unsigned)DS; u += 2)
+          {
+            second_sample(u);
+            second_sample(u + 1);
+          }
+        }
+        else
+#endif
         {
-          /* FM PLL output stage (FmDecode.cpp:409-412): low-pass of the NCO frequency term as
-           * DC offset, off the PLL's own recurrence and therefore done here.  The chunk entry is
-           * read one sample ahead so its LDS latency is not at the head of the iteration. */
-          const float pinc = pinc_next;
-          pinc_next = chunk[(j - 1) & 1][min(u + 1, (unsigned)DS - 1)][lane];
-          dc = (float)((1 - 0.0001) * (double)dc + 0.0001 * (double)pinc);
-          const float v = (pinc - dc) * k.demod_gain;
-          vsum += v;
-          vsumsq += v * v;
-          /* ---- pilot PLL (FmDecode.cpp:151-217) ---- */
-          float ps, pc;
-          fmd_sincos_tab(p_phase, sctab, sct, &ps, &pc);
-          const float tone = 2 * ps * pc;
-          float ph_i = ps * v;
-          float ph_q = pc * v;
-          ph_i = k.p_b0 * ph_i - k.p_a1 * p_i1 - k.p_a2 * p_i2;
-          ph_q = k.p_b0 * ph_q - k.p_a1 * p_q1 - k.p_a2 * p_q2;
-          p_i2 = p_i1;
-          p_i1 = ph_i;
-          p_q2 = p_q1;
-          p_q1 = ph_q;
-          /* :194-201 as selects; the quotient is formed unconditionally and only used in lock */
-          const float ratio = ph_q / ph_i;
-          const float sgn = (ph_q > 0) ? 1.0f : -1.0f;
-          const float perr = (ph_i > fabsf(ph_q)) ? ratio : sgn;
-          p_level = (ph_i < p_level) ? ph_i : p_level;
-          p_freq += k.p_lf_b0 * perr + k.p_lf_b1 * p_x1;
-          p_x1 = perr;
-          {
-            const float t = (p_freq < k.p_maxfreq) ? p_freq : k.p_maxfreq;
-            p_freq = (k.p_minfreq < t) ? t : k.p_minfreq;
-          }
-          p_phase += p_freq;
-          {
-            const double pd = (double)p_phase;
-            const float down = (float)(pd - FMD_K_2PI);
-            p_phase = (pd > FMD_K_2PI) ? down : p_phase; // :215-216
-          }
-          /* ---- RDS oscillator mix (DownConvert.cpp:436-442, :464-465), imag(input) == 0 ---- */
-          float2 osc;
-          osc.x = o_re * k.osc_cos - o_im * k.osc_sin;
-          osc.y = o_im * k.osc_cos + o_re * k.osc_sin;
-          const float gn = (float)(1.95 - (double)(o_re * o_re + o_im * o_im));
-          o_re = gn * osc.x;
-          o_im = gn * osc.y;
-          const float zero = 0.0f;
-          *reinterpret_cast<float2*>(br_rows + row_off) = make_float2(v, tone * (2 * v)); // FmDecode.cpp:456
-          *reinterpret_cast<float2*>(mix_rows + row_off) =
-              make_float2((v * osc.x) - (zero * osc.y), (v * osc.y) + (zero * osc.x));
-          row_off += row_step;
+#pragma unroll 1
+          for (unsigned u = 0; u < cnt; u++)
+            second_sample(u);
         }
         stores_behind = 2 * cnt;
       }
@@ -1934,7 +2036,7 @@ __global__ __launch_bounds__(64) void k_rds_bits(const float* __restrict__ mf, u
             queue[slot] = r;
           }
           else
-            dev_error(st.err, DEVERR_RDS_QUEUE_FULL);
+            dev_error(st.err + 1, DEVERR_RDS_QUEUE_FULL);
           seq++;
         }
       }
@@ -2134,7 +2236,8 @@ constexpr int AT_STEPS = 16; // audio frames buffered per lane before a coalesce
 __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp, unsigned A,
                                                    unsigned C, unsigned CP, AudioConsts k,
                                                    ChannelState st, float* __restrict__ audio,
-                                                   size_t audio_stride, unsigned stereo_q)
+                                                   size_t audio_stride, unsigned stereo_q,
+                                                   unsigned call_index)
 {
   // [channel lane][AT_STEPS frames + pad]: one row = 128 B of a channel's interleaved L/R output
   __shared__ float2 tile[64][AT_STEPS + 1];
@@ -2223,9 +2326,31 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
     // m_AudioLevel = 0.95 * m_AudioLevel + 0.05 * audio_rms in double (RadioReceiver.cpp:526-528)
     const float n = (float)(2u * A);
     const float rms = sqrtf(vsumsq / n);
-    st.F(F_AUDIO_MEAN)[c] = vsum / n;
+    const float mean = vsum / n;
+    const float level = (float)(0.95 * (double)st.F(F_AUDIO_LEVEL)[c] + 0.05 * (double)rms);
+    st.F(F_AUDIO_MEAN)[c] = mean;
     st.F(F_AUDIO_RMS)[c] = rms;
-    st.F(F_AUDIO_LEVEL)[c] = (float)(0.95 * (double)st.F(F_AUDIO_LEVEL)[c] + 0.05 * (double)rms);
+    st.F(F_AUDIO_LEVEL)[c] = level;
+    /* The call is complete for this channel: its status goes to the host's snapshot (see
+     * HostStatusWord).  The level meters are the state arrays as they stand now; the stereo flag is
+     * this call's own copy.  With overlapped calls (concurrency 2) the next call's IF / baseband
+     * meters may already be in -- the reference's status thread reads its decoder mid-call too
+     * (RadioReceiver.cpp:544-572 against :524, no common lock). */
+    volatile unsigned* h = st.hs + c;
+    const unsigned CPs = st.CP;
+    h[HS_SEQ_BEGIN * CPs] = call_index;
+    __threadfence_system();
+    h[HS_IF_LEVEL * CPs] = __float_as_uint(st.F(F_IF_LEVEL)[c]);
+    h[HS_BB_MEAN * CPs] = __float_as_uint(st.F(F_BB_MEAN)[c]);
+    h[HS_BB_LEVEL * CPs] = __float_as_uint(st.F(F_BB_LEVEL)[c]);
+    h[HS_P_LEVEL * CPs] = __float_as_uint(st.F(F_P_LEVEL)[c]);
+    h[HS_STEREO * CPs] = (unsigned)stereo;
+    h[HS_R_STATE * CPs] = (unsigned)st.I(I_R_STATE)[c];
+    h[HS_AUDIO_MEAN * CPs] = __float_as_uint(mean);
+    h[HS_AUDIO_RMS * CPs] = __float_as_uint(rms);
+    h[HS_AUDIO_LEVEL * CPs] = __float_as_uint(level);
+    __threadfence_system();
+    h[HS_SEQ_END * CPs] = call_index;
   }
 }
 
@@ -2260,7 +2385,7 @@ __global__ __launch_bounds__(256) void k_rds_export(const RdsGroupRec* __restric
   if (threadIdx.x == 0)
   {
     if (base + n > cap)
-      dev_error(err, DEVERR_RDS_QUEUE_FULL); // more groups than the caller's record buffer holds
+      dev_error(err + 1, DEVERR_RDS_QUEUE_FULL); // more groups than the caller's record buffer holds
     *queue_count = 0;
   }
 }
@@ -2300,12 +2425,16 @@ __global__ void k_probe_nop(int* sink)
 __global__ __launch_bounds__(64) void k_debug_math(int what, unsigned n, const float* __restrict__ a,
                                                    const float* __restrict__ b, float* __restrict__ o0,
                                                    float* __restrict__ o1,
-                                                   const double* __restrict__ sctab_g, FmdSincosTab sct)
+                                                   const double* __restrict__ sctab_g, FmdSincosTab sct,
+                                                   const double* __restrict__ sctab256_g)
 {
   __shared__ double sctab[2 * FMD_SINCOS_TAB_SIZE];
+  __shared__ double sctab256[2 * FMD_SINCOS_P256_SIZE];
   __shared__ float atab[FMD_ATAN_TAB_FLOATS];
   for (unsigned i = threadIdx.x; i < 2 * FMD_SINCOS_TAB_SIZE; i += 64)
     sctab[i] = sctab_g[i];
+  for (unsigned i = threadIdx.x; i < 2 * FMD_SINCOS_P256_SIZE; i += 64)
+    sctab256[i] = sctab256_g[i];
   if (threadIdx.x == 0)
     fmd_atan_table_fill(atab);
   __syncthreads();
@@ -2332,6 +2461,9 @@ __global__ __launch_bounds__(64) void k_debug_math(int what, unsigned n, const f
         break;
       case 5:
         r0 = fmd_u8_to_f32((unsigned)a[k]);
+        break;
+      case 7:
+        fmd_sincos_p256(a[k], sctab256, &r0, &r1);
         break;
       default:
         r0 = fmd_rds_arctan2(a[k], b[k]);

@@ -46,6 +46,38 @@
 #define FMD_HD_NOINLINE static __attribute__((noinline))
 #endif
 
+#ifndef FMD_OPT_MAGIC
+#define FMD_OPT_MAGIC 1
+#endif
+#ifndef FMD_OPT_RANGE
+#define FMD_OPT_RANGE 0
+#endif
+#ifndef FMD_OPT_NOCLAMP
+#define FMD_OPT_NOCLAMP 1
+#endif
+#ifndef FMD_OPT_PKND
+#define FMD_OPT_PKND 1
+#endif
+#if defined(__clang__)
+typedef float fmd_v2f __attribute__((ext_vector_type(2)));
+#else
+typedef float fmd_v2f __attribute__((vector_size(8)));
+#endif
+
+/* (a.x - b.y, a.y + b.x): one packed add with the second operand's halves swapped and the low one
+ * negated (operand modifiers, no extra instruction) */
+FMD_HD fmd_v2f fmd_pk_add_cross(fmd_v2f a, fmd_v2f b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  fmd_v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  fmd_v2f r = {a[0] - b[1], a[1] + b[0]};
+  return r;
+#endif
+}
+
 #define FMD_K_2PI (2.0 * 3.14159265358979323846)
 #define FMD_K_PI (3.14159265358979323846)
 #define FMD_K_PI2 (FMD_K_PI / 2.0)
@@ -335,16 +367,44 @@ FMD_HD float fmd_atan2f_tab_core(float y, float x, const float* tab, bool* need_
   const bool rare = iq - 0x31000000u >= 0x4c000000u - 0x31000000u; /* see above */
   /* the common-range evaluation runs for every lane (a rare lane computes a value nobody uses:
    * its range index is clamped, nothing here can trap) */
+#if FMD_OPT_NOCLAMP
+  /* no clamp for the rare lanes: whatever their bits are, the range index below stays within 0..4,
+   * nothing on the way can trap, and their result is replaced by the literal function's */
+  const uint32_t ic = iq;
+#else
   const uint32_t ic = rare ? 0x3f800000u : iq;
+#endif
   const float qc = fmd_u2f(ic);
   /* range index without compares: (ic - T) is negative, i.e. shifts to -1, exactly when ic < T */
+#if FMD_OPT_RANGE
+  const int r = (int)(ic >= 0x3ee00000u) + (int)(ic >= 0x3f300000u) + (int)(ic >= 0x3f980000u) +
+                (int)(ic >= 0x401c0000u);
+#else
   const int r = 4 + ((int32_t)(ic - 0x3ee00000u) >> 31) + ((int32_t)(ic - 0x3f300000u) >> 31) +
                 ((int32_t)(ic - 0x3f980000u) >> 31) + ((int32_t)(ic - 0x401c0000u) >> 31);
+#endif
   const float* t = tab + 8 * r;
   /* a = d and c = -b in every row (a: 1 2 1 1 0, c: 0 1 1 1.5 1), so the reduction only needs two
    * small numbers per range; they come out of two packed nibble constants (a, 2c) with a bit-field
    * extract and a conversion instead of waiting for the table row, which is then only needed for
    * hi / lo at the very end. */
+#if FMD_OPT_PKND
+  /* Numerator and denominator are taken TWICE as large, which leaves the quotient as it is (a power
+   * of two scales every product, sum and the rounding of each exactly): 2a and 2c are small integers,
+   * nibble r of 0x02242 is 2a (2 4 2 2 0 for r = 0..4), of 0x23220 is 2c (0 2 2 3 2).  Both products as
+   * one packed multiply, both sums as one packed add: (2a q, 2c q) + (-2c, 2a). */
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float a2 = (float)__builtin_amdgcn_ubfe(0x02242u, 4u * (unsigned)r, 4u);
+  const float c2 = (float)__builtin_amdgcn_ubfe(0x23220u, 4u * (unsigned)r, 4u);
+#else
+  const float a2 = (float)((0x02242u >> (4u * (unsigned)r)) & 0xfu);
+  const float c2 = (float)((0x23220u >> (4u * (unsigned)r)) & 0xfu);
+#endif
+  const fmd_v2f ac = {a2, c2};
+  const fmd_v2f nd = fmd_pk_add_cross(ac * qc, ac);
+  const float num = nd[0];
+  const float den = nd[1]; /* 2, 4+2q, 2q+2, 2+3q or 2q: within [0.875, 2^26] */
+#else
   /* nibble r of 0x01121 is a (1 2 1 1 0 for r = 0..4), of 0x23220 is 2c (0 2 2 3 2) */
 #if defined(__HIP_DEVICE_COMPILE__)
   const float ca = (float)__builtin_amdgcn_ubfe(0x01121u, 4u * (unsigned)r, 4u);
@@ -355,6 +415,7 @@ FMD_HD float fmd_atan2f_tab_core(float y, float x, const float* tab, bool* need_
 #endif
   const float num = ca * qc + (-cc);
   const float den = cc * qc + ca; /* 1, 2+q, q+1, 1+1.5q or q: within [0.4375, 2^25] */
+#endif
   const float xr = fmd_div_midrange(num, den);
   const float z = xr * xr;
   const float w = z * z;
@@ -396,12 +457,49 @@ FMD_HD void fmd_sincos_tab(float phase, const double* tab /* [1024][2] */, struc
                            float* s, float* c)
 {
   const double x = (double)phase;
+#if FMD_OPT_MAGIC
+  /* k = x / h rounded to an integer, as the low word of x / h + 1.5 * 2^52 (one operation instead
+   * of multiply, round, convert; |x / h| < 2^31) */
+  const double magic = 6755399441055744.0;
+  const double tt = __builtin_fma(x, t.inv_h, magic);
+  const double kf = tt - magic;
+  uint64_t ttu;
+  memcpy(&ttu, &tt, 8);
+  const int k = (int)(uint32_t)ttu;
+#else
   const double kf = __builtin_rint(x * t.inv_h);
   const int k = (int)kf;
+#endif
   double r = __builtin_fma(-kf, t.h_hi, x);
   r = __builtin_fma(-kf, t.h_lo, r);
   const double S = tab[2 * (k & (FMD_SINCOS_TAB_SIZE - 1))];
   const double C = tab[2 * (k & (FMD_SINCOS_TAB_SIZE - 1)) + 1];
+  const double r2 = r * r;
+  const double sr = __builtin_fma(r * r2, __builtin_fma(r2, 1.0 / 120.0, -1.0 / 6.0), r);
+  const double cm1 = r2 * __builtin_fma(r2, 1.0 / 24.0, -0.5);
+  const double so = S + __builtin_fma(C, sr, S * cm1);
+  const double co = C + __builtin_fma(-S, sr, C * cm1);
+  *s = (float)so;
+  *c = (float)co;
+}
+
+/* The same for a phase known to lie in [0, 8): the table is (sin, cos)(k / 256), k = 0 .. 2047, and the
+ * split phase = k / 256 + r is done in FLOAT without any rounding error: phase + 1.5 * 2^15 has an ulp
+ * of 2^-8, i.e. the sum IS phase rounded to a multiple of 1 / 256 with k in its low mantissa bits;
+ * taking the constant off again and subtracting from phase are both exact (|r| <= 2^-9).  Three float
+ * operations and one conversion instead of a conversion and five double operations, and r carries no
+ * error at all.  The two NCOs of the serial stage keep their phase in [0, 2 pi] (FmDecode.cpp:404-407,
+ * :215-216).  NaN / infinite phases give NaN like fsincos; the table index is masked. */
+#define FMD_SINCOS_P256_SIZE 2048
+FMD_HD void fmd_sincos_p256(float phase, const double* tab /* [2048][2] */, float* s, float* c)
+{
+  const float big = 49152.0f;
+  const float t = phase + big;
+  const uint32_t k = fmd_f2u(t) & (FMD_SINCOS_P256_SIZE - 1);
+  const float kx = t - big;
+  const double r = (double)(phase - kx);
+  const double S = tab[2 * k];
+  const double C = tab[2 * k + 1];
   const double r2 = r * r;
   const double sr = __builtin_fma(r * r2, __builtin_fma(r2, 1.0 / 120.0, -1.0 / 6.0), r);
   const double cm1 = r2 * __builtin_fma(r2, 1.0 / 24.0, -0.5);

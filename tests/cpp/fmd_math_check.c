@@ -45,7 +45,13 @@ int main(int argc, char** argv)
     t.h_hi = hd;
     t.h_lo = (double)(h - (long double)hd);
   }
-  long bad_a = 0, bad_f = 0, bad_s = 0, bad_t = 0, bad_r = 0;
+  static double tab256[2 * FMD_SINCOS_P256_SIZE];
+  for (int k = 0; k < FMD_SINCOS_P256_SIZE; k++)
+  {
+    tab256[2 * k] = (double)sinl((long double)k / 256.0L);
+    tab256[2 * k + 1] = (double)cosl((long double)k / 256.0L);
+  }
+  long bad_a = 0, bad_f = 0, bad_s = 0, bad_t = 0, bad_r = 0, bad_p = 0;
   for (long i = 0; i < n; i++)
   {
     float y, x;
@@ -84,6 +90,11 @@ int main(int argc, char** argv)
     bad_s += (fmd_f2u(s1) != fmd_f2u(s2)) + (fmd_f2u(c1) != fmd_f2u(c2));
     bad_t += (fmd_f2u(s1) != fmd_f2u(s3)) + (fmd_f2u(c1) != fmd_f2u(c3));
     (void)bad_r;
+    /* the exact-reduction form of the serial stage's NCOs: phases in [0, 2 pi] */
+    const float p2 = (float)((rnd() >> 11) * (1.0 / 9007199254740992.0) * 6.2832);
+    x87(p2, &s1, &c1);
+    fmd_sincos_p256(p2, tab256, &s3, &c3);
+    bad_p += (fmd_f2u(s1) != fmd_f2u(s3)) + (fmd_f2u(c1) != fmd_f2u(c3));
   }
   /* RTL-SDR byte -> float (RTL_SDR_Source.cpp:207-211): all 256 inputs */
   long bad_u = 0;
@@ -92,7 +103,7 @@ int main(int argc, char** argv)
     const float ref = (float)(b / (255.0 / 2.0) - 1.0);
     bad_u += fmd_f2u(ref) != fmd_f2u(fmd_u8_to_f32(b));
   }
-  printf("n=%ld atan2f=%ld atan2f_tab=%ld sincos_nco=%ld sincos_tab=%ld u8_to_f32=%ld\n", n, bad_a, bad_f,
-         bad_s, bad_t, bad_u);
+  printf("n=%ld atan2f=%ld atan2f_tab=%ld sincos_nco=%ld sincos_tab=%ld u8_to_f32=%ld sincos_p256=%ld\n", n,
+         bad_a, bad_f, bad_s, bad_t, bad_u, bad_p);
   return 0;
 }

@@ -1,0 +1,25 @@
+"""`python bench.py --gpus N` with N > 1 and no rank variables in the environment starts its own N
+ranks (one child process per GPU, before anything touches HIP).  Without a GPU the ranks cannot get
+past device selection: what is checked here is the launcher -- it comes back promptly with a nonzero
+exit code and names the ranks that failed, instead of hanging in a rendezvous.  The same invocation on a
+GPU box is tests/test_gpu_multirank.py::test_bench_starts_its_own_ranks."""
+import os
+import subprocess
+import sys
+
+from __graft_entry__ import ROOT
+
+
+def test_launcher_reports_failed_ranks_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present: covered by the gpu test of the same invocation")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                          "--warmup", "1", "--channels", "64", "--no-cpu-baseline", "--watchdog", "60"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0
+    assert "ranks failed" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]  # no result line

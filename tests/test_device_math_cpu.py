@@ -20,4 +20,5 @@ def test_math_restatements_match_host_libm(tmp_path):
     assert m["atan2f_tab"] == 0, out    # table-parameterised form used in the kernels
     assert m["sincos_nco"] <= 2, out    # 40M values: expected ~0.15 double-rounding cases
     assert m["sincos_tab"] <= 2, out
+    assert m["sincos_p256"] <= 2, out   # exact float reduction (the serial stage's two NCOs)
     assert m["u8_to_f32"] == 0, out     # RTL-SDR byte conversion, all 256 inputs

@@ -210,16 +210,16 @@ def test_profiling_level_change_between_overlapped_calls(oracle, fmsig):
     b.close()
 
 
-def test_device_error_word_surfaces(monkeypatch, fmsig):
+def test_device_error_word_surfaces(fmsig):
     """A serial-stage hand-off that times out does not go unnoticed: the kernel sets a bit in the
     batch's error word, fmd_batch_wait / collect_rds return FMD_ERR_DEVICE, later calls are refused
-    until fmd_batch_reset.  FMD_DEBUG_SPIN_LIMIT=0 makes every hand-off wait time out at once."""
+    until fmd_batch_reset.  fmd_batch_debug_set_spin_limit(b, 0) makes every hand-off wait time out at
+    once."""
     import torch
     pkg = load_package()
     fs, D, C = 2.4e6, 11, 1024  # >= 1024 channels: the whole-CU serial stage with LDS hand-offs
-    monkeypatch.setenv("FMD_DEBUG_SPIN_LIMIT", "0")
     b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
-    monkeypatch.delenv("FMD_DEBUG_SPIN_LIMIT")
+    b.debug_set_spin_limit(0)
     b.set_concurrency(2)
     a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
     iq = torch.zeros((C, N, 2), dtype=torch.float32, device="cuda")

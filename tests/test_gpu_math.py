@@ -89,6 +89,33 @@ def test_sincos_forms_equal_fsincos(pkg, oracle):
         assert bad <= 1, (what, bad)  # expected ~0.003 double-rounding cases in 700k values
 
 
+def test_sincos_exact_reduction_equals_fsincos(pkg, oracle):
+    """fmd_sincos_p256 (the form the serial stage's two NCOs use: phase in [0, 2 pi], split into
+    k / 256 + r without rounding error) against the x87 instruction: a dense sweep of the range, every
+    float next to the table's grid points, and the floats around 0 and 2 pi."""
+    rng = np.random.default_rng(7)
+    twopi = np.float32(2 * np.pi)
+    grid = (np.arange(0, 1610, dtype=np.float32) / np.float32(256.0))
+    near = np.concatenate([np.nextafter(grid, np.float32(10)), grid, np.nextafter(grid, np.float32(-1)),
+                           grid + np.float32(1.0 / 512), np.nextafter(grid + np.float32(1.0 / 512), np.float32(10))])
+    edge = np.array([0.0, 1e-45, 1e-38, 1e-20, 1e-7, twopi, np.nextafter(twopi, np.float32(0)),
+                     np.nextafter(twopi, np.float32(10)), 6.2831855, 6.29, 7.99], dtype=np.float32)
+    ph = np.concatenate([rng.uniform(0, 6.2832, 400_000).astype(np.float32), near[near >= 0], edge])
+    s_ref = np.empty_like(ph)
+    c_ref = np.empty_like(ph)
+    f = oracle.lib().fmo_sincos_x87
+    sv, cv = C.c_float(), C.c_float()
+    for i, p in enumerate(ph):
+        f(float(p), C.byref(sv), C.byref(cv))
+        s_ref[i], c_ref[i] = sv.value, cv.value
+    s, c = pkg.debug_math(7, ph)
+    bad = int((_bits(s) != _bits(s_ref)).sum() + (_bits(c) != _bits(c_ref)).sum())
+    assert bad <= 1, bad  # double-rounding cases: probability ~2^-28 per value
+    # non-finite phases give NaN like the instruction does
+    s, c = pkg.debug_math(7, np.array([np.nan, np.inf], dtype=np.float32))
+    assert np.isnan(s).all() and np.isnan(c).all()
+
+
 def test_byte_conversion_all_values(pkg, oracle):
     b = np.arange(256, dtype=np.float32)
     got, _ = pkg.debug_math(5, b)

@@ -67,3 +67,49 @@ def test_rccl_path_with_a_world_of_one():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert "RCCL" in d["config"]["gather"] and d["verify"]["ok"]
     assert d["config"]["rds_groups_in_timed_region"] > 0
+
+
+def test_bench_starts_its_own_ranks():
+    """The driver's own invocation shape, `python bench.py --gpus 2 ...`, with NO rank variables in the
+    environment: bench.py becomes the launcher (before importing torch), starts one child per rank and
+    passes rank 0's JSON line through as the last line of stdout.  Two ranks share this box's one GPU
+    (gloo + FMD_BENCH_SHARE_GPU, as above); --verify is on by default with more than one rank."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("LD_PRELOAD", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FMD_BENCH_BACKEND="gloo", FMD_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline",
+                          "--channels", "192", "--steps", "30", "--warmup", "3", "--ring", "24",
+                          "--watchdog", "240"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    last = out.stdout.strip().splitlines()[-1]
+    d = json.loads(last)  # the JSON line is the LAST line of stdout
+    assert d["n_gpus"] == 2 and d["verify"]["ok"] and d["verify"]["ranks"] == 2
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1]
+    assert all(r["ms_per_step"] > 0 and r["if_fir_ms"] > 0 and r["gather_ms_per_step"] is not None
+               for r in d["per_rank"])
+
+
+def test_single_gpu_invocation_is_unchanged():
+    """`python bench.py --gpus 1` stays one process: no launcher, no process group."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("LD_PRELOAD", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline",
+                          "--channels", "256", "--steps", "12", "--warmup", "2", "--ring", "4",
+                          "--watchdog", "240"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["config"]["gather"] == "none (1 GPU)" and "per_rank" not in d
+
+
+@pytest.mark.parametrize("workload,steps", [("config5", 8), ("config3", 12)])
+def test_full_size_verify_of_the_other_configs(workload, steps):
+    """BASELINE configs[4] (4096 channels, 4096-tap filter, 10 MS/s) and configs[2] (256 channels from one
+    capture) at their FULL size through `bench.py --verify`: what the overlapped pipeline wrote for the
+    first, second, middle and last channel is compared bit for bit with a small batch of the same
+    stations (audio and RDS records)."""
+    d = _run_bench(1, ["--workload", workload, "--steps", str(steps), "--warmup", "2", "--ring", "4"],
+                   29545 if workload == "config5" else 29546)
+    assert d["verify"]["ok"] and not d["verify"]["mismatches"]
+    C = 4096 if workload == "config5" else 256
+    assert d["config"]["channels_per_gpu"] == C
+    assert d["verify"]["channels_per_rank"] == sorted({0, 1, C // 2, C - 1})

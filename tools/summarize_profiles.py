@@ -38,6 +38,11 @@ out = open(os.path.join(pr, tag + "_pmc_k_if_fir.txt"), "w")
 out.write("rocprofv3 --pmc passes (separate runs, counters only) on k_if_fir<InF32,64,7,true,0,false> (one tile per workgroup: calls not overlapped), 8192 channels,\n"
           "bench.py --concurrency 0; mean per launch.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE\n"
           "counts 1/2 of a wide coalesced read stream (MI355X_MICROARCH.md, HBM): read bytes = 2*FETCH_SIZE*1024.\n")
+# bench.py reads the traffic of the kernel form it times: the file is keyed by form
+tpath = os.path.join(pr, "traffic_k_if_fir.json")
+traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+if "bytes_per_launch" in traffic:  # the flat round-2 layout
+    traffic = {}
 vals = {}
 for d in ("pmc1", "pmc2", "pmc3"):
     fs = glob.glob(os.path.join(go, "%s_%s" % (tag, d), "**", "*_counter_collection.csv"), recursive=True)
@@ -54,12 +59,13 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     out.write("HBM traffic per launch: read %.4g B + write %.4g B = %.4g B (algorithmic 4.6854e9 B)\n"
               % (rd, wr, rd + wr))
     print("traffic per launch:", rd + wr)
-    json.dump({"kernel": "k_if_fir", "channels": 8192, "samples_per_call": 65536,
-               "bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
-               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
-                         "read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024",
-               "source": "profiles/%s_pmc_k_if_fir.txt" % tag},
-              open(os.path.join(pr, "traffic_k_if_fir.json"), "w"), indent=1)
+    traffic["k_if_fir"] = {
+        "kernel": "k_if_fir<InF32,64,7,true,0,false> (one tile per workgroup: calls not overlapped)",
+        "channels": 8192, "samples_per_call": 65536,
+        "bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
+        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                  "read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024",
+        "source": "profiles/%s_pmc_k_if_fir.txt" % tag}
 out.close()
 # the two-tile form that runs when calls overlap (passes 4 and 5: default bench.py, regex k_if_fir_mt)
 mt = {}
@@ -77,4 +83,14 @@ if "FETCH_SIZE" in mt and "WRITE_SIZE" in mt:
         out2.write("\nThe two-tile form that runs when calls overlap (k_if_fir_mt<InF32,7,2>, default bench.py, the same\n"
                    "separate --pmc passes, n=%d launches): read %.4g B + write %.4g B = %.4g B per launch = %.3f x algorithmic.\n"
                    % (mt["FETCH_SIZE"][1], rd, wr, rd + wr, (rd + wr) / 4.6854e9))
+    traffic["k_if_fir_mt"] = {
+        "kernel": "k_if_fir_mt<InF32,7,2> (two tiles per workgroup: overlapped calls beside the whole-CU "
+                  "serial stage, the default bench.py run)",
+        "channels": 8192, "samples_per_call": 65536,
+        "bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
+        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the default (overlapped) "
+                  "bench.py, read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024",
+        "source": "profiles/%s_pmc_k_if_fir.txt (last paragraph)" % tag}
+if traffic:
+    json.dump(traffic, open(tpath, "w"), indent=1)
 print(open(os.path.join(pr, tag + "_pmc_k_if_fir.txt")).read())
