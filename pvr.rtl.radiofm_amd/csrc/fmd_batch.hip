@@ -721,6 +721,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     // created: every extra stream competes for the few hardware queues (GPU_MAX_HW_QUEUES)
     b->heavy_par = getenv("FMD_HEAVY_PAR") ? atoi(getenv("FMD_HEAVY_PAR")) != 0 : false;
     const int nstreams = b->heavy_par ? 5 : 4;
+    // (the light chain's stream at the high priority too: measured, no difference)
     const int prio[5] = {hi, hi, lo, lo, lo};
     hipStream_t st4[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (pick_independent_streams(nstreams, prio, st4) != 0)

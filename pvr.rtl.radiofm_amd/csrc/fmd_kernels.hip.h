@@ -1847,23 +1847,44 @@ __global__ __launch_bounds__(64) void k_rds_pll(const float2* __restrict__ lpf, 
   if (c >= C)
     return;
   float phase = st.F(F_R_PHASE)[c], freq = st.F(F_R_FREQ)[c];
-  float2 cur = lpf[c];
   float* __restrict__ o = rpll + (size_t)Hout * CP + c;
-#pragma unroll 1
-  for (unsigned i = 0; i < R; i++)
+  /* The input travels a whole tile ahead of its use: the loads of tile n + 1 are in flight while
+   * tile n goes through the recurrence (one load per sample, issued one sample ahead, had to come
+   * back within an iteration -- 0.2 us; beside the bandwidth kernels a load takes several times that
+   * and the kernel took 0.56 ms inside the pipeline against 0.23 ms alone). */
+  constexpr unsigned PT = 16;
+  float2 nxt[PT];
+#pragma unroll
+  for (unsigned u = 0; u < PT; u++)
+    nxt[u] = lpf[(size_t)min(u, R - 1) * CP + c];
+  for (unsigned i0 = 0; i0 < R; i0 += PT)
   {
-    const float2 in = cur;
-    cur = lpf[(size_t)((i + 1 < R) ? i + 1 : i) * CP + c]; // one step ahead of its use
-    float sn, cs;
-    fmd_sincos_tab(phase, sctab, sct, &sn, &cs);
-    const float tr = cs * in.x - sn * in.y;
-    const float ti = cs * in.y + sn * in.x;
-    const float err = -fmd_rds_arctan2(ti, tr);
-    freq += (k.pll_beta * err);
-    freq = (freq > k.nco_hl) ? k.nco_hl : ((freq < k.nco_ll) ? k.nco_ll : freq);
-    phase += (freq + k.pll_alpha * err);
-    *o = ti;
-    o += CP;
+    float2 cur[PT];
+#pragma unroll
+    for (unsigned u = 0; u < PT; u++)
+      cur[u] = nxt[u];
+#pragma unroll
+    for (unsigned u = 0; u < PT; u++) // clamped: past the end the last row again (never used)
+      nxt[u] = lpf[(size_t)min(i0 + PT + u, R - 1) * CP + c];
+    const unsigned cnt = min(PT, R - i0);
+#pragma unroll
+    for (unsigned u = 0; u < PT; u++)
+    {
+      if (u < cnt)
+      {
+        const float2 in = cur[u];
+        float sn, cs;
+        fmd_sincos_tab(phase, sctab, sct, &sn, &cs);
+        const float tr = cs * in.x - sn * in.y;
+        const float ti = cs * in.y + sn * in.x;
+        const float err = -fmd_rds_arctan2(ti, tr);
+        freq += (k.pll_beta * err);
+        freq = (freq > k.nco_hl) ? k.nco_hl : ((freq < k.nco_ll) ? k.nco_ll : freq);
+        phase += (freq + k.pll_alpha * err);
+        *o = ti;
+        o += CP;
+      }
+    }
   }
   st.F(F_R_PHASE)[c] = fmodf(phase, (float)FMD_K_2PI); // RDSProcess.cpp:269
   st.F(F_R_FREQ)[c] = freq;
@@ -1901,13 +1922,20 @@ __global__ __launch_bounds__(64) void k_rds_bits(const float* __restrict__ mf, u
     bd[q] = st.r_data[(size_t)q * CP + c];
   uint32_t seq = (uint32_t)st.I(I_R_SEQ)[c];
 
+  float dnext[RB_TILE];
+#pragma unroll
+  for (unsigned u = 0; u < RB_TILE; u++)
+    dnext[u] = mf[(size_t)min(u, R - 1) * CP + c];
   for (unsigned i0 = 0; i0 < R; i0 += RB_TILE)
   {
     const unsigned cnt = min((unsigned)RB_TILE, R - i0);
     float din[RB_TILE];
 #pragma unroll
-    for (unsigned u = 0; u < RB_TILE; u++) // all loads of the tile in flight before the recurrence
-      din[u] = mf[(size_t)min(i0 + u, R - 1) * CP + c];
+    for (unsigned u = 0; u < RB_TILE; u++)
+      din[u] = dnext[u];
+#pragma unroll
+    for (unsigned u = 0; u < RB_TILE; u++) // the next tile's loads are in flight during this tile's recurrence
+      dnext[u] = mf[(size_t)min(i0 + RB_TILE + u, R - 1) * CP + c];
     uint64_t qbits = 0; // bits sliced in this tile, oldest in the MSBs
     int qcount = 0;
 #pragma unroll
@@ -2296,12 +2324,21 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
   };
 
   unsigned i0 = 0;
+  // full tiles: the loads of the next tile are in flight while this one goes through the recurrence
+  // out of registers (past the last full tile: clamped rows nobody uses)
+  float2 vnext[AT_STEPS];
+#pragma unroll
+  for (unsigned u = 0; u < AT_STEPS; u++)
+    vnext[u] = lp[(size_t)min(u, A - 1) * CP + c];
   for (; i0 + AT_STEPS <= A; i0 += AT_STEPS)
-  { // full tiles: all loads in flight first, then the recurrence out of registers
+  {
     float2 vin[AT_STEPS];
 #pragma unroll
     for (unsigned u = 0; u < AT_STEPS; u++)
-      vin[u] = lp[(size_t)(i0 + u) * CP + c];
+      vin[u] = vnext[u];
+#pragma unroll
+    for (unsigned u = 0; u < AT_STEPS; u++)
+      vnext[u] = lp[(size_t)min(i0 + AT_STEPS + u, A - 1) * CP + c];
 #pragma unroll
     for (unsigned u = 0; u < AT_STEPS; u++)
       tile[lane][u] = frame(vin[u]);
@@ -2310,8 +2347,10 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
   if (i0 < A)
   {
     const unsigned cnt = A - i0;
-    for (unsigned u = 0; u < cnt; u++)
-      tile[lane][u] = frame(lp[(size_t)(i0 + u) * CP + c]);
+#pragma unroll
+    for (unsigned u = 0; u < AT_STEPS; u++) // the ragged last tile is already in vnext
+      if (u < cnt)
+        tile[lane][u] = frame(vnext[u]);
     flush(i0, cnt);
   }
   if (active)
