@@ -583,6 +583,12 @@ def main():
         dt = reduce_scalar(dt, dist.ReduceOp.MAX)
     stage, calls = batch.stage_ms()
     fir_ms = stage["if_fir"]
+    if os.environ.get("FMD_BENCH_TIMELINE") and rank == 0:  # dev aid: what fill and drain are made of
+        tl = batch.debug_timeline()
+        sys.stderr.write("TIMELINE (ms since the first timed call's FIR start; wall %.3f ms)\n"
+                         "call  fir_start fir_end  ser_start ser_end  tail_start tail_end\n" % (dt * 1e3))
+        for c, row in enumerate(tl):
+            sys.stderr.write("%4d  %s\n" % (c, "  ".join("%8.3f" % v for v in row)))
     # what makes an N > 1 run explain itself: every rank's own time per step and FIR time, and what the
     # gather costs on the side stream (on rank 0: receiving from every peer; elsewhere: sending)
     gather_ms = None

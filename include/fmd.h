@@ -301,6 +301,12 @@ int fmd_debug_math(int what, unsigned n, const float* a, const float* b, float* 
  * records of workgroups that did not exist stay zero.  Returns the number of records written (0
  * when the probe is off).  Synchronises the device. */
 int fmd_batch_debug_serial_probe(fmd_batch* b, long long* out, unsigned cap_workgroups);
+/* Dev aid (overlapped calls at profiling level 1, whole-CU serial stage): per profiled call when its
+ * IF FIR, its serial stage and its audio tail started and ended on the device, in ms since the first
+ * profiled call's FIR started: cap_calls rows of 6 floats (-1 = not recorded).  Returns the number of
+ * rows.  Synchronises the device.  What a short run's fill and drain are made of (bench.py prints it
+ * with FMD_BENCH_TIMELINE=1). */
+int fmd_batch_debug_timeline(fmd_batch* b, float* out, unsigned cap_calls);
 /* Test aid: bound (in polls) of the serial stage's LDS hand-off waits for the calls that follow;
  * 0 makes every wait time out at once, which exercises the device-side error path. */
 int fmd_batch_debug_set_spin_limit(fmd_batch* b, unsigned limit);

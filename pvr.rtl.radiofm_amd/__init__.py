@@ -112,7 +112,7 @@ EXPORTS = [
     "fmd_version", "fmd_group_decoder_create", "fmd_group_decoder_destroy",
     "fmd_group_decoder_reset", "fmd_group_decoder_push", "fmd_uecp_stuff_frame",
     "fmd_batch_flush", "fmd_batch_take_rds_lost", "fmd_batch_status_call_index",
-    "fmd_batch_debug_set_spin_limit",
+    "fmd_batch_debug_set_spin_limit", "fmd_batch_debug_timeline",
 ]
 
 
@@ -201,6 +201,7 @@ def lib():
         L.fmd_batch_take_rds_lost.argtypes = [vp]
         L.fmd_batch_status_call_index.argtypes = [vp, u, C.POINTER(C.c_uint32)]
         L.fmd_batch_debug_set_spin_limit.argtypes = [vp, u]
+        L.fmd_batch_debug_timeline.argtypes = [vp, vp, u]
         _LIB = L
     return _LIB
 
@@ -362,6 +363,13 @@ class Batch:
         ci = C.c_uint32()
         _check(lib().fmd_batch_status_call_index(self._h, channel, C.byref(ci)))
         return ci.value
+
+    def debug_timeline(self, cap=512):
+        """[calls, 6] ms since the first profiled call's FIR start: FIR, serial stage, audio tail
+        (start, end each); empty unless calls overlap at profiling level 1."""
+        buf = np.full((cap, 6), -1.0, dtype=np.float32)
+        n = _check(lib().fmd_batch_debug_timeline(self._h, buf.ctypes.data, cap))
+        return buf[:n].copy()
 
     def debug_set_spin_limit(self, limit):
         _check(lib().fmd_batch_debug_set_spin_limit(self._h, limit))

@@ -181,6 +181,7 @@ struct fmd_batch
     uint32_t call_index = 0;
     float* d_audio = nullptr;
     size_t audio_stride = 0;
+    hipEvent_t tl0 = nullptr, tl1 = nullptr; // profiling level 1: the audio tail's own start / stop
   } light_job;
   bool split_post = false;
   bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
@@ -997,8 +998,13 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     k.n_b2 = d.notch.b2;
     k.n_a1 = d.notch.a1;
     k.n_a2 = d.notch.a2;
-    hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, s, b->alp[j.q].p, j.A, C, CP, k,
-                       b->st, j.d_audio, j.audio_stride, unsigned(j.sq), j.call_index);
+    if (j.tl0)
+      hipExtLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0u, s, j.tl0, j.tl1, 0u,
+                            (const float2*)b->alp[j.q].p, j.A, C, CP, k, b->st, j.d_audio, j.audio_stride,
+                            unsigned(j.sq), j.call_index);
+    else
+      hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, s, b->alp[j.q].p, j.A, C, CP, k,
+                         b->st, j.d_audio, j.audio_stride, unsigned(j.sq), j.call_index);
   }
   if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_AUD], s) != hipSuccess)
     mark_failed(b, "hipEventRecord failed behind the audio tail of a call");
@@ -1221,15 +1227,22 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     const unsigned groups = CP / 64;
     const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
     const unsigned Hmix = unsigned(d.hb[0].len - 1);
-    if (b->serial_exclusive && !serial_mode)
+    if (b->serial_exclusive && !serial_mode && evset && b->profiling == 1)
+      // profiling level 1: the stage's own start and stop too (fmd_batch_debug_timeline)
+      hipExtLaunchKernelGGL((fmd::k_demod_serial<2, true>), dim3((groups + 1) / 2), dim3(256), 0u, sS, evset[2],
+                            evset[3], 0u, (const float2*)b->demod[q].p, b->Mstride, M, C, CP, k, b->st,
+                            b->brp(q), Hbb, b->mix[q].p, Hmix,
+                            (const double*)(b->sctab256.p), sct, unsigned(sq),
+                            (long long*)nullptr);
+    else if (b->serial_exclusive && !serial_mode)
       hipLaunchKernelGGL((fmd::k_demod_serial<2, true>), dim3((groups + 1) / 2), dim3(256), 0, sS,
                          b->demod[q].p, b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p,
-                         Hmix, FMD_OPT_P256 ? b->sctab256.p : b->sctab.p, sct, unsigned(sq),
+                         Hmix, b->sctab256.p, sct, unsigned(sq),
                          b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : nullptr);
     else
       hipLaunchKernelGGL((fmd::k_demod_serial<1, false>), dim3(groups), dim3(128), 0, sS, b->demod[q].p,
                          b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p, Hmix,
-                         FMD_OPT_P256 ? b->sctab256.p : b->sctab.p, sct, unsigned(sq),
+                         b->sctab256.p, sct, unsigned(sq),
                          b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : nullptr);
   }
   signal(ce[fmd_batch::EV_SER], sS);
@@ -1427,6 +1440,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     job.call_index = ci;
     job.d_audio = d_audio;
     job.audio_stride = audio_channel_stride;
+    if (evset && b->profiling == 1)
+    {
+      job.tl0 = evset[4];
+      job.tl1 = evset[5];
+    }
     if (b->concurrency == 2)
     { // Overlapped calls: the light part of the PREVIOUS call goes out now, behind this call's
       // serial stage, i.e. it runs beside the heavy part of this call at the start of the next
@@ -2109,6 +2127,32 @@ int fmd_debug_math(int what, unsigned n, const float* a, const float* b, float* 
   tab.release();
   tab256.release();
   return bad ? fail(FMD_ERR_DEVICE, "fmd_debug_math: device error") : FMD_OK;
+}
+
+int fmd_batch_debug_timeline(fmd_batch* b, float* out, unsigned cap_calls)
+{
+  if (!b || !out)
+    return fail(FMD_ERR_ARG, "fmd_batch_debug_timeline: null argument");
+  if (b->profiling != 1 || b->prof_calls == 0 || !b->serial_exclusive || b->concurrency != 2)
+    return 0;
+  HIPCHK(hipSetDevice(b->device));
+  flush_light(b);
+  HIPCHK(hipDeviceSynchronize());
+  const unsigned n = std::min(cap_calls, b->prof_calls);
+  hipEvent_t t0 = b->ev[0];
+  for (unsigned c = 0; c < n; c++)
+  {
+    hipEvent_t* es = &b->ev[size_t(c) * (ST_COUNT + 1)];
+    for (int i = 0; i < 6; i++)
+    {
+      float ms = -1.0f;
+      if (hipEventElapsedTime(&ms, t0, es[i]) != hipSuccess)
+        ms = -1.0f; // an event that was never recorded (the call's tail was not profiled)
+      out[size_t(c) * 6 + i] = ms;
+    }
+  }
+  (void)hipGetLastError();
+  return int(n);
 }
 
 int fmd_batch_debug_serial_probe(fmd_batch* b, long long* out, unsigned cap_workgroups)

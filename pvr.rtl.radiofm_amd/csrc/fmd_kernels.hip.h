@@ -981,21 +981,7 @@ __global__ __launch_bounds__(64) void k_if_level(const typename IN::elem* __rest
  * SIMD (half the register file each, 32 CUs owned): the waves do not fit into each other's issue
  * gaps, the stage takes 3.5 ms (151 GS/s). */
 constexpr int DS = 32; // samples per LDS chunk
-#ifndef FMD_OPT_FAR
-#define FMD_OPT_FAR 1
-#endif
-#ifndef FMD_OPT_PKCMUL
-#define FMD_OPT_PKCMUL 1
-#endif
-#ifndef FMD_OPT_PKPLL
-#define FMD_OPT_PKPLL 1
-#endif
-#ifndef FMD_OPT_P256
-#define FMD_OPT_P256 1
-#endif
-#ifndef FMD_OPT_UNROLL
-#define FMD_OPT_UNROLL 2
-#endif
+constexpr unsigned FM_UNROLL = 4; // samples per trip of the FM wave's loop over a full chunk (1, 2, 4: 651 / 599 / 596 cycles per sample)
 
 template <int NG, bool EXCL>
 __global__ __launch_bounds__(128 * NG) void k_demod_serial(
@@ -1004,7 +990,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     float2* __restrict__ mix, unsigned Hmix, const double* __restrict__ sctab_g, FmdSincosTab sct,
     unsigned stereo_q, long long* __restrict__ wg_probe)
 {
-  // sctab_g: FMD_OPT_P256 ? (sin, cos)(k / 256), 2048 entries : (sin, cos)(k 2 pi / 1024)
+  // sctab_g: (sin, cos)(k / 256), 2048 entries (fmd_sincos_p256)
   // dev aid (FMD_SERIAL_PROBE=1): when each workgroup started and ended on the 100 MHz clock, and
   // its shader-clock cycles in between
   const long long probe_r0 = wg_probe ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
@@ -1013,11 +999,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
   __shared__ float2 stage_all[NG][2][DS][64]; // IF-FIR output, pilot/RDS role -> FM role
   // the larger alignment puts the tables first in the LDS layout: below 64 KB their base folds
   // into the read's offset field (one instruction less on the path from the phase to its sine)
-#if FMD_OPT_P256
   constexpr unsigned SCTAB_N = FMD_SINCOS_P256_SIZE;
-#else
-  constexpr unsigned SCTAB_N = FMD_SINCOS_TAB_SIZE;
-#endif
   __shared__ __attribute__((aligned(1024))) double sctab[2 * SCTAB_N];
   __shared__ __attribute__((aligned(512))) float atab[FMD_ATAN_TAB_FLOATS];
   /* Chunk hand-off between the two role waves of a group.  One group per workgroup: a barrier per
@@ -1045,6 +1027,9 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
   float2 (*stage)[DS][64] = stage_all[grp];
   const unsigned done_fm = (unsigned)(size_t)&done_all[grp][0];  // LDS byte addresses
   const unsigned done_2nd = (unsigned)(size_t)&done_all[grp][1];
+  // a constant of the sine series, pinned in a vector register for both sample loops
+  double m16 = -1.0 / 6.0;
+  asm volatile("" : "+v"(m16));
   const unsigned c0 = (blockIdx.x * NG + grp) * 64 + lane;
   const bool active = c0 < C;
   const unsigned c = active ? c0 : C - 1; // padded lanes shadow the last channel, stores masked
@@ -1077,20 +1062,11 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           const float2 sin_ = stage[j & 1][u][lane]; // staged one chunk ahead by the other wave
           const float sre = sin_.x, sim = sin_.y;
           float sn, cs;
-#if FMD_OPT_P256
-          fmd_sincos_p256(nco_phase, sctab, &sn, &cs);
-#else
-          fmd_sincos_tab(nco_phase, sctab, sct, &sn, &cs);
-#endif
-#if FMD_OPT_PKCMUL
+          fmd_sincos_p256k(nco_phase, sctab, m16, &sn, &cs);
           // ComplexType(Cos, Sin) * signal[i] as three packed operations:
           // (cs sre, cs sim) + (-(sn sim), sn sre)  [fmd_pk_add_cross: (a.x - b.y, a.y + b.x)]
           const fmd_v2f dd = fmd_pk_add_cross((fmd_v2f){sre, sim} * cs, (fmd_v2f){sre, sim} * sn);
           const float dre = dd.x, dim = dd.y;
-#else
-          const float dre = cs * sre - sn * sim; // ComplexType(Cos, Sin) * signal[i]
-          const float dim = cs * sim + sn * sre;
-#endif
           /* One test for the rare inputs (arctangent outside the table form's range): the common
            * path carries no fix-up code, the rare path redoes the update literally. */
           bool lit;
@@ -1098,48 +1074,31 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           const float incr0 = nco_incr, phase0 = nco_phase;
           /* :399-402 as max / min: the same as the reference's two compares for every number; a
            * NaN state (only ever out of non-finite input) goes through the literal path below */
-#if FMD_OPT_PKPLL
           const fmd_v2f ba = (fmd_v2f){k.pll_beta, k.pll_alpha} * err;
           nco_incr += ba.x;
           nco_incr = fminf(fmaxf(nco_incr, k.nco_ll), k.nco_hl);
           nco_phase += nco_incr + ba.y;
-#else
-          nco_incr += k.pll_beta * err;
-          nco_incr = fminf(fmaxf(nco_incr, k.nco_ll), k.nco_hl);
-          nco_phase += nco_incr + k.pll_alpha * err;
-#endif
           {
             /* :404-407  if (phase >= 2pi) phase = fmod(phase, 2pi); while (phase < 0) phase += 2pi;
              * For phase in [2pi, 4pi) fmod is the exact difference phase - 2pi, and for
              * [-2pi, 0) the loop runs once. */
             const double pd = (double)nco_phase;
-#if FMD_OPT_FAR
             /* K_2PI lies between the floats 0x40c90fda and 0x40c90fdb, so (double)phase >= K_2PI is
              * this float compare */
             const bool ge = nco_phase >= 6.2831855f;
-#else
-            const bool ge = pd >= FMD_K_2PI;
-#endif
             const bool lt = nco_phase < 0;
             const double off = ge ? -FMD_K_2PI : FMD_K_2PI;
             const float moved = (float)(pd + off); // exact difference / sum, rounded once
-#if FMD_OPT_FAR
             /* The new phase cannot be outside (-2 pi, 4 pi): the old one lies in [0, 2 pi] (by this
              * very wrap), the increment is clamped to +-0.95 pi and alpha |err| <= 0.67 pi.  A NaN
              * anywhere (only ever out of non-finite input) makes the quotient inside the arctangent
              * NaN, i.e. `lit`: the literal path then reproduces what the reference's compares do
              * with it, and from then on every sample goes that way. */
-            const bool redo = lit;
-#else
-            // outside (-2pi, 4pi) (never with the clamps), tested generously: |phase - pi| >= 9.4
-            const bool far = !(fabsf(nco_phase - 3.1415927f) < 9.4f) | (incr0 != incr0);
-            const bool redo = lit | far;
-#endif
             nco_phase = (ge | lt) ? moved : nco_phase;
-            if (__builtin_expect(redo, 0))
+            if (__builtin_expect(lit, 0))
             {
               {
-                const float e2 = lit ? -fmd_atan2f(dim, dre) : err;
+                const float e2 = -fmd_atan2f(dim, dre);
                 float in2 = incr0 + k.pll_beta * e2;
                 in2 = (in2 < k.nco_ll) ? k.nco_ll : in2;
                 in2 = (in2 > k.nco_hl) ? k.nco_hl : in2;
@@ -1157,20 +1116,18 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           // the NCO increment; phaseIncr = 2 * increment (:409) and the output filter run in wave 1
           chunk[j & 1][u][lane] = nco_incr;
         };
-#if FMD_OPT_UNROLL > 1
         if (cnt == (unsigned)DS)
-        { // full chunks: FMD_OPT_UNROLL samples per trip (no register copies at the back edge, LDS
+        { // full chunks: FM_UNROLL samples per trip (no register copies at the back edge, LDS
           // addresses with immediate offsets)
 #pragma unroll 1
-          for (unsigned u = 0; u < (unsigned)DS; u += FMD_OPT_UNROLL)
+          for (unsigned u = 0; u < (unsigned)DS; u += FM_UNROLL)
           {
 #pragma unroll
-            for (unsigned v = 0; v < FMD_OPT_UNROLL; v++)
+            for (unsigned v = 0; v < FM_UNROLL; v++)
               fm_sample(u + v);
           }
         }
         else
-#endif
         {
 #pragma unroll 1
           for (unsigned u = 0; u < cnt; u++)
@@ -1274,11 +1231,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
             vsumsq += v * v;
             /* ---- pilot PLL (FmDecode.cpp:151-217) ---- */
             float ps, pc;
-#if FMD_OPT_P256
-            fmd_sincos_p256(p_phase, sctab, &ps, &pc);
-#else
-            fmd_sincos_tab(p_phase, sctab, sct, &ps, &pc);
-#endif
+            fmd_sincos_p256k(p_phase, sctab, m16, &ps, &pc);
             const float tone = 2 * ps * pc;
             float ph_i = ps * v;
             float ph_q = pc * v;
@@ -1317,7 +1270,6 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
                 make_float2((v * osc.x) - (zero * osc.y), (v * osc.y) + (zero * osc.x));
             row_off += row_step;
         };
-#if FMD_OPT_UNROLL > 1
         if (cnt == (unsigned)DS)
         { // full chunks: two samples per trip (no register copies at the back edge)
 #pragma unroll 1
@@ -1328,7 +1280,6 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           }
         }
         else
-#endif
         {
 #pragma unroll 1
           for (unsigned u = 0; u < cnt; u++)

@@ -46,18 +46,6 @@
 #define FMD_HD_NOINLINE static __attribute__((noinline))
 #endif
 
-#ifndef FMD_OPT_MAGIC
-#define FMD_OPT_MAGIC 1
-#endif
-#ifndef FMD_OPT_RANGE
-#define FMD_OPT_RANGE 0
-#endif
-#ifndef FMD_OPT_NOCLAMP
-#define FMD_OPT_NOCLAMP 1
-#endif
-#ifndef FMD_OPT_PKND
-#define FMD_OPT_PKND 1
-#endif
 #if defined(__clang__)
 typedef float fmd_v2f __attribute__((ext_vector_type(2)));
 #else
@@ -367,28 +355,18 @@ FMD_HD float fmd_atan2f_tab_core(float y, float x, const float* tab, bool* need_
   const bool rare = iq - 0x31000000u >= 0x4c000000u - 0x31000000u; /* see above */
   /* the common-range evaluation runs for every lane (a rare lane computes a value nobody uses:
    * its range index is clamped, nothing here can trap) */
-#if FMD_OPT_NOCLAMP
   /* no clamp for the rare lanes: whatever their bits are, the range index below stays within 0..4,
    * nothing on the way can trap, and their result is replaced by the literal function's */
   const uint32_t ic = iq;
-#else
-  const uint32_t ic = rare ? 0x3f800000u : iq;
-#endif
   const float qc = fmd_u2f(ic);
   /* range index without compares: (ic - T) is negative, i.e. shifts to -1, exactly when ic < T */
-#if FMD_OPT_RANGE
-  const int r = (int)(ic >= 0x3ee00000u) + (int)(ic >= 0x3f300000u) + (int)(ic >= 0x3f980000u) +
-                (int)(ic >= 0x401c0000u);
-#else
   const int r = 4 + ((int32_t)(ic - 0x3ee00000u) >> 31) + ((int32_t)(ic - 0x3f300000u) >> 31) +
                 ((int32_t)(ic - 0x3f980000u) >> 31) + ((int32_t)(ic - 0x401c0000u) >> 31);
-#endif
   const float* t = tab + 8 * r;
   /* a = d and c = -b in every row (a: 1 2 1 1 0, c: 0 1 1 1.5 1), so the reduction only needs two
    * small numbers per range; they come out of two packed nibble constants (a, 2c) with a bit-field
    * extract and a conversion instead of waiting for the table row, which is then only needed for
    * hi / lo at the very end. */
-#if FMD_OPT_PKND
   /* Numerator and denominator are taken TWICE as large, which leaves the quotient as it is (a power
    * of two scales every product, sum and the rounding of each exactly): 2a and 2c are small integers,
    * nibble r of 0x02242 is 2a (2 4 2 2 0 for r = 0..4), of 0x23220 is 2c (0 2 2 3 2).  Both products as
@@ -404,18 +382,6 @@ FMD_HD float fmd_atan2f_tab_core(float y, float x, const float* tab, bool* need_
   const fmd_v2f nd = fmd_pk_add_cross(ac * qc, ac);
   const float num = nd[0];
   const float den = nd[1]; /* 2, 4+2q, 2q+2, 2+3q or 2q: within [0.875, 2^26] */
-#else
-  /* nibble r of 0x01121 is a (1 2 1 1 0 for r = 0..4), of 0x23220 is 2c (0 2 2 3 2) */
-#if defined(__HIP_DEVICE_COMPILE__)
-  const float ca = (float)__builtin_amdgcn_ubfe(0x01121u, 4u * (unsigned)r, 4u);
-  const float cc = (float)__builtin_amdgcn_ubfe(0x23220u, 4u * (unsigned)r, 4u) * 0.5f;
-#else
-  const float ca = (float)((0x01121u >> (4u * (unsigned)r)) & 0xfu);
-  const float cc = (float)((0x23220u >> (4u * (unsigned)r)) & 0xfu) * 0.5f;
-#endif
-  const float num = ca * qc + (-cc);
-  const float den = cc * qc + ca; /* 1, 2+q, q+1, 1+1.5q or q: within [0.4375, 2^25] */
-#endif
   const float xr = fmd_div_midrange(num, den);
   const float z = xr * xr;
   const float w = z * z;
@@ -457,7 +423,6 @@ FMD_HD void fmd_sincos_tab(float phase, const double* tab /* [1024][2] */, struc
                            float* s, float* c)
 {
   const double x = (double)phase;
-#if FMD_OPT_MAGIC
   /* k = x / h rounded to an integer, as the low word of x / h + 1.5 * 2^52 (one operation instead
    * of multiply, round, convert; |x / h| < 2^31) */
   const double magic = 6755399441055744.0;
@@ -466,10 +431,6 @@ FMD_HD void fmd_sincos_tab(float phase, const double* tab /* [1024][2] */, struc
   uint64_t ttu;
   memcpy(&ttu, &tt, 8);
   const int k = (int)(uint32_t)ttu;
-#else
-  const double kf = __builtin_rint(x * t.inv_h);
-  const int k = (int)kf;
-#endif
   double r = __builtin_fma(-kf, t.h_hi, x);
   r = __builtin_fma(-kf, t.h_lo, r);
   const double S = tab[2 * (k & (FMD_SINCOS_TAB_SIZE - 1))];
@@ -490,8 +451,23 @@ FMD_HD void fmd_sincos_tab(float phase, const double* tab /* [1024][2] */, struc
  * operations and one conversion instead of a conversion and five double operations, and r carries no
  * error at all.  The two NCOs of the serial stage keep their phase in [0, 2 pi] (FmDecode.cpp:404-407,
  * :215-216).  NaN / infinite phases give NaN like fsincos; the table index is masked. */
+/* x * a + b with two constants that are no inline literals: as ONE instruction, a in a scalar
+ * register pair and b in a vector one (the compiler's choice is a register copy plus a two-operand
+ * multiply-add; in loops whose cost is their instruction count that is one too many) */
+FMD_HD double fmd_fma_const(double x, double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(a), "v"(b));
+  return r;
+#else
+  return __builtin_fma(x, a, b);
+#endif
+}
+
 #define FMD_SINCOS_P256_SIZE 2048
-FMD_HD void fmd_sincos_p256(float phase, const double* tab /* [2048][2] */, float* s, float* c)
+/* m16 = -1 / 6: passed in so that a loop can keep it in a vector register (see fmd_fma_const) */
+FMD_HD void fmd_sincos_p256k(float phase, const double* tab /* [2048][2] */, double m16, float* s, float* c)
 {
   const float big = 49152.0f;
   const float t = phase + big;
@@ -501,12 +477,16 @@ FMD_HD void fmd_sincos_p256(float phase, const double* tab /* [2048][2] */, floa
   const double S = tab[2 * k];
   const double C = tab[2 * k + 1];
   const double r2 = r * r;
-  const double sr = __builtin_fma(r * r2, __builtin_fma(r2, 1.0 / 120.0, -1.0 / 6.0), r);
+  const double sr = __builtin_fma(r * r2, fmd_fma_const(r2, 1.0 / 120.0, m16), r);
   const double cm1 = r2 * __builtin_fma(r2, 1.0 / 24.0, -0.5);
   const double so = S + __builtin_fma(C, sr, S * cm1);
   const double co = C + __builtin_fma(-S, sr, C * cm1);
   *s = (float)so;
   *c = (float)co;
+}
+FMD_HD void fmd_sincos_p256(float phase, const double* tab /* [2048][2] */, float* s, float* c)
+{
+  fmd_sincos_p256k(phase, tab, -1.0 / 6.0, s, c);
 }
 
 /* RDSProcess.cpp:187-217 */

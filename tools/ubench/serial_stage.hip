@@ -105,7 +105,7 @@ int main(int argc, char** argv)
   CK(hipMalloc(&d_r, size_t(4) * CP * 2));
   CK(hipMemset(d_f, 0, size_t(fmd::F_SLOTS) * CP * 4));
   CK(hipMemset(d_i, 0, size_t(fmd::I_SLOTS) * CP * 4));
-  const std::vector<double>& tab = FMD_OPT_P256 ? d.sincos_tab256 : d.sincos_tab;
+  const std::vector<double>& tab = d.sincos_tab256;
   CK(hipMalloc(&d_tab, tab.size() * 8));
   CK(hipMemcpy(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&d_probe, size_t(3) * (CP / 64) * 8));
