@@ -255,6 +255,9 @@ def main():
     shared = False
     if args.workload == "config5":
         FS, D, order = 10e6, 46, 4096
+        if os.environ.get("FMD_BENCH_GEOM"):  # dev aid: "fs,D,order" -- the other long-filter window layouts
+            g = os.environ["FMD_BENCH_GEOM"].split(",")
+            FS, D, order = float(g[0]), int(g[1]), int(g[2])
         if args.channels == 8192:
             args.channels = 4096
     elif args.workload == "config3":
@@ -644,8 +647,10 @@ def main():
                            "full ProcessStream path" % C,
                 "config3": "BASELINE configs[2]: %d channels freq-shifted from ONE shared 2.4 MS/s "
                            "capture (table_size 256), full ProcessStream path" % C,
-                "config5": "BASELINE configs[4]: %d channels @10 MS/s, D=46, 4096-tap IF FIR, full "
-                           "ProcessStream path" % C}[args.workload]
+                "config5": ("BASELINE configs[4]: %d channels @10 MS/s, D=46, 4096-tap IF FIR, full "
+                            "ProcessStream path" % C) if not os.environ.get("FMD_BENCH_GEOM") else
+                           ("dev geometry %d channels @%.3g MS/s, D=%d, %d-tap IF FIR" % (C, FS / 1e6, D, order))}[
+                               args.workload]
                 + (" -- input as RTL-SDR u8 byte pairs, ReadAsyncCB conversion fused into the IF "
                    "kernel (SURVEY 8(f)-2; not the BASELINE metric's input format)" if u8 else ""),
                        "input_format": args.input,

@@ -808,7 +808,7 @@ using FirFn = void (*)(const typename IN::elem*, size_t, unsigned, const float2*
                        unsigned, unsigned, const float*, unsigned, unsigned, unsigned, unsigned, float2*,
                        unsigned, unsigned, unsigned);
 
-template <class IN, int TILE, int E>
+template <class IN, int TILE, int E, bool RB128 = false>
 int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
                       unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
                       hipEvent_t ev_start, hipEvent_t ev_stop)
@@ -817,12 +817,14 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   const unsigned C = b->C, D = d.D, T = d.table_size;
   const unsigned ntiles = (M + TILE - 1) / TILE;
   // 2^E regions of ((TILE-1)*D + order + slack) >> E slots each (see k_if_fir)
-  const size_t region = ((size_t(TILE - 1) * D + d.if_order + 2u * (1u << E) + 2u) >> E) + 1u;
-  // long filter in the two-region window: one workgroup per CU, hand-scheduled tap loop
-  // (k_if_fir LONGASM)
-  const bool longasm = TILE == 256 && (E == 1 || (E == 0 && D % 4 == 2)) && d.if_order >= 512;
-  // + 32 slots in front of the plain window for the b128 tap loop's dummy prefetch (k_if_fir WIN_PAD)
-  const size_t lds = (region << E) * sizeof(float2) + (longasm && E == 0 ? 32 * sizeof(float2) : 0);
+  // (+ 1: the regions of the 16-byte-read form are rounded up to an even size)
+  const size_t region = ((size_t(TILE - 1) * D + d.if_order + 2u * (1u << E) + 2u) >> E) + 2u;
+  // long filter: one workgroup per CU, hand-scheduled tap loop for every window layout (k_if_fir
+  // LONGASM: plain window read 16 bytes at a time for D = 2 * odd, 8 bytes at a time for odd D, and
+  // the two- and four-region windows)
+  const bool longasm = TILE == 256 && d.if_order >= 512;
+  // + 32 slots in front of the window for the tap loops' dummy last prefetch (k_if_fir WIN_PAD)
+  const size_t lds = (region << E) * sizeof(float2) + (longasm ? 32 * sizeof(float2) : 0);
   if (lds > 160 * 1024)
     return fail(FMD_ERR_ARG, "IF filter window does not fit in LDS");
   // fast staging: the tuner table is a power of two that divides a tile's sample span, so a lane
@@ -838,7 +840,7 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
         : rounds <= 7 ? &fmd::k_if_fir<IN, TILE, 7, true, E>
                       : &fmd::k_if_fir<IN, TILE, 8, true, E>;
   if (pow2 && longasm)
-    kfn = &fmd::k_if_fir<IN, TILE, 8, true, E, TILE == 256 && (E == 1 || E == 0)>;
+    kfn = &fmd::k_if_fir<IN, TILE, 8, true, E, TILE == 256, false, TILE == 256 && RB128 && (E >= 1)>;
   // opt-in shuffle-reduced tap sum (not bit-exact): headline window layout only
   const bool shfl = b->params.fir_reduction == 1 && TILE == 64 && E == 0 && pow2 && rounds <= 8;
   if (shfl)
@@ -908,6 +910,22 @@ int launch_if_stage_e(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
     if (b128 && TILE == 256 && b->des.if_order >= 512 && pow2)
       return launch_if_stage_t<IN, TILE, 0>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
     return launch_if_stage_t<IN, TILE, 1>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
+  }
+  { // D = 4 * odd and above.  Long filters: one region fewer than the power of two in D asks for, so
+    // that the lane stride inside a region stays EVEN and two adjacent positions come with one
+    // 16-byte read (fir_long_e1_b128_asm / fir_long_e2_b128_asm); FMD_FIR_B128=0 keeps the 8-byte reads
+    // of the four-region window (fir_long_e2_asm).  Short filters: four regions (odd stride for 4 * odd).
+    static const int b128 = getenv("FMD_FIR_B128") ? atoi(getenv("FMD_FIR_B128")) : 1;
+    const unsigned T = b->des.table_size;
+    const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
+    if (b128 && TILE == 256 && b->des.if_order >= 512 && pow2)
+    {
+      if (D % 8 != 0)
+        return launch_if_stage_t<IN, TILE, 1, true>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start,
+                                                    ev_stop);
+      return launch_if_stage_t<IN, TILE, 2, true>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start,
+                                                  ev_stop);
+    }
   }
   return launch_if_stage_t<IN, TILE, 2>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
 }

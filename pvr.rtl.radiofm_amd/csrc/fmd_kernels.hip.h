@@ -176,7 +176,7 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
  * current batch in region 1 / region 0 (region 1 holds the first tap of every pair); klo / khi is
  * the address of the batch's first tap; cnt counts pairs of batches (32 taps each, >= 1).  The last
  * batch load is a dummy: it reads 16 taps past the table (the buffer is padded) and 8 positions
- * below the window (LDS reads outside the allocation return zero).  Measured (4096 taps, D = 46):
+ * below the last batch (region 0's lie in the 32 slots the kernel keeps in front of the window).  Measured (4096 taps, D = 46):
  * 3.5 ms per launch against 5.8 ms for the compiler-scheduled loop; the LDS array delivers
  * ~110 B/clk/CU here, i.e. the loop is LDS-bandwidth-bound (a variant with the tap table in LDS
  * too: 4.1 ms).  Body generated by tools/gen_fir_long_asm.py. */
@@ -310,6 +310,553 @@ __device__ __forceinline__ void fir_long_e1_asm(fmd_f2v& acc2, unsigned& a1, uns
         "v135", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
         "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",
         "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "scc", "memory");
+}
+
+/* The same loop for the plain window and an ODD decimation (G = 1 of tools/gen_fir_long_asm.py): the 16
+ * taps of a batch are 16 consecutive slots, read two at a time with ds_read2_b64 -- a 16-byte read
+ * would be misaligned for every other lane (the lanes sit D slots apart).  a0 = LDS byte address of
+ * tap j + 15 (the batch's lowest slot). */
+__device__ __forceinline__ void fir_long_odd_asm(fmd_f2v& acc2, unsigned& a0, unsigned klo, unsigned khi,
+                                                 unsigned& cnt)
+{
+  asm volatile(
+      "s_mov_b32 s72, %3\n\t"
+      "s_mov_b32 s73, %4\n\t"
+      "s_load_dwordx16 s[40:55], s[72:73], 0x0\n\t"
+      "ds_read2_b64 v[64:67], %1 offset0:15 offset1:14\n\t"
+      "ds_read2_b64 v[68:71], %1 offset0:13 offset1:12\n\t"
+      "ds_read2_b64 v[72:75], %1 offset0:11 offset1:10\n\t"
+      "ds_read2_b64 v[76:79], %1 offset0:9 offset1:8\n\t"
+      "ds_read2_b64 v[80:83], %1 offset0:7 offset1:6\n\t"
+      "ds_read2_b64 v[84:87], %1 offset0:5 offset1:4\n\t"
+      "ds_read2_b64 v[88:91], %1 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[92:95], %1 offset0:1\n\t"
+      "v_subrev_u32 %1, 128, %1\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "1:\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[56:71], s[72:73], 0x0\n\t"
+      "ds_read2_b64 v[96:99], %1 offset0:15 offset1:14\n\t"
+      "ds_read2_b64 v[100:103], %1 offset0:13 offset1:12\n\t"
+      "ds_read2_b64 v[104:107], %1 offset0:11 offset1:10\n\t"
+      "ds_read2_b64 v[108:111], %1 offset0:9 offset1:8\n\t"
+      "ds_read2_b64 v[112:115], %1 offset0:7 offset1:6\n\t"
+      "ds_read2_b64 v[116:119], %1 offset0:5 offset1:4\n\t"
+      "ds_read2_b64 v[120:123], %1 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[124:127], %1 offset0:1\n\t"
+      "v_subrev_u32 %1, 128, %1\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "v_pk_mul_f32 v[128:129], v[64:65], s[40:41] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 v[130:131], v[66:67], s[40:41] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[68:69], s[42:43] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[70:71], s[42:43] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[72:73], s[44:45] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[74:75], s[44:45] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[76:77], s[46:47] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[78:79], s[46:47] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[80:81], s[48:49] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[82:83], s[48:49] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[84:85], s[50:51] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[86:87], s[50:51] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[88:89], s[52:53] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[90:91], s[52:53] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[92:93], s[54:55] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[94:95], s[54:55] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[40:55], s[72:73], 0x0\n\t"
+      "ds_read2_b64 v[64:67], %1 offset0:15 offset1:14\n\t"
+      "ds_read2_b64 v[68:71], %1 offset0:13 offset1:12\n\t"
+      "ds_read2_b64 v[72:75], %1 offset0:11 offset1:10\n\t"
+      "ds_read2_b64 v[76:79], %1 offset0:9 offset1:8\n\t"
+      "ds_read2_b64 v[80:83], %1 offset0:7 offset1:6\n\t"
+      "ds_read2_b64 v[84:87], %1 offset0:5 offset1:4\n\t"
+      "ds_read2_b64 v[88:91], %1 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[92:95], %1 offset0:1\n\t"
+      "v_subrev_u32 %1, 128, %1\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "v_pk_mul_f32 v[128:129], v[96:97], s[56:57] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 v[130:131], v[98:99], s[56:57] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[100:101], s[58:59] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[102:103], s[58:59] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[104:105], s[60:61] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[106:107], s[60:61] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[108:109], s[62:63] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[110:111], s[62:63] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[112:113], s[64:65] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[114:115], s[64:65] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[116:117], s[66:67] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[118:119], s[66:67] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[120:121], s[68:69] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[122:123], s[68:69] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[124:125], s[70:71] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[126:127], s[70:71] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "s_sub_u32 %2, %2, 1\n\t"
+      "s_cmp_lg_u32 %2, 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      : "+v"(acc2), "+v"(a0), "+s"(cnt)
+      : "s"(klo), "s"(khi)
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76",
+        "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89",
+        "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101",
+        "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
+        "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+        "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134",
+        "v135", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+        "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",
+        "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "scc", "memory"
+  );
+}
+
+/* And for the four-region window (D = 4 * odd and higher powers of two; G = 4): tap j + s sits in region
+ * 3 - s, a batch takes four consecutive positions from each region.  a3 .. a0 = LDS byte address of the
+ * lowest of them in region 3 .. 0. */
+__device__ __forceinline__ void fir_long_e2_asm(fmd_f2v& acc2, unsigned& a3, unsigned& a2, unsigned& a1,
+                                                unsigned& a0, unsigned klo, unsigned khi, unsigned& cnt)
+{
+  asm volatile(
+      "s_mov_b32 s72, %6\n\t"
+      "s_mov_b32 s73, %7\n\t"
+      "s_load_dwordx16 s[40:55], s[72:73], 0x0\n\t"
+      "ds_read2_b64 v[64:67], %1 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[68:71], %1 offset0:1\n\t"
+      "ds_read2_b64 v[72:75], %2 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[76:79], %2 offset0:1\n\t"
+      "ds_read2_b64 v[80:83], %3 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[84:87], %3 offset0:1\n\t"
+      "ds_read2_b64 v[88:91], %4 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[92:95], %4 offset0:1\n\t"
+      "v_subrev_u32 %1, 32, %1\n\t"
+      "v_subrev_u32 %2, 32, %2\n\t"
+      "v_subrev_u32 %3, 32, %3\n\t"
+      "v_subrev_u32 %4, 32, %4\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "1:\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[56:71], s[72:73], 0x0\n\t"
+      "ds_read2_b64 v[96:99], %1 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[100:103], %1 offset0:1\n\t"
+      "ds_read2_b64 v[104:107], %2 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[108:111], %2 offset0:1\n\t"
+      "ds_read2_b64 v[112:115], %3 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[116:119], %3 offset0:1\n\t"
+      "ds_read2_b64 v[120:123], %4 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[124:127], %4 offset0:1\n\t"
+      "v_subrev_u32 %1, 32, %1\n\t"
+      "v_subrev_u32 %2, 32, %2\n\t"
+      "v_subrev_u32 %3, 32, %3\n\t"
+      "v_subrev_u32 %4, 32, %4\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "v_pk_mul_f32 v[128:129], v[64:65], s[40:41] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 v[130:131], v[72:73], s[40:41] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[80:81], s[42:43] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[88:89], s[42:43] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[66:67], s[44:45] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[74:75], s[44:45] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[82:83], s[46:47] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[90:91], s[46:47] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[68:69], s[48:49] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[76:77], s[48:49] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[84:85], s[50:51] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[92:93], s[50:51] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[70:71], s[52:53] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[78:79], s[52:53] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[86:87], s[54:55] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[94:95], s[54:55] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[40:55], s[72:73], 0x0\n\t"
+      "ds_read2_b64 v[64:67], %1 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[68:71], %1 offset0:1\n\t"
+      "ds_read2_b64 v[72:75], %2 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[76:79], %2 offset0:1\n\t"
+      "ds_read2_b64 v[80:83], %3 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[84:87], %3 offset0:1\n\t"
+      "ds_read2_b64 v[88:91], %4 offset0:3 offset1:2\n\t"
+      "ds_read2_b64 v[92:95], %4 offset0:1\n\t"
+      "v_subrev_u32 %1, 32, %1\n\t"
+      "v_subrev_u32 %2, 32, %2\n\t"
+      "v_subrev_u32 %3, 32, %3\n\t"
+      "v_subrev_u32 %4, 32, %4\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "v_pk_mul_f32 v[128:129], v[96:97], s[56:57] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 v[130:131], v[104:105], s[56:57] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[112:113], s[58:59] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[120:121], s[58:59] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[98:99], s[60:61] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[106:107], s[60:61] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[114:115], s[62:63] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[122:123], s[62:63] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[100:101], s[64:65] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[108:109], s[64:65] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[116:117], s[66:67] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[124:125], s[66:67] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[102:103], s[68:69] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[110:111], s[68:69] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[118:119], s[70:71] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[126:127], s[70:71] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "s_sub_u32 %5, %5, 1\n\t"
+      "s_cmp_lg_u32 %5, 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      : "+v"(acc2), "+v"(a3), "+v"(a2), "+v"(a1), "+v"(a0), "+s"(cnt)
+      : "s"(klo), "s"(khi)
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76",
+        "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89",
+        "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101",
+        "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
+        "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+        "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134",
+        "v135", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+        "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",
+        "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "scc", "memory"
+  );
+}
+
+/* The region forms with ds_read_b128 (tools/gen_fir_long_asm.py G b128): two adjacent positions of a
+ * region per LDS instruction at twice the rate of ds_read2_b64.  Every lane's pair has to sit on a
+ * 16-byte boundary: lane stride inside a region even, region size even, lowest position of the batch
+ * even -- the two-region window for D = 4 * odd, the four-region window for D = 8 * odd. */
+__device__ __forceinline__ void fir_long_e1_b128_asm(fmd_f2v& acc2, unsigned& a1, unsigned& a0, unsigned klo,
+                                                     unsigned khi, unsigned& cnt)
+{
+  asm volatile(
+      "s_mov_b32 s72, %4\n\t"
+      "s_mov_b32 s73, %5\n\t"
+      "s_load_dwordx16 s[40:55], s[72:73], 0x0\n\t"
+      "ds_read_b128 v[64:67], %1 offset:48\n\t"
+      "ds_read_b128 v[68:71], %1 offset:32\n\t"
+      "ds_read_b128 v[72:75], %1 offset:16\n\t"
+      "ds_read_b128 v[76:79], %1 offset:0\n\t"
+      "ds_read_b128 v[80:83], %2 offset:48\n\t"
+      "ds_read_b128 v[84:87], %2 offset:32\n\t"
+      "ds_read_b128 v[88:91], %2 offset:16\n\t"
+      "ds_read_b128 v[92:95], %2 offset:0\n\t"
+      "v_subrev_u32 %1, 64, %1\n\t"
+      "v_subrev_u32 %2, 64, %2\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "1:\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[56:71], s[72:73], 0x0\n\t"
+      "ds_read_b128 v[96:99], %1 offset:48\n\t"
+      "ds_read_b128 v[100:103], %1 offset:32\n\t"
+      "ds_read_b128 v[104:107], %1 offset:16\n\t"
+      "ds_read_b128 v[108:111], %1 offset:0\n\t"
+      "ds_read_b128 v[112:115], %2 offset:48\n\t"
+      "ds_read_b128 v[116:119], %2 offset:32\n\t"
+      "ds_read_b128 v[120:123], %2 offset:16\n\t"
+      "ds_read_b128 v[124:127], %2 offset:0\n\t"
+      "v_subrev_u32 %1, 64, %1\n\t"
+      "v_subrev_u32 %2, 64, %2\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "v_pk_mul_f32 v[128:129], v[66:67], s[40:41] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 v[130:131], v[82:83], s[40:41] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[64:65], s[42:43] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[80:81], s[42:43] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[70:71], s[44:45] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[86:87], s[44:45] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[68:69], s[46:47] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[84:85], s[46:47] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[74:75], s[48:49] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[90:91], s[48:49] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[72:73], s[50:51] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[88:89], s[50:51] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[78:79], s[52:53] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[94:95], s[52:53] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[76:77], s[54:55] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[92:93], s[54:55] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[40:55], s[72:73], 0x0\n\t"
+      "ds_read_b128 v[64:67], %1 offset:48\n\t"
+      "ds_read_b128 v[68:71], %1 offset:32\n\t"
+      "ds_read_b128 v[72:75], %1 offset:16\n\t"
+      "ds_read_b128 v[76:79], %1 offset:0\n\t"
+      "ds_read_b128 v[80:83], %2 offset:48\n\t"
+      "ds_read_b128 v[84:87], %2 offset:32\n\t"
+      "ds_read_b128 v[88:91], %2 offset:16\n\t"
+      "ds_read_b128 v[92:95], %2 offset:0\n\t"
+      "v_subrev_u32 %1, 64, %1\n\t"
+      "v_subrev_u32 %2, 64, %2\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "v_pk_mul_f32 v[128:129], v[98:99], s[56:57] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 v[130:131], v[114:115], s[56:57] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[96:97], s[58:59] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[112:113], s[58:59] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[102:103], s[60:61] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[118:119], s[60:61] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[100:101], s[62:63] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[116:117], s[62:63] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[106:107], s[64:65] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[122:123], s[64:65] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[104:105], s[66:67] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[120:121], s[66:67] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[110:111], s[68:69] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[126:127], s[68:69] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[108:109], s[70:71] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[124:125], s[70:71] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "s_sub_u32 %3, %3, 1\n\t"
+      "s_cmp_lg_u32 %3, 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      : "+v"(acc2), "+v"(a1), "+v"(a0), "+s"(cnt)
+      : "s"(klo), "s"(khi)
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76",
+        "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89",
+        "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101",
+        "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
+        "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+        "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134",
+        "v135", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+        "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",
+        "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "scc", "memory"
+  );
+}
+__device__ __forceinline__ void fir_long_e2_b128_asm(fmd_f2v& acc2, unsigned& a3, unsigned& a2, unsigned& a1,
+                                                     unsigned& a0, unsigned klo, unsigned khi, unsigned& cnt)
+{
+  asm volatile(
+      "s_mov_b32 s72, %6\n\t"
+      "s_mov_b32 s73, %7\n\t"
+      "s_load_dwordx16 s[40:55], s[72:73], 0x0\n\t"
+      "ds_read_b128 v[64:67], %1 offset:16\n\t"
+      "ds_read_b128 v[68:71], %1 offset:0\n\t"
+      "ds_read_b128 v[72:75], %2 offset:16\n\t"
+      "ds_read_b128 v[76:79], %2 offset:0\n\t"
+      "ds_read_b128 v[80:83], %3 offset:16\n\t"
+      "ds_read_b128 v[84:87], %3 offset:0\n\t"
+      "ds_read_b128 v[88:91], %4 offset:16\n\t"
+      "ds_read_b128 v[92:95], %4 offset:0\n\t"
+      "v_subrev_u32 %1, 32, %1\n\t"
+      "v_subrev_u32 %2, 32, %2\n\t"
+      "v_subrev_u32 %3, 32, %3\n\t"
+      "v_subrev_u32 %4, 32, %4\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "1:\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[56:71], s[72:73], 0x0\n\t"
+      "ds_read_b128 v[96:99], %1 offset:16\n\t"
+      "ds_read_b128 v[100:103], %1 offset:0\n\t"
+      "ds_read_b128 v[104:107], %2 offset:16\n\t"
+      "ds_read_b128 v[108:111], %2 offset:0\n\t"
+      "ds_read_b128 v[112:115], %3 offset:16\n\t"
+      "ds_read_b128 v[116:119], %3 offset:0\n\t"
+      "ds_read_b128 v[120:123], %4 offset:16\n\t"
+      "ds_read_b128 v[124:127], %4 offset:0\n\t"
+      "v_subrev_u32 %1, 32, %1\n\t"
+      "v_subrev_u32 %2, 32, %2\n\t"
+      "v_subrev_u32 %3, 32, %3\n\t"
+      "v_subrev_u32 %4, 32, %4\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "v_pk_mul_f32 v[128:129], v[66:67], s[40:41] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 v[130:131], v[74:75], s[40:41] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[82:83], s[42:43] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[90:91], s[42:43] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[64:65], s[44:45] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[72:73], s[44:45] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[80:81], s[46:47] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[88:89], s[46:47] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[70:71], s[48:49] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[78:79], s[48:49] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[86:87], s[50:51] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[94:95], s[50:51] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[68:69], s[52:53] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[76:77], s[52:53] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[84:85], s[54:55] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[92:93], s[54:55] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[40:55], s[72:73], 0x0\n\t"
+      "ds_read_b128 v[64:67], %1 offset:16\n\t"
+      "ds_read_b128 v[68:71], %1 offset:0\n\t"
+      "ds_read_b128 v[72:75], %2 offset:16\n\t"
+      "ds_read_b128 v[76:79], %2 offset:0\n\t"
+      "ds_read_b128 v[80:83], %3 offset:16\n\t"
+      "ds_read_b128 v[84:87], %3 offset:0\n\t"
+      "ds_read_b128 v[88:91], %4 offset:16\n\t"
+      "ds_read_b128 v[92:95], %4 offset:0\n\t"
+      "v_subrev_u32 %1, 32, %1\n\t"
+      "v_subrev_u32 %2, 32, %2\n\t"
+      "v_subrev_u32 %3, 32, %3\n\t"
+      "v_subrev_u32 %4, 32, %4\n\t"
+      "s_add_u32 s72, s72, 64\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "v_pk_mul_f32 v[128:129], v[98:99], s[56:57] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 v[130:131], v[106:107], s[56:57] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[114:115], s[58:59] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[122:123], s[58:59] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[96:97], s[60:61] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[104:105], s[60:61] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[112:113], s[62:63] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[120:121], s[62:63] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[102:103], s[64:65] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[110:111], s[64:65] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[118:119], s[66:67] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[126:127], s[66:67] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "v_pk_mul_f32 v[128:129], v[100:101], s[68:69] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "v_pk_mul_f32 v[130:131], v[108:109], s[68:69] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[128:129]\n\t"
+      "v_pk_mul_f32 v[132:133], v[116:117], s[70:71] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, v[130:131]\n\t"
+      "v_pk_mul_f32 v[134:135], v[124:125], s[70:71] op_sel:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, v[132:133]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_add_f32 %0, %0, v[134:135]\n\t"
+      "s_sub_u32 %5, %5, 1\n\t"
+      "s_cmp_lg_u32 %5, 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      : "+v"(acc2), "+v"(a3), "+v"(a2), "+v"(a1), "+v"(a0), "+s"(cnt)
+      : "s"(klo), "s"(khi)
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76",
+        "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89",
+        "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101",
+        "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
+        "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+        "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134",
+        "v135", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+        "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",
+        "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "scc", "memory"
+  );
 }
 
 /* Long filters in the PLAIN window (E = 0) with D = 2 * odd, two taps per LDS instruction.  With such
@@ -521,7 +1068,8 @@ struct InU8
  * north star describes; it changes the order of the float additions, so its output is NOT
  * bit-identical to the reference's sequential sum (measured against the parity mode in
  * tests/test_gpu_fast_mode.py, figures in DESIGN.md section 3).  Not the default. */
-template <class IN, int TILE, int UNROLL, bool POW2, int E = 0, bool LONGASM = false, bool SHFL = false>
+template <class IN, int TILE, int UNROLL, bool POW2, int E = 0, bool LONGASM = false, bool SHFL = false,
+          bool RB128 = false>
 __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __restrict__ iq,
                                                  size_t chan_stride, unsigned N,
                                                  const float2* __restrict__ hist_in,
@@ -535,12 +1083,15 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
   typedef typename IN::pair pair_t;
   constexpr int G = 1 << E; // regions of the de-interleaved window
   extern __shared__ __attribute__((aligned(16))) float2 smem_win[];
-  // the b128 tap loop's last (dummy) prefetch reaches 16 slots below the window: keep them inside
-  constexpr int WIN_PAD = (LONGASM && E == 0) ? 32 : 0;
+  // the hand-scheduled tap loops' last (dummy) prefetch reaches up to 16 slots below the window (below
+  // region 0 in the de-interleaved layouts): keep them inside the allocation
+  constexpr int WIN_PAD = LONGASM ? 32 : 0;
   float2* const win = smem_win + WIN_PAD;
   __builtin_amdgcn_s_setprio(1); // ahead of the post-chain kernels it may share a SIMD with
   // region size in slots: the window spans (TILE-1)*D + order samples plus alignment slack
-  const unsigned H = (((unsigned)(TILE - 1) * D + order + 2u * G + 2u) >> E) + 1u;
+  // (RB128: even, so that every region starts on a 16-byte boundary)
+  const unsigned H0 = (((unsigned)(TILE - 1) * D + order + 2u * G + 2u) >> E) + 1u;
+  const unsigned H = RB128 ? ((H0 + 1u) & ~1u) : H0;
   auto slot = [&](int i) -> unsigned { // LDS index of window slot i
     return E == 0 ? (unsigned)i : ((unsigned)i & (unsigned)(G - 1)) * H + ((unsigned)i >> E);
   };
@@ -666,7 +1217,21 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
     {
       const float2* w = win + (k_lo - k_al) + tid * D + order; // w[-j] = x[p - j]
       unsigned j = 1;
-      if (b128 && nb128)
+      if (LONGASM && (D & 1u) && order >= 32u)
+      { // odd D: pairs of adjacent slots with ds_read2_b64 (fir_long_odd_asm)
+        unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)(order >> 5));
+        const unsigned taps = cnt << 5;
+        unsigned a0 = (unsigned)(size_t)(w - (int)j - 15); // slot of tap j + 15: the batch's lowest
+        const size_t ka = (size_t)(coeff + j);
+        const unsigned klo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ka);
+        const unsigned khi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ka >> 32));
+        fmd_f2v acc2 = {acc.x, acc.y};
+        fir_long_odd_asm(acc2, a0, klo, khi, cnt);
+        acc.x = acc2.x;
+        acc.y = acc2.y;
+        j += taps;
+      }
+      else if (b128 && nb128)
       {
         if (jb == 2u)
         { // one tap in front of the pairs
@@ -711,7 +1276,44 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
         acc.x += s.x * k;
         acc.y += s.y * k;
       }
-      if (LONGASM && E == 1 && order + 1u - j >= 32u)
+      if (LONGASM && RB128 && E >= 1 && ((((U0 - j) >> E) & 1u) == 0u) && j + (unsigned)G <= order + 1u)
+      { // the 16-byte reads take positions (P - 1, P) with P - 1 even: one round in front when P is even
+        const unsigned P = (U0 - j) >> E;
+#pragma unroll
+        for (int g = 0; g < G; g++)
+        {
+          const float2 s = lanebase[(unsigned)(G - 1 - g) * H + P];
+          const float k = coeff[j + g];
+          acc.x += s.x * k;
+          acc.y += s.y * k;
+        }
+        j += (unsigned)G;
+      }
+      if (LONGASM && RB128 && E >= 1 && order + 1u - j >= 32u)
+      {
+        unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)((order + 1u - j) >> 5));
+        const unsigned taps = cnt << 5;
+        const float2* ptop = lanebase + (unsigned)(G - 1) * H + ((U0 - j) >> E) - (16 / G - 1); // region G-1
+        const size_t ka = (size_t)(coeff + j);
+        const unsigned klo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ka);
+        const unsigned khi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ka >> 32));
+        fmd_f2v acc2 = {acc.x, acc.y};
+        if (E == 1)
+        {
+          unsigned a1 = (unsigned)(size_t)ptop, a0 = (unsigned)(size_t)(ptop - H);
+          fir_long_e1_b128_asm(acc2, a1, a0, klo, khi, cnt);
+        }
+        else
+        {
+          unsigned a3 = (unsigned)(size_t)ptop, a2 = (unsigned)(size_t)(ptop - H),
+                   a1 = (unsigned)(size_t)(ptop - 2u * H), a0 = (unsigned)(size_t)(ptop - 3u * H);
+          fir_long_e2_b128_asm(acc2, a3, a2, a1, a0, klo, khi, cnt);
+        }
+        acc.x = acc2.x;
+        acc.y = acc2.y;
+        j += taps;
+      }
+      if (LONGASM && !RB128 && E == 1 && order + 1u - j >= 32u)
       { // see fir_long_e1_asm; whatever is left after whole pairs of batches continues below
         unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)((order + 1u - j) >> 5));
         const unsigned taps = cnt << 5;
@@ -722,6 +1324,22 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
         const unsigned khi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ka >> 32));
         fmd_f2v acc2 = {acc.x, acc.y};
         fir_long_e1_asm(acc2, a1, a0, klo, khi, cnt);
+        acc.x = acc2.x;
+        acc.y = acc2.y;
+        j += taps;
+      }
+      if (LONGASM && !RB128 && E == 2 && order + 1u - j >= 32u)
+      { // see fir_long_e2_asm: tap j is in region 3 here, four positions per region and batch
+        unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)((order + 1u - j) >> 5));
+        const unsigned taps = cnt << 5;
+        const float2* p3 = lanebase + 3u * H + ((U0 - j) >> 2) - 3; // lowest of the batch's 4 positions
+        unsigned a3 = (unsigned)(size_t)p3, a2 = (unsigned)(size_t)(p3 - H), a1 = (unsigned)(size_t)(p3 - 2u * H),
+                 a0 = (unsigned)(size_t)(p3 - 3u * H);
+        const size_t ka = (size_t)(coeff + j);
+        const unsigned klo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ka);
+        const unsigned khi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ka >> 32));
+        fmd_f2v acc2 = {acc.x, acc.y};
+        fir_long_e2_asm(acc2, a3, a2, a1, a0, klo, khi, cnt);
         acc.x = acc2.x;
         acc.y = acc2.y;
         j += taps;

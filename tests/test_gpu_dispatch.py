@@ -102,6 +102,20 @@ def test_config5_on_its_benchmarked_dispatch(oracle, fmsig, u8):
                     check=[0, 1, 7, 8, 515, 516, 1030, 1031], u8=u8, order=4096)
 
 
+@pytest.mark.parametrize("fs,D,order", [(2.4e6, 11, 2048), (9.6e6, 44, 2048), (1.0e6, 4, 1500),
+                                        (1.4e6, 6, 1024)],
+                         ids=["odd-D", "4x-odd-D", "D4", "2x-odd-D"])
+def test_long_filter_tap_loops_overlapped(oracle, fmsig, fs, D, order):
+    """The hand-scheduled long-filter tap loops of every window layout -- plain window read 8 bytes at a
+    time (odd D: fir_long_odd_asm), four regions (D = 4 * odd, D = 4: fir_long_e2_asm), plain window read 16
+    bytes at a time (D = 2 * odd: fir_long_b128_asm) -- at >= 1024 channels (TILE 256, XCD-aware block
+    mapping, whole-CU serial stage) with overlapped calls and late consumption, on full and ragged
+    blocks (head / tail taps around the 32-tap pairs of batches, first tile out of the history)."""
+    pkg = load_package()
+    _run_overlapped(pkg, fmsig, oracle, fs, D, 1032, [N, 40001, N, 12288],
+                    check=[0, 1, 8, 515, 1024, 1031], u8=False, order=order)
+
+
 @pytest.mark.parametrize("u8", [False, True], ids=["f32", "u8"])
 def test_config4_geometry_overlapped_ragged_two_tile_fir(oracle, fmsig, u8):
     """The headline geometry (2.4 MS/s, D = 11, 88 taps) at >= 1024 channels with overlapped calls:

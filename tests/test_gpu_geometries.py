@@ -190,11 +190,14 @@ def test_eleven_tap_half_band_first_stage(oracle, fmsig, fs, D, sizes):
 
 @pytest.mark.parametrize("fs,D,order,n", [(1.4e6, 6, 1000, 65536), (1.4e6, 6, 520, 33333),
                                          (2.2e6, 10, 2047, 65536), (10e6, 46, 4096, 40000),
-                                         (1.0e6, 4, 600, 65536), (2.4e6, 11, 1000, 65536)])
+                                         (1.0e6, 4, 600, 65536), (2.4e6, 11, 1000, 65536),
+                                         (1.8e6, 8, 1500, 50000), (3.5e6, 16, 1000, 65536),
+                                         (2.6e6, 12, 777, 65536)])
 def test_long_filters_and_even_decimation(oracle, fmsig, fs, D, order, n):
     """Long IF filters through every window layout of k_if_fir: D = 2*odd (two-region window, the
     hand-scheduled tap loop with its head / tail taps around whole 32-tap pairs of batches, first
-    tile out of the history, partial last tile), D = 4*odd (four regions) and odd D (plain).
+    tile out of the history, partial last tile), D = 4*odd (two regions read 16 bytes at a time), D = 8*odd
+    and 16*odd (four regions) and odd D (plain, 8 bytes at a time).
     Float and byte input; FIR output and audio bit for bit."""
     pkg = load_package()
     p = fmsig.default_params(fs, noise_sigma=0.01, seed=31)
