@@ -428,9 +428,6 @@ def main():
         return nf
 
     def drain():
-        # nothing more is coming: the newest call's kept-back light part goes out now, not when the
-        # loop below reaches it (the device would idle through the two synchronisations before it)
-        batch.flush()
         # the last LAG calls one by one, so that every call's groups land in its own record buffer
         while state["finalized"] < state["submitted"]:
             lag = state["submitted"] - (state["finalized"] + 1)

@@ -203,21 +203,16 @@ int fmd_batch_export_rds_device(fmd_batch* b, int32_t* d_records, unsigned cap, 
  *   1  on internal streams, the caller's stream is ordered after each call (default; same
  *      observable semantics as 0)
  *   2  on internal streams and the caller's stream is NOT ordered after the call: the FIR of
- *      call k+1 overlaps the serial stages of call k, and the last part of a call's post chain
- *      (RDS bit recovery, audio tail) is only submitted together with the next call, or when its
- *      results are asked for (fmd_batch_wait / fmd_batch_collect_rds with lag 0, the getters).
- *      The caller must use different audio buffers for calls in flight, keep d_iq and d_audio
- *      valid, and call fmd_batch_wait[_lagged] (or collect_rds) before consuming outputs. */
+ *      call k+1 overlaps the serial stages of call k.  The caller must use different audio buffers
+ *      for calls in flight, keep d_iq and d_audio valid, and call fmd_batch_wait[_lagged] (or
+ *      collect_rds) before consuming outputs. */
 int fmd_batch_set_concurrency(fmd_batch* b, int mode);
 /* Orders `stream` after every call submitted so far (outputs complete, inputs released). */
 int fmd_batch_wait(fmd_batch* b, void* stream);
-/* lag = 1..4: every call except the newest `lag` ones (whose kernels may still be running; the
- * light tail of a call's post chain finishes beside the FIR of the call after next, so a host that
- * must never block consumes outputs three calls late). */
+/* lag = 1..4: every call except the newest `lag` ones (whose kernels may still be running: a call is
+ * complete about 1.3 periods after its serial stage has started, so a host that must never block
+ * consumes outputs two to three calls late). */
 int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream);
-/* Concurrency 2: submits the kept-back tail of the newest call now (nothing is waited for).  For the
- * moment a caller knows that no further call follows soon; wait / collect with lag 0 do the same. */
-int fmd_batch_flush(fmd_batch* b);
 /* 1 if RDS groups were lost since the last report (see FMD_WARN_RDS_LOST; clears the flag), else 0. */
 int fmd_batch_take_rds_lost(fmd_batch* b);
 

@@ -16,13 +16,25 @@
 #include <string.h>
 #include <time.h>
 
+/* Start gate: every thread reports ready and waits for `go`; the caller opens the gate once all
+ * threads it managed to start are ready -- with `run` = 0 when it could not start them all, so that
+ * the ones that exist leave at once and can be joined (a barrier sized for the full count would keep
+ * them waiting for ever). */
+typedef struct
+{
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  unsigned ready;
+  int go, run;
+} start_gate;
+
 typedef struct
 {
   const fmo_params* params;
   const float* blocks; /* nblocks x samples x 2 floats */
   unsigned nblocks, samples;
   double seconds;
-  pthread_barrier_t* start;
+  start_gate* start;
   unsigned long long calls; /* out */
   double elapsed;           /* out: seconds inside this thread's timed loop */
 } bench_job;
@@ -43,11 +55,18 @@ static void* bench_thread(void* arg)
   if (d && audio)
     for (unsigned b = 0; b < 2 && b < j->nblocks; b++) /* warm caches and the PLLs */
       fmo_process_stream(d, j->blocks + stride * b, j->samples, audio);
-  pthread_barrier_wait(j->start); /* all threads enter their timed loops together */
+  int run;
+  pthread_mutex_lock(&j->start->mu);
+  j->start->ready++;
+  pthread_cond_broadcast(&j->start->cv);
+  while (!j->start->go)
+    pthread_cond_wait(&j->start->cv, &j->start->mu);
+  run = j->start->run;
+  pthread_mutex_unlock(&j->start->mu); /* all threads enter their timed loops together */
   unsigned long long n = 0;
   const double t0 = now_s();
   double t = t0;
-  if (d && audio)
+  if (d && audio && run)
     while (t - t0 < j->seconds)
     {
       fmo_process_stream(d, j->blocks + stride * (n % j->nblocks), j->samples, audio);
@@ -73,13 +92,23 @@ double fmo_bench_threads(const fmo_params* p, unsigned threads, double seconds, 
     return 0.0;
   bench_job* jobs = (bench_job*)calloc(threads, sizeof(bench_job));
   pthread_t* th = (pthread_t*)calloc(threads, sizeof(pthread_t));
-  pthread_barrier_t start;
-  if (!jobs || !th || pthread_barrier_init(&start, NULL, threads) != 0)
+  start_gate start;
+  if (!jobs || !th || pthread_mutex_init(&start.mu, NULL) != 0)
   {
     free(jobs);
     free(th);
     return 0.0;
   }
+  if (pthread_cond_init(&start.cv, NULL) != 0)
+  {
+    pthread_mutex_destroy(&start.mu);
+    free(jobs);
+    free(th);
+    return 0.0;
+  }
+  start.ready = 0;
+  start.go = 0;
+  start.run = 0;
   unsigned started = 0;
   for (unsigned i = 0; i < threads; i++)
   {
@@ -95,10 +124,17 @@ double fmo_bench_threads(const fmo_params* p, unsigned threads, double seconds, 
   }
   double rate = 0.0, worst = 0.0;
   unsigned long long calls = 0;
+  /* open the gate when every thread that exists is ready; they only run if all of them exist */
+  pthread_mutex_lock(&start.mu);
+  while (start.ready < started)
+    pthread_cond_wait(&start.cv, &start.mu);
+  start.run = started == threads;
+  start.go = 1;
+  pthread_cond_broadcast(&start.cv);
+  pthread_mutex_unlock(&start.mu);
+  for (unsigned i = 0; i < started; i++)
+    pthread_join(th[i], NULL);
   if (started == threads)
-  {
-    for (unsigned i = 0; i < threads; i++)
-      pthread_join(th[i], NULL);
     for (unsigned i = 0; i < threads; i++)
     {
       if (jobs[i].elapsed > 0)
@@ -107,15 +143,8 @@ double fmo_bench_threads(const fmo_params* p, unsigned threads, double seconds, 
       if (jobs[i].elapsed > worst)
         worst = jobs[i].elapsed;
     }
-  }
-  else
-  { /* could not start every thread: release the ones waiting at the barrier is impossible without
-       them all -- detach and report failure (never seen; thread counts here are <= 512) */
-    for (unsigned i = 0; i < started; i++)
-      pthread_detach(th[i]);
-  }
-  if (started == threads)
-    pthread_barrier_destroy(&start);
+  pthread_cond_destroy(&start.cv);
+  pthread_mutex_destroy(&start.mu);
   if (total_calls)
     *total_calls = calls;
   if (max_elapsed)

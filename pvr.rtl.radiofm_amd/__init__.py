@@ -111,7 +111,7 @@ EXPORTS = [
     "fmd_batch_set_debug_taps", "fmd_batch_set_profiling", "fmd_batch_get_stage_ms", "fmd_stage_name", "fmd_last_error",
     "fmd_version", "fmd_group_decoder_create", "fmd_group_decoder_destroy",
     "fmd_group_decoder_reset", "fmd_group_decoder_push", "fmd_uecp_stuff_frame",
-    "fmd_batch_flush", "fmd_batch_take_rds_lost", "fmd_batch_status_call_index",
+    "fmd_batch_take_rds_lost", "fmd_batch_status_call_index",
     "fmd_batch_debug_set_spin_limit", "fmd_batch_debug_timeline",
 ]
 
@@ -197,7 +197,6 @@ def lib():
         L.fmd_group_decoder_reset.argtypes = [vp]
         L.fmd_group_decoder_push.argtypes = [vp, vp]
         L.fmd_uecp_stuff_frame.argtypes = [vp, u, vp, u]
-        L.fmd_batch_flush.argtypes = [vp]
         L.fmd_batch_take_rds_lost.argtypes = [vp]
         L.fmd_batch_status_call_index.argtypes = [vp, u, C.POINTER(C.c_uint32)]
         L.fmd_batch_debug_set_spin_limit.argtypes = [vp, u]
@@ -350,10 +349,6 @@ class Batch:
     def wait(self, stream=None, lag=0):
         """Returns True when RDS groups were lost since the last report (FMD_WARN_RDS_LOST)."""
         return _check(lib().fmd_batch_wait_lagged(self._h, lag, stream)) == FMD_WARN_RDS_LOST
-
-    def flush(self):
-        """Concurrency 2: submit the kept-back tail of the newest call now (fmd_batch_flush)."""
-        _check(lib().fmd_batch_flush(self._h))
 
     def take_rds_lost(self):
         return bool(_check(lib().fmd_batch_take_rds_lost(self._h)))

@@ -171,21 +171,20 @@ struct fmd_batch
   // The two heavy chains behind the serial stage -- RDS decimator (bandwidth-bound) and resampler +
   // audio low-pass (issue-bound) -- side by side on s_post and s_aud instead of one after the other
   bool heavy_par = false;
-  // The light part of a call's post chain (RDS PLL, matched filter, bit recovery, audio tail), kept
-  // back until the next call is submitted (or its results are asked for): see process_device_impl.
+  // What the light part of a call's post chain (RDS PLL, matched filter, bit recovery, audio tail)
+  // needs to know about its call: see launch_light.
   struct LightJob
   {
-    bool pending = false;
     unsigned R = 0, A = 0, mf_g = 0;
     int q = 0, es = 0, sq = 0;
     uint32_t call_index = 0;
     float* d_audio = nullptr;
     size_t audio_stride = 0;
     hipEvent_t tl0 = nullptr, tl1 = nullptr; // profiling level 1: the audio tail's own start / stop
-  } light_job;
+  };
   bool split_post = false;
   bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
-  enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_HEAVY_A, EV_N };
+  enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_HEAVY_A, EV_RDSH, EV_N };
   hipEvent_t cev[NSLOT][EV_N] = {};
   bool cev_ready = false;
   uint32_t slot_call[NSLOT] = {}; // call index that last used the slot (0 = never)
@@ -200,6 +199,7 @@ struct fmd_batch
   bool failed = false;
   std::string fail_msg;
   unsigned spin_limit = 1u << 20; // fmd_batch_debug_set_spin_limit
+  bool if_dry_run = false;        // launch_if_stage stops behind its feasibility checks
   // Status snapshot in host-mapped memory, written by the last kernel of every call
   // (fmd::HostStatusWord): what the getters read -- no device call, no batch bookkeeping touched,
   // so they are safe from any thread while another one is inside a process call.
@@ -408,7 +408,10 @@ int zero_rows(T* p, size_t rows, size_t CP)
  * clears the demod/RDS recurrences and re-initialises the three RDS filters; leaves tuner index,
  * FIR/resampler histories, pilot PLL, half-band histories, oscillator, de-emphasis, notch,
  * audio LPF and the block-sync shift register untouched, like the reference. */
-void flush_light(fmd_batch* b);
+template <class IN>
+int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
+                    unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
+                    hipEvent_t ev_start, hipEvent_t ev_stop);
 
 int do_reset(fmd_batch* b)
 {
@@ -722,7 +725,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     // created: every extra stream competes for the few hardware queues (GPU_MAX_HW_QUEUES)
     b->heavy_par = getenv("FMD_HEAVY_PAR") ? atoi(getenv("FMD_HEAVY_PAR")) != 0 : false;
     const int nstreams = b->heavy_par ? 5 : 4;
-    // (the light chain's stream at the high priority too: measured, no difference)
+    // (the light chain's stream at the high priority too: measured twice, no difference)
     const int prio[5] = {hi, hi, lo, lo, lo};
     hipStream_t st4[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (pick_independent_streams(nstreams, prio, st4) != 0)
@@ -754,14 +757,22 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   b->cev_ready = true;
   HIPCHK(hipDeviceSynchronize());
+  { // can the IF stage of this geometry be launched at all (window in LDS)?  Decided here, once: a
+    // process call is then never refused half-way for it
+    b->if_dry_run = true;
+    const std::function<void(int)> nomark = [](int) {};
+    const int rc = launch_if_stage<fmd::InF32>(b.get(), nullptr, 0, FMD_MAX_BLOCK, 0, b->Mmax - 1, 0, nullptr, nomark,
+                                              nullptr, nullptr);
+    b->if_dry_run = false;
+    if (rc != FMD_OK)
+      return rc;
+  }
   *out = b.release();
   return FMD_OK;
 }
 
 void fmd_batch_destroy(fmd_batch* b)
 {
-  if (b && b->light_job.pending)
-    flush_light(b);
   delete b;
 }
 
@@ -770,7 +781,6 @@ int fmd_batch_reset(fmd_batch* b)
   if (!b)
     return fail(FMD_ERR_ARG, "null batch");
   HIPCHK(hipSetDevice(b->device));
-  flush_light(b);
   HIPCHK(hipDeviceSynchronize());
   if (do_reset(b))
     return fail(FMD_ERR_DEVICE, "state reset failed");
@@ -827,6 +837,8 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   const size_t lds = (region << E) * sizeof(float2) + (longasm ? 32 * sizeof(float2) : 0);
   if (lds > 160 * 1024)
     return fail(FMD_ERR_ARG, "IF filter window does not fit in LDS");
+  if (b->if_dry_run) // fmd_batch_create: only whether this geometry can be launched at all
+    return FMD_OK;
   // fast staging: the tuner table is a power of two that divides a tile's sample span, so a lane
   // needs the same two table entries for every load (all reference configurations: T = 64)
   const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
@@ -1008,6 +1020,10 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
   }
   if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_RDS], s) != hipSuccess)
     mark_failed(b, "hipEventRecord failed behind the RDS part of a call");
+  // the RDS part above only needed the RDS half of the call's heavy part (EV_RDSH, waited for by the
+  // caller); the audio tail needs the other half too
+  if (record && hipStreamWaitEvent(s, b->cev[j.es][fmd_batch::EV_HEAVY], 0) != hipSuccess)
+    mark_failed(b, "hipStreamWaitEvent failed in front of the audio tail of a call");
   {
     fmd::AudioConsts k{};
     k.de_alpha = d.de_alpha;
@@ -1026,18 +1042,6 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
   }
   if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_AUD], s) != hipSuccess)
     mark_failed(b, "hipEventRecord failed behind the audio tail of a call");
-}
-
-/* Submits a kept-back light part now (its results are wanted, or the batch changes mode). */
-void flush_light(fmd_batch* b)
-{
-  if (!b->light_job.pending)
-    return;
-  const fmd_batch::LightJob j = b->light_job;
-  b->light_job.pending = false;
-  if (hipStreamWaitEvent(b->s_rds, b->cev[j.es][fmd_batch::EV_HEAVY], 0) != hipSuccess)
-    mark_failed(b, "hipStreamWaitEvent failed in front of the light part of a call");
-  launch_light(b, j, b->s_rds, true);
 }
 
 enum IqFormat
@@ -1142,8 +1146,6 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   const bool have_prev2 = ci > 2;
   hipEvent_t* pe2 = b->cev[(ci + fmd_batch::NSLOT - 2) % fmd_batch::NSLOT];
   const bool serial_mode = b->concurrency == 0 || b->profiling >= 2;
-  if (b->light_job.pending && (serial_mode || b->split_post || b->concurrency != 2))
-    flush_light(b); // leaving the overlapped form: nothing stays kept back
   hipStream_t sF = serial_mode ? stream : b->s_fir;
   hipStream_t sS = serial_mode ? stream : b->s_ser;
   hipStream_t sP = serial_mode ? stream : b->s_post;
@@ -1196,6 +1198,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     // low-pass, resamplers, audio low-pass): side by side with those the FIR and they were both
     // ~25 % slower.  The rest of that chain (RDS PLL, matched filter, bit recovery, audio tail) is
     // lane-per-channel work that leaves most CUs idle: the FIR runs beside it.
+    // (behind the RDS half only, i.e. beside the resampler and the audio low-pass: measured, the FIR then
+    // takes 1.00 instead of 0.95 ms and the period does not move)
     after(sF, pe2[fmd_batch::EV_HEAVY]);
   }
   {
@@ -1211,8 +1215,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                                                    evset ? evset[0] : nullptr, evset ? evset[1] : nullptr)
                        : launch_if_stage<fmd::InF32>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn,
                                                     evset ? evset[0] : nullptr, evset ? evset[1] : nullptr);
-    if (rc != FMD_OK)
-      return rc; // refused before anything was launched: the batch is unchanged
+    if (rc != FMD_OK) // cannot happen: the geometry was checked when the batch was created
+    {
+      mark_failed(b, "the IF stage refused a call after events were recorded");
+      return rc;
+    }
   }
   signal(ce[fmd_batch::EV_INDONE], sF);
 
@@ -1285,6 +1292,28 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
 
   /* The post chain in four pieces.  "Heavy" = bandwidth / LDS bound and filling the chip; "light" =
    * lane-per-channel recurrences on CP/64 workgroups. */
+  /* History rolls of a chain whose stages all run in their normal regime: collected and done in one
+   * launch at the chain's end (k_roll_set) instead of one launch behind every stage. */
+  fmd::RollSet rolls{};
+  unsigned nrolls = 0, roll_hmax = 1;
+  auto roll_later = [&](const float2* src, float2* dst, unsigned H, unsigned n) {
+    rolls.src[nrolls] = src;
+    rolls.dst[nrolls] = dst;
+    rolls.H[nrolls] = H;
+    rolls.n[nrolls] = n;
+    nrolls++;
+    roll_hmax = std::max(roll_hmax, H);
+  };
+  auto roll_flush = [&](hipStream_t s) {
+    if (nrolls)
+      hipLaunchKernelGGL(fmd::k_roll_set, dim3((CP + 255) / 256, std::min(roll_hmax, 64u), nrolls), rt, 0, s, rolls,
+                         CP);
+    nrolls = 0;
+    roll_hmax = 1;
+  };
+  bool hb_all_normal = d.hb.size() <= 3;
+  for (size_t s = 0; s < d.hb.size(); s++)
+    hb_all_normal = hb_all_normal && hb_mode[s] == HB_NORMAL && d.hb[s].len != 11;
   auto rds_heavy = [&]() {
     /* ---- RDS branch  (stream R): half-bands, 75-tap LPF, PLL, matched filter, bits ---- */
     after(sR, ce[fmd_batch::EV_SER]);
@@ -1324,9 +1353,14 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                              hist_dst, Hs, hb_in[s], n_out, Hout, CP);
         else if (s == 0)
         { // tail of mix[q] -> history rows of mix[q^1], which the next call's half-band reads
-          hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->mix[q].p, b->mix[q ^ 1].p, Hs,
-                             hb_in[0], CP);
+          if (hb_all_normal)
+            roll_later(b->mix[q].p, b->mix[q ^ 1].p, Hs, hb_in[0]);
+          else
+            hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->mix[q].p, b->mix[q ^ 1].p, Hs,
+                               hb_in[0], CP);
         }
+        else if (hb_all_normal)
+          roll_later(b->hbbuf[s - 1].p, b->hbbuf[s - 1].p, Hs, hb_in[s]);
         else
           hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->hbbuf[s - 1].p,
                              b->hbbuf[s - 1].p, Hs, hb_in[s], CP);
@@ -1343,7 +1377,13 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
                        size_t(T_lpf - 1 + fmd::RF_TI) * 64 * sizeof(float2), sR, b->rdsraw.p,
                        b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C, CP, 0u);
-    hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, sR, b->rdsraw.p, b->rdsraw.p, T_lpf - 1, R, CP);
+    if (hb_all_normal)
+    {
+      roll_later(b->rdsraw.p, b->rdsraw.p, T_lpf - 1, R);
+      roll_flush(sR);
+    }
+    else
+      hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, sR, b->rdsraw.p, b->rdsraw.p, T_lpf - 1, R, CP);
     mark(4);
   };
   auto rds_light = [&]() {
@@ -1388,7 +1428,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
                        dim3(64, 4), 0, sA, b->brp(q), Hbb, d.rs_order, b->ktab.p, b->rs_row,
                        b->rs_margin, b->pidx.p, A, b->rs.p, T_alp - 1, C, CP);
-    hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hbb), rt, 0, sA, b->brp(q), b->brp(q ^ 1), Hbb, M, CP);
+    roll_later(b->brp(q), b->brp(q ^ 1), Hbb, M); // with the low-pass's own roll, at the chain's end
     mark(6);
     static const int ring4a = getenv("FMD_RING4") ? atoi(getenv("FMD_RING4")) : 1;
     if (ring4a && T_alp >= unsigned(fmd::RG))
@@ -1398,7 +1438,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (A + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
                        size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), sA, b->rs.p, b->alp[q].p, A,
                        int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
-    hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_alp - 1), rt, 0, sA, b->rs.p, b->rs.p, T_alp - 1, A, CP);
+    roll_later(b->rs.p, b->rs.p, T_alp - 1, A);
+    roll_flush(sA);
     mark(7);
   };
   auto audio_light = [&]() {
@@ -1440,6 +1481,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       after(sA, pe2[fmd_batch::EV_AUD]);
     }
     rds_heavy();
+    signal(ce[fmd_batch::EV_RDSH], sR);
     audio_heavy();
     if (heavy_par)
     { // EV_HEAVY = both chains done
@@ -1448,7 +1490,6 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     }
     signal(ce[fmd_batch::EV_HEAVY], sP);
     fmd_batch::LightJob job;
-    job.pending = true;
     job.R = R;
     job.A = A;
     job.mf_g = b->mf_g;
@@ -1463,28 +1504,14 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       job.tl0 = evset[4];
       job.tl1 = evset[5];
     }
-    if (b->concurrency == 2)
-    { // Overlapped calls: the light part of the PREVIOUS call goes out now, behind this call's
-      // serial stage, i.e. it runs beside the heavy part of this call at the start of the next
-      // period and not beside the FIR of the next call (which then only shares the chip with the
-      // serial stage on its own CUs).  This call's light part is kept back the same way; anything
-      // that asks for its results submits it (flush_light).
-      if (b->light_job.pending)
-      {
-        const fmd_batch::LightJob prev = b->light_job;
-        b->light_job.pending = false;
-        after(sL, b->cev[prev.es][fmd_batch::EV_HEAVY]);
-        after(sL, ce[fmd_batch::EV_SER]);
-        post_delay(sL);
-        launch_light(b, prev, sL, true);
-      }
-      b->light_job = job;
-    }
-    else
-    {
-      after(sL, ce[fmd_batch::EV_HEAVY]);
-      launch_light(b, job, sL, true);
-    }
+    /* The light part goes out at once, on its own stream: its RDS half behind the RDS half of the
+     * heavy part (it runs beside the resampler and the audio low-pass), the audio tail behind the
+     * whole heavy part (launch_light).  Until round 3 it was kept back until the NEXT call's serial
+     * stage had ended, so that it ran beside that call's heavy part and not beside a FIR; since its
+     * kernels fetch their input a tile ahead they no longer stretch beside the bandwidth kernels, and
+     * not keeping it back finishes every call 1.2 ms earlier (20 timed steps: +0.9 %, 160: +0.3 %). */
+    after(sL, ce[fmd_batch::EV_RDSH]);
+    launch_light(b, job, sL, true);
   }
   mark(9);
   if (!serial_mode && b->concurrency < 2)
@@ -1554,8 +1581,6 @@ int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream_)
     return fail(FMD_ERR_ARG, "fmd_batch_wait: bad argument (lag must be 0..4)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
-  if (lag == 0)
-    flush_light(b); // the newest call's light part may still be kept back
   for (int q = 0; q < fmd_batch::NSLOT; q++)
     if (slot_eligible(b, q, lag))
     {
@@ -1567,15 +1592,6 @@ int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream_)
   if (int rc = check_device_errors(b))
     return rc;
   return take_lost_groups(b);
-}
-
-int fmd_batch_flush(fmd_batch* b)
-{
-  if (!b)
-    return fail(FMD_ERR_ARG, "null batch");
-  HIPCHK(hipSetDevice(b->device));
-  flush_light(b);
-  return check_device_errors(b);
 }
 
 int fmd_batch_take_rds_lost(fmd_batch* b)
@@ -1604,7 +1620,6 @@ int fmd_batch_set_concurrency(fmd_batch* b, int mode)
   if (!b || mode < 0 || mode > 2)
     return fail(FMD_ERR_ARG, "fmd_batch_set_concurrency: mode must be 0, 1 or 2");
   HIPCHK(hipSetDevice(b->device));
-  flush_light(b);
   HIPCHK(hipDeviceSynchronize());
   b->concurrency = mode;
   return FMD_OK;
@@ -1623,8 +1638,6 @@ int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap,
     return fail(FMD_ERR_ARG, "fmd_batch_collect_rds: bad argument (lag must be 0..4)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
-  if (lag == 0)
-    flush_light(b);
   /* Two synchronisations whatever the number of queues: all counts in one copy, then the records of
    * the non-empty queues back to back.  Page-locked destinations: the copies are DMA transfers, not
    * staging kernels that would queue up behind the decoder's own. */
@@ -1722,8 +1735,6 @@ int fmd_batch_export_rds_device(fmd_batch* b, int32_t* d_records, unsigned cap, 
     return fail(FMD_ERR_ARG, "fmd_batch_export_rds_device: bad argument (lag must be 0..4)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
-  if (lag == 0)
-    flush_light(b);
   HIPCHK(hipMemsetAsync(d_records, 0, size_t(cap) * 4 * sizeof(int32_t), stream));
   HIPCHK(hipMemsetAsync(b->export_cursor.p, 0, sizeof(unsigned), stream));
   for (int q = 0; q < fmd_batch::NSLOT; q++)
@@ -1870,7 +1881,6 @@ int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsig
   if (!b || !out || channel >= b->C)
     return fail(FMD_ERR_ARG, "fmd_batch_get_tap: bad argument");
   HIPCHK(hipSetDevice(b->device));
-  flush_light(b);
   HIPCHK(hipDeviceSynchronize());
   const size_t CP = b->CP;
   const void* src = nullptr;
@@ -2002,7 +2012,6 @@ int fmd_batch_set_profiling(fmd_batch* b, int level)
   // concurrency 2 that stream was never ordered behind the calls in flight: like set_concurrency,
   // a change of execution mode starts from an idle device.
   HIPCHK(hipSetDevice(b->device));
-  flush_light(b);
   HIPCHK(hipDeviceSynchronize());
   b->profiling = level < 0 ? 0 : (level > 2 ? 2 : level);
   b->prof_calls = 0; // restart the averaging window
@@ -2154,7 +2163,6 @@ int fmd_batch_debug_timeline(fmd_batch* b, float* out, unsigned cap_calls)
   if (b->profiling != 1 || b->prof_calls == 0 || !b->serial_exclusive || b->concurrency != 2)
     return 0;
   HIPCHK(hipSetDevice(b->device));
-  flush_light(b);
   HIPCHK(hipDeviceSynchronize());
   const unsigned n = std::min(cap_calls, b->prof_calls);
   hipEvent_t t0 = b->ev[0];

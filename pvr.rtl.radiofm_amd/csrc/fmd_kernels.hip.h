@@ -3090,6 +3090,35 @@ __global__ __launch_bounds__(64) void k_debug_math(int what, unsigned n, const f
 /* dst rows [0, H) <- src rows [n, n+H): the last H rows of (history + n new rows).  src == dst
  * for single buffers (then n >= H is required for the row-parallel form), src != dst for the
  * double-buffered ones. */
+/* Up to four rolls of float2 buffers in ONE launch (blockIdx.z = job): the history tails of a chain's
+ * stages, all due at the chain's end.  Same semantics per job as k_roll. */
+struct RollSet
+{
+  const float2* src[4];
+  float2* dst[4];
+  unsigned H[4], n[4];
+};
+__global__ void k_roll_set(RollSet rs, unsigned CP)
+{
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= CP)
+    return;
+  const unsigned job = blockIdx.z;
+  const float2* src = rs.src[job];
+  float2* dst = rs.dst[job];
+  const unsigned H = rs.H[job], n = rs.n[job];
+  if (n >= H || src != dst)
+  {
+    for (unsigned r = blockIdx.y; r < H; r += gridDim.y)
+      dst[(size_t)r * CP + c] = src[(size_t)(r + n) * CP + c];
+  }
+  else if (blockIdx.y == 0)
+  {
+    for (unsigned r = 0; r < H; r++)
+      dst[(size_t)r * CP + c] = src[(size_t)(r + n) * CP + c];
+  }
+}
+
 template <typename T>
 __global__ void k_roll(const T* src, T* dst, unsigned H, unsigned n, unsigned CP)
 {

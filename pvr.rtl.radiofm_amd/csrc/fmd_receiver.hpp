@@ -34,6 +34,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -64,10 +65,12 @@ inline void uecp_stuff(const uint8_t* frame, unsigned len, Emit&& emit)
   emit(uint8_t(0xFF));
 }
 
-/* One block of IQ as the source delivered it, in pinned host memory. */
+/* One block of IQ as the source delivered it, in page-locked host memory (pageable once the pool's
+ * page-locked budget is used up: the copy to the device still works, only slower). */
 struct IqBlock
 {
-  void* mem = nullptr;  // hipHostMalloc
+  void* mem = nullptr;  // hipHostMalloc, or malloc when !pinned
+  bool pinned = false;
   size_t capacity = 0;  // bytes
   unsigned samples = 0;
   bool bytes_in = false; // RTL-SDR (I, Q) byte pairs instead of complex<float>
@@ -76,14 +79,28 @@ struct IqBlock
 
 /* FIFO of filled blocks plus a free list of empty ones.  One producer (the source thread) and one
  * consumer (the demux thread); the queue is unbounded like the reference's (it warns about a
- * growing backlog, it never drops), but blocks are reused once the consumer hands them back. */
+ * growing backlog, it never drops), but blocks are reused once the consumer hands them back.
+ * Blocks come in power-of-two size classes from 16 KiB (a 16 k-sample byte block is 32 KiB, a full
+ * float block 512 KiB), and at most kPinnedBudget bytes of them are page-locked: a consumer that falls
+ * behind makes the backlog grow in ordinary memory, not in the machine's pinned pages. */
 class BlockPool
 {
 public:
+  static constexpr size_t kPinnedBudget = size_t(64) << 20;
+
   ~BlockPool()
   {
     release_chain(m_head);
     release_chain(m_free);
+  }
+
+  /* a few blocks up front, from the thread that opens the stream (page-locking takes milliseconds:
+   * not something the source thread should do in the middle of a delivery) */
+  void prime(unsigned blocks, size_t bytes)
+  {
+    for (unsigned i = 0; i < blocks; i++)
+      if (IqBlock* blk = take_free(bytes))
+        recycle(blk);
   }
 
   /* copies `bytes` bytes into a recycled (or new) pinned block and appends it; false = out of
@@ -153,27 +170,54 @@ public:
   }
 
 private:
+  static size_t size_class(size_t bytes)
+  {
+    size_t c = size_t(16) << 10;
+    while (c < bytes)
+      c <<= 1;
+    return c;
+  }
   IqBlock* take_free(size_t bytes)
   {
     IqBlock* blk = nullptr;
     {
       std::lock_guard<std::mutex> g(m_lock);
-      blk = m_free;
-      if (blk)
-        m_free = blk->next;
+      // first free block that is large enough (the list holds few blocks, mostly of one class)
+      for (IqBlock** pp = &m_free; *pp; pp = &(*pp)->next)
+        if ((*pp)->capacity >= bytes)
+        {
+          blk = *pp;
+          *pp = blk->next;
+          break;
+        }
     }
-    if (blk && blk->capacity >= bytes)
+    if (blk)
       return blk;
-    if (!blk)
-      blk = new (std::nothrow) IqBlock;
+    blk = new (std::nothrow) IqBlock;
     if (!blk)
       return nullptr;
-    if (blk->mem)
-      (void)hipHostFree(blk->mem);
-    blk->mem = nullptr;
-    // whole blocks of the largest call size, so a recycled block fits the next one
-    const size_t want = std::max(bytes, size_t(FMD_MAX_BLOCK) * 8);
-    if (hipHostMalloc(&blk->mem, want, hipHostMallocDefault) != hipSuccess)
+    const size_t want = size_class(bytes);
+    bool pin;
+    {
+      std::lock_guard<std::mutex> g(m_lock);
+      pin = m_pinned_bytes + want <= kPinnedBudget;
+      if (pin)
+        m_pinned_bytes += want;
+    }
+    // portable: valid for every device and from every thread (the source thread never selects one)
+    if (pin && hipHostMalloc(&blk->mem, want, hipHostMallocPortable) == hipSuccess)
+      blk->pinned = true;
+    else
+    {
+      if (pin)
+      {
+        std::lock_guard<std::mutex> g(m_lock);
+        m_pinned_bytes -= want;
+      }
+      blk->mem = std::malloc(want);
+      blk->pinned = false;
+    }
+    if (!blk->mem)
     {
       delete blk;
       return nullptr;
@@ -186,8 +230,10 @@ private:
     while (b)
     {
       IqBlock* n = b->next;
-      if (b->mem)
+      if (b->mem && b->pinned)
         (void)hipHostFree(b->mem);
+      else if (b->mem)
+        std::free(b->mem);
       delete b;
       b = n;
     }
@@ -199,6 +245,7 @@ private:
   IqBlock* m_tail = nullptr;
   IqBlock* m_free = nullptr;
   size_t m_backlog = 0; // samples queued
+  size_t m_pinned_bytes = 0;
   bool m_closed = false;
 };
 
@@ -266,6 +313,9 @@ public:
       return rc;
     m_announce_change.store(true);
     m_clock = double(FMD_STREAM_TIME_BASE);
+    // page-locked blocks for the first deliveries (RTL-SDR byte blocks: 2 bytes per sample; sized by the
+    // source's default block, RTL_SDR_Source.h:25)
+    m_blocks.prime(4, size_t(FMD_MAX_BLOCK) * 2);
     return fmd_reset(m_decoder);
   }
 
