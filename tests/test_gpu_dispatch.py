@@ -3,8 +3,8 @@
 The launch code picks different kernels by batch size: from 1024 channels on the serial stage owns
 whole CUs (k_demod_serial<2, true>), with a channel count that is a multiple of 8 the IF FIR uses
 the XCD-aware block mapping, overlapped calls (concurrency 2) use two-tile FIR workgroups
-(k_if_fir_mt) in the headline geometry and the hand-scheduled tap loop for long filters, and the
-light part of a call is kept back until the next call.  Small-batch tests never reach those forms,
+(k_if_fir_mt) in the headline geometry and the hand-scheduled tap loops for long filters, and the
+post chain runs as a heavy and a light part on two streams.  Small-batch tests never reach those forms,
 so these run them at >= 1024 channels with overlapped calls: a handful of channels against the CPU
 oracle bit for bit on the very bytes the device generator produced, and the whole batch through a
 size-independent property (channels c and c + C/2 carry the same station: identical audio, status
@@ -171,9 +171,9 @@ def test_config3_shared_capture_overlapped(oracle, fmsig):
 
 
 def test_process_host_is_synchronous_in_concurrency_2(oracle, fmsig):
-    """fmd_batch_process_host returns finished audio in every concurrency mode: in mode 2 the light
-    part of the call (audio tail) is kept back and the null stream is not ordered behind the call,
-    so the entry point has to submit it and wait before it copies the audio out."""
+    """fmd_batch_process_host returns finished audio in every concurrency mode: in mode 2 the null
+    stream is not ordered behind the call, so the entry point has to order it behind the call's last
+    kernel (the audio tail on the light stream) before it copies the audio out."""
     pkg = load_package()
     fs, D, C = 2.4e6, 11, 3
     ps = [fmsig.default_params(fs, noise_sigma=0.01, seed=40 + c, pi=0x4400 + c) for c in range(C)]
