@@ -1795,9 +1795,8 @@ static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t 
     return rc;
   if (C > 1 && nf > audio_channel_stride)
     return fail(FMD_ERR_ARG, "audio_channel_stride smaller than the audio produced");
-  // Synchronous entry point in every concurrency mode: in mode 2 the call's light part (RDS bit
-  // recovery, audio tail) is still kept back and the null stream is not ordered after the call --
-  // submit it and order the null stream behind the whole call before copying the audio out.
+  // Synchronous entry point in every concurrency mode: in mode 2 the null stream is not ordered after
+  // the call -- order it behind the whole call before copying the audio out.
   rc = fmd_batch_wait(b, nullptr);
   if (rc < 0)
     return rc;
