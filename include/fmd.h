@@ -223,8 +223,9 @@ int fmd_batch_take_rds_lost(fmd_batch* b);
  * operation, nothing of the batch is modified.  They may be called from any thread at any time,
  * also while another thread is inside a process call on the same batch (Kodi's status thread does
  * that: RadioReceiver.cpp:544-572 against :524).  A record is always one call's values, never a mix
- * of two writes.  With overlapped calls (concurrency 2) the interface / baseband meters in it may
- * already include the following call. */
+ * of two writes (rds_state, which is no cFmDecoder getter, is a word of its own that the bit recovery
+ * updates).  With overlapped calls (concurrency 2) the interface / baseband meters in it may already
+ * include the following call. */
 int fmd_batch_get_status(fmd_batch* b, unsigned channel, fmd_status* st);
 /* index (1-based) of the call whose status the getters return at this moment, 0 = none yet */
 int fmd_batch_status_call_index(fmd_batch* b, unsigned channel, uint32_t* call_index);

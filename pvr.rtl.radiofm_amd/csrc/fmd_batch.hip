@@ -1462,12 +1462,10 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     signal(ce[fmd_batch::EV_RDS], sR);
     mark(5);
     audio_heavy();
-    // the audio tail closes the call: it publishes the status snapshot, RDS state included, so it
-    // runs behind the RDS chain also when that chain has a stream of its own
-    after(sA, ce[fmd_batch::EV_RDS]);
     audio_light();
     signal(ce[fmd_batch::EV_AUD], sA);
     mark(8);
+    after(sA, ce[fmd_batch::EV_RDS]);
     signal(ce[fmd_batch::EV_HEAVY], sA);
   }
   else

@@ -2650,6 +2650,10 @@ __global__ __launch_bounds__(64) void k_rds_bits(const float* __restrict__ mf, u
   st.I(I_R_BLOCK)[c] = block;
   st.I(I_R_BITPOS)[c] = bitpos;
   st.I(I_R_STATE)[c] = state;
+  // the status snapshot's RDS state (not a cFmDecoder getter) is this kernel's to write: a word of its
+  // own, outside the audio tail's sequence-locked record, so that the tail need not wait for the RDS
+  // chain where the two run on different streams
+  reinterpret_cast<volatile unsigned*>(st.hs)[(size_t)HS_R_STATE * st.CP + c] = (unsigned)state;
   st.I(I_R_BOFF)[c] = boff;
   st.I(I_R_ERRORS)[c] = errors;
 #pragma unroll
@@ -2953,7 +2957,6 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
     h[HS_BB_LEVEL * CPs] = __float_as_uint(st.F(F_BB_LEVEL)[c]);
     h[HS_P_LEVEL * CPs] = __float_as_uint(st.F(F_P_LEVEL)[c]);
     h[HS_STEREO * CPs] = (unsigned)stereo;
-    h[HS_R_STATE * CPs] = (unsigned)st.I(I_R_STATE)[c];
     h[HS_AUDIO_MEAN * CPs] = __float_as_uint(mean);
     h[HS_AUDIO_RMS * CPs] = __float_as_uint(rms);
     h[HS_AUDIO_LEVEL * CPs] = __float_as_uint(level);
