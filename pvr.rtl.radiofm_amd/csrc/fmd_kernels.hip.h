@@ -1675,8 +1675,10 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
         const unsigned m0 = j * DS;
         const unsigned cnt = min((unsigned)DS, M - m0);
         /* One sample of the FM PLL (FmDecode.cpp:371-413).  The wave is bound by the number of
-         * instructions it issues (one wave per SIMD): everything below is written for that count. */
-        auto fm_sample = [&](unsigned u) {
+         * instructions it issues (one wave per SIMD, ~5 cycles each whatever their class): everything
+         * below is written for that count.  Returns whether the sample met a rare input (arctangent
+         * outside the table form's range): its result is then meaningless and the caller redoes it. */
+        auto fm_sample = [&](unsigned u) -> bool {
           const float2 sin_ = stage[j & 1][u][lane]; // staged one chunk ahead by the other wave
           const float sre = sin_.x, sim = sin_.y;
           float sn, cs;
@@ -1685,13 +1687,10 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           // (cs sre, cs sim) + (-(sn sim), sn sre)  [fmd_pk_add_cross: (a.x - b.y, a.y + b.x)]
           const fmd_v2f dd = fmd_pk_add_cross((fmd_v2f){sre, sim} * cs, (fmd_v2f){sre, sim} * sn);
           const float dre = dd.x, dim = dd.y;
-          /* One test for the rare inputs (arctangent outside the table form's range): the common
-           * path carries no fix-up code, the rare path redoes the update literally. */
           bool lit;
           const float err = -fmd_atan2f_tab_core(dim, dre, atab, &lit);
-          const float incr0 = nco_incr, phase0 = nco_phase;
           /* :399-402 as max / min: the same as the reference's two compares for every number; a
-           * NaN state (only ever out of non-finite input) goes through the literal path below */
+           * NaN state (only ever out of non-finite input) goes through the literal path */
           const fmd_v2f ba = (fmd_v2f){k.pll_beta, k.pll_alpha} * err;
           nco_incr += ba.x;
           nco_incr = fminf(fmaxf(nco_incr, k.nco_ll), k.nco_hl);
@@ -1699,7 +1698,10 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           {
             /* :404-407  if (phase >= 2pi) phase = fmod(phase, 2pi); while (phase < 0) phase += 2pi;
              * For phase in [2pi, 4pi) fmod is the exact difference phase - 2pi, and for
-             * [-2pi, 0) the loop runs once. */
+             * [-2pi, 0) the loop runs once.  The new phase cannot be outside (-2 pi, 4 pi): the old one
+             * lies in [0, 2 pi] (by this very wrap), the increment is clamped to +-0.95 pi and
+             * alpha |err| <= 0.67 pi.  A NaN anywhere (only ever out of non-finite input) makes the
+             * quotient inside the arctangent NaN, i.e. `lit`. */
             const double pd = (double)nco_phase;
             /* K_2PI lies between the floats 0x40c90fda and 0x40c90fdb, so (double)phase >= K_2PI is
              * this float compare */
@@ -1707,49 +1709,71 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
             const bool lt = nco_phase < 0;
             const double off = ge ? -FMD_K_2PI : FMD_K_2PI;
             const float moved = (float)(pd + off); // exact difference / sum, rounded once
-            /* The new phase cannot be outside (-2 pi, 4 pi): the old one lies in [0, 2 pi] (by this
-             * very wrap), the increment is clamped to +-0.95 pi and alpha |err| <= 0.67 pi.  A NaN
-             * anywhere (only ever out of non-finite input) makes the quotient inside the arctangent
-             * NaN, i.e. `lit`: the literal path then reproduces what the reference's compares do
-             * with it, and from then on every sample goes that way. */
             nco_phase = (ge | lt) ? moved : nco_phase;
-            if (__builtin_expect(lit, 0))
-            {
-              {
-                const float e2 = -fmd_atan2f(dim, dre);
-                float in2 = incr0 + k.pll_beta * e2;
-                in2 = (in2 < k.nco_ll) ? k.nco_ll : in2;
-                in2 = (in2 > k.nco_hl) ? k.nco_hl : in2;
-                float ph2 = phase0 + (in2 + k.pll_alpha * e2);
-                const double pd2 = (double)ph2;
-                if (pd2 >= FMD_K_2PI)
-                  ph2 = (float)fmod(pd2, FMD_K_2PI);
-                while (ph2 < 0)
-                  ph2 = (float)((double)ph2 + FMD_K_2PI);
-                nco_incr = in2;
-                nco_phase = ph2;
-              }
-            }
           }
           // the NCO increment; phaseIncr = 2 * increment (:409) and the output filter run in wave 1
           chunk[j & 1][u][lane] = nco_incr;
+          return lit;
+        };
+        /* The same sample written out literally (fdlibm arctangent as glibc has it, the reference's
+         * compares and its fmod): what a rare input gets, and -- identical for every other input --
+         * what the rest of its group is redone with. */
+        auto fm_sample_literal = [&](unsigned u) {
+          const float2 sin_ = stage[j & 1][u][lane];
+          float sn, cs;
+          fmd_sincos_p256k(nco_phase, sctab, m16, &sn, &cs);
+          const fmd_v2f dd = fmd_pk_add_cross((fmd_v2f){sin_.x, sin_.y} * cs, (fmd_v2f){sin_.x, sin_.y} * sn);
+          const float e2 = -fmd_atan2f(dd.y, dd.x);
+          float in2 = nco_incr + k.pll_beta * e2;
+          in2 = (in2 < k.nco_ll) ? k.nco_ll : in2;
+          in2 = (in2 > k.nco_hl) ? k.nco_hl : in2;
+          float ph2 = nco_phase + (in2 + k.pll_alpha * e2);
+          const double pd2 = (double)ph2;
+          if (pd2 >= FMD_K_2PI)
+            ph2 = (float)fmod(pd2, FMD_K_2PI);
+          while (ph2 < 0)
+            ph2 = (float)((double)ph2 + FMD_K_2PI);
+          nco_incr = in2;
+          nco_phase = ph2;
+          chunk[j & 1][u][lane] = nco_incr;
         };
         if (cnt == (unsigned)DS)
-        { // full chunks: FM_UNROLL samples per trip (no register copies at the back edge, LDS
-          // addresses with immediate offsets)
+        { /* Full chunks: FM_UNROLL samples per trip (no register copies at the back edge, LDS
+           * addresses with immediate offsets) and ONE rare-input test per trip: the samples of a group
+           * run straight through, their rare flags are collected, and a group in which any lane met a
+           * rare input is redone literally from the state it started with (a branch per sample costs
+           * three scalar instructions and keeps the scheduler from moving anything across it). */
 #pragma unroll 1
           for (unsigned u = 0; u < (unsigned)DS; u += FM_UNROLL)
           {
+            const float phase_g = nco_phase, incr_g = nco_incr;
+            bool any = false;
 #pragma unroll
             for (unsigned v = 0; v < FM_UNROLL; v++)
-              fm_sample(u + v);
+              any |= fm_sample(u + v);
+            if (__builtin_expect(any, 0))
+            {
+              nco_phase = phase_g;
+              nco_incr = incr_g;
+#pragma unroll 1
+              for (unsigned v = 0; v < FM_UNROLL; v++)
+                fm_sample_literal(u + v);
+            }
           }
         }
         else
         {
 #pragma unroll 1
           for (unsigned u = 0; u < cnt; u++)
-            fm_sample(u);
+          {
+            const float phase_g = nco_phase, incr_g = nco_incr;
+            if (__builtin_expect(fm_sample(u), 0))
+            {
+              nco_phase = phase_g;
+              nco_incr = incr_g;
+              fm_sample_literal(u);
+            }
+          }
         }
       }
       if (PAIRSYNC)
