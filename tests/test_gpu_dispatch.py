@@ -258,3 +258,37 @@ def test_device_error_word_surfaces(fmsig):
     torch.cuda.synchronize()
     b.collect_rds_array(cap=16, stream=st)
     b.close()
+
+
+def test_device_timeline_of_overlapped_calls(fmsig):
+    """fmd_batch_debug_timeline (what `FMD_BENCH_TIMELINE=1 python bench.py` prints): per profiled call the
+    device times of its IF FIR, serial stage and audio tail.  Every call's stages are in order, the
+    serial stages of consecutive calls do not overlap (they hand channel state to each other), and
+    the FIR of call k + 1 does overlap the serial stage of call k -- the point of concurrency 2."""
+    import torch
+    pkg = load_package()
+    fs, D, C, nblk = 2.4e6, 11, 2048, 8
+    gen = fmsig.DeviceGenerator([fmsig.channel_params(fs, c % 16) for c in range(C)], "cuda")
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
+    b.set_concurrency(2)
+    a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
+    iq = [torch.empty((C, N, 2), dtype=torch.float32, device="cuda") for _ in range(nblk)]
+    audio = [torch.zeros((C, a_stride), dtype=torch.float32, device="cuda") for _ in range(nblk)]
+    for k in range(nblk):
+        gen.generate(iq[k], k * N, N)
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    b.set_profiling(1)
+    for k in range(nblk):
+        b.process_device(iq[k].data_ptr(), N, N, audio[k].data_ptr(), a_stride, st)
+    b.wait(stream=st)
+    torch.cuda.synchronize()
+    tl = b.debug_timeline()
+    assert tl.shape == (nblk, 6) and (tl >= 0).all() and tl[0, 0] == 0.0
+    for k in range(nblk):
+        f0, f1, s0, s1, t0, t1 = tl[k]
+        assert f0 < f1 <= s0 < s1 <= t0 < t1, (k, tl[k])
+    assert all(tl[k, 3] <= tl[k + 1, 2] for k in range(nblk - 1))           # serial stages one after the other
+    assert any(tl[k + 1, 0] < tl[k, 3] for k in range(1, nblk - 1))           # a later FIR beside an earlier serial stage
+    b.set_profiling(0)
+    b.close()
