@@ -628,6 +628,12 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   const unsigned T_mf = unsigned(d.rds_mf_taps.size());
   const unsigned T_alp = unsigned(d.lpf_taps.size());
 
+  /* The serial stage addresses its input rows (demod) and its two output row buffers with 32-bit
+   * byte offsets per lane (fmd_kernels.hip.h, k_demod_serial): a batch stays below 4 GB in each.  At
+   * 2.4 MS/s that is ~80 000 channels; at 400 kS/s (no decimation) 8 000. */
+  if (size_t(b->Mstride) * C * sizeof(float2) + 4096 >= (size_t(1) << 32) ||
+      size_t(b->Mmax) * CP * sizeof(float2) >= (size_t(1) << 32))
+    return fail(FMD_ERR_ARG, "too many channels for one batch at this sample rate (4 GB per row buffer): split the batch");
   int bad = 0;
   bad |= b->lut.alloc(size_t(d.table_size) * C);
   bad |= b->hist[0].alloc(size_t(d.if_order) * C);

@@ -1599,6 +1599,8 @@ __global__ __launch_bounds__(64) void k_if_level(const typename IN::elem* __rest
  * SIMD (half the register file each, 32 CUs owned): the waves do not fit into each other's issue
  * gaps, the stage takes 3.5 ms (151 GS/s). */
 constexpr int DS = 32; // samples per LDS chunk
+typedef float fmd_v4f __attribute__((ext_vector_type(4)));
+constexpr int STAGE_RS = 65; // row stride of the staged input in LDS (float2 units)
 constexpr unsigned FM_UNROLL = 4; // samples per trip of the FM wave's loop over a full chunk (1, 2, 4: 651 / 599 / 596 cycles per sample)
 
 template <int NG, bool EXCL>
@@ -1614,7 +1616,9 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
   const long long probe_r0 = wg_probe ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   const long long probe_c0 = wg_probe ? (long long)__builtin_readcyclecounter() : 0;
   __shared__ float chunk_all[NG][2][DS][64];  // baseband, FM role -> pilot/RDS role
-  __shared__ float2 stage_all[NG][2][DS][64]; // IF-FIR output, pilot/RDS role -> FM role
+  // IF-FIR output, pilot/RDS role -> FM role.  Rows of 65: the staging writes a lane's two samples
+  // of one channel, lanes 16 apart in rows 2 apart -- with rows of 64 that is one bank pair for 16 lanes
+  __shared__ float2 stage_all[NG][2][DS][STAGE_RS];
   // the larger alignment puts the tables first in the LDS layout: below 64 KB their base folds
   // into the read's offset field (one instruction less on the path from the phase to its sine)
   constexpr unsigned SCTAB_N = FMD_SINCOS_P256_SIZE;
@@ -1642,7 +1646,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
   const unsigned role = wave & 1u;
   const unsigned grp = wave >> 1;
   float (*chunk)[DS][64] = chunk_all[grp];
-  float2 (*stage)[DS][64] = stage_all[grp];
+  float2 (*stage)[DS][STAGE_RS] = stage_all[grp];
   const unsigned done_fm = (unsigned)(size_t)&done_all[grp][0];  // LDS byte addresses
   const unsigned done_2nd = (unsigned)(size_t)&done_all[grp][1];
   // a constant of the sine series, pinned in a vector register for both sample loops
@@ -1702,14 +1706,19 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
              * lies in [0, 2 pi] (by this very wrap), the increment is clamped to +-0.95 pi and
              * alpha |err| <= 0.67 pi.  A NaN anywhere (only ever out of non-finite input) makes the
              * quotient inside the arctangent NaN, i.e. `lit`. */
-            const double pd = (double)nco_phase;
-            /* K_2PI lies between the floats 0x40c90fda and 0x40c90fdb, so (double)phase >= K_2PI is
-             * this float compare */
-            const bool ge = nco_phase >= 6.2831855f;
-            const bool lt = nco_phase < 0;
-            const double off = ge ? -FMD_K_2PI : FMD_K_2PI;
-            const float moved = (float)(pd + off); // exact difference / sum, rounded once
-            nco_phase = (ge | lt) ? moved : nco_phase;
+            /* K_2PI lies between the floats 0x40c90fda and 0x40c90fdb, so "0 <= phase < K_2PI" is one
+             * unsigned compare of the float's bits (the phase is never -0: a sum is -0 only out of two
+             * -0, the state starts at +0 and a wrapped phase is never 0 at all).  The offset -2 pi / 0 /
+             * +2 pi is built as a double's high word -- sign = the phase's inverted, everything else K_2PI's,
+             * or all zero in range -- over K_2PI's low word: in range that is a subnormal (below
+             * 2^-1043) and phase + it rounds back to the phase, so no select of the result is needed. */
+            const uint32_t pb = fmd_f2u(nco_phase);
+            uint32_t khi = (~pb & 0x80000000u) | 0x401921fbu;
+            khi = pb < 0x40c90fdbu ? 0u : khi;
+            const uint64_t kb = ((uint64_t)khi << 32) | 0x54442d18u;
+            double off;
+            memcpy(&off, &kb, 8);
+            nco_phase = (float)((double)nco_phase + off); // exact difference / sum, rounded once
           }
           // the NCO increment; phaseIncr = 2 * increment (:409) and the output filter run in wave 1
           chunk[j & 1][u][lane] = nco_incr;
@@ -1737,6 +1746,14 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           nco_phase = ph2;
           chunk[j & 1][u][lane] = nco_incr;
         };
+#ifdef FMD_DBG_NO_FM /* dev aid (tools/ubench/serial_stage): the second wave's loop alone */
+        if (true)
+        {
+          for (unsigned u = 0; u < cnt; u++)
+            chunk[j & 1][u][lane] = nco_incr;
+        }
+        else
+#endif
         if (cnt == (unsigned)DS)
         { /* Full chunks: FM_UNROLL samples per trip (no register copies at the back edge, LDS
            * addresses with immediate offsets) and ONE rare-input test per trip: the samples of a group
@@ -1797,6 +1814,11 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     // the state is in registers before the chunk loop starts: inside it, the only loads in flight
     // are the staged chunk's, and nothing in the sample loop waits for them
     __builtin_amdgcn_s_waitcnt(0);
+    FmdSincosP256 p_sc = fmd_sincos_p256_lookup(p_phase, sctab); // pilot NCO: one sample ahead
+#ifdef FMD_DBG_DEPHASE
+    if (NG > 1 && grp == 1)
+      __builtin_amdgcn_s_sleep(FMD_DBG_DEPHASE);
+#endif
     float vsum = 0.0f, vsumsq = 0.0f;
     /* The two per-sample stores: wave-uniform row bases plus ONE 32-bit byte offset per lane that
      * advances a row per sample (the row buffers stay below 4 GB).  Padded lanes shadow the last
@@ -1806,6 +1828,14 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     char* __restrict__ mix_rows = reinterpret_cast<char*>(mix + (size_t)Hmix * CP);
     unsigned row_off = c * (unsigned)sizeof(float2);
     const unsigned row_step = CP * (unsigned)sizeof(float2);
+    // staging (see the chunk loop): this lane's 16 bytes of the rows 4 i + co_row, as 32-bit byte
+    // offsets from the chunk's first sample in channel 0's row (the host keeps the buffer below 4 GB)
+    const unsigned co_row = lane >> 4, co_col = lane & 15u;
+    unsigned co_off[DS / 2];
+#pragma unroll
+    for (unsigned i = 0; i < DS / 2; i++)
+      co_off[i] = min((blockIdx.x * NG + grp) * 64 + 4 * i + co_row, C - 1) * (Mstride * (unsigned)sizeof(float2)) +
+                  co_col * 16u;
     for (unsigned j = 0; j <= nchunks; j++)
     {
       /* This wave also moves the FM wave's input: while that wave works on chunk j, the IF-FIR
@@ -1820,38 +1850,28 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
        * LAST operations too -- the two stores of the sample just finished, 3-8 us under load --
        * and a second wave that late makes the FM wave wait (seen per workgroup with the probe: up
        * to +13 % cycles, in a third of the workgroups of a launch).  Vector memory operations
-       * retire in issue order: with the 64 stores of a full chunk behind the 32 loads,
+       * retire in issue order: with the 64 stores of a full chunk behind the 16 loads,
        * `s_waitcnt vmcnt(63)` is enough, and the oldest of those stores is a chunk old.
        * (A ragged last chunk is loaded whole: the host leaves DS samples of slack behind the last
        * channel's row; what lies beyond M is never used.) */
-      constexpr bool BYHAND = true; // every form of the kernel (the compiler's loads: false)
-      float2 pre[DS], pre_h[DS];
-      if (BYHAND)
+      /* The loads are cooperative: a chunk is 64 rows (channels) of 256 contiguous bytes, and a lane
+       * reading its own channel's row 8 bytes at a time touches 64 cache lines per instruction (64
+       * cycles of the CU's L1 each: with two groups per CU the L1 was busy a fifth of the time and the
+       * stage's stores queued behind it).  Instead 16 lanes read one row 16 bytes each and an instruction
+       * covers 4 rows = 8 lines; the transposition happens in the LDS writes below. */
+      fmd_v4f pre_c[DS / 2];
+      if (staging)
       {
-        if (staging)
-        {
-        const float2* src = row + pf0;
+        const float2* sb = demod + pf0; // wave-uniform; the lanes' row offsets are co_off[]
 #pragma unroll
-        for (unsigned u = 0; u < DS; u += 8)
-          asm volatile("global_load_dwordx2 %0, %8, off offset:%9\n\t"
-                       "global_load_dwordx2 %1, %8, off offset:%9+8\n\t"
-                       "global_load_dwordx2 %2, %8, off offset:%9+16\n\t"
-                       "global_load_dwordx2 %3, %8, off offset:%9+24\n\t"
-                       "global_load_dwordx2 %4, %8, off offset:%9+32\n\t"
-                       "global_load_dwordx2 %5, %8, off offset:%9+40\n\t"
-                       "global_load_dwordx2 %6, %8, off offset:%9+48\n\t"
-                       "global_load_dwordx2 %7, %8, off offset:%9+56"
-                       : "=&v"(pre_h[u]), "=&v"(pre_h[u + 1]), "=&v"(pre_h[u + 2]), "=&v"(pre_h[u + 3]),
-                         "=&v"(pre_h[u + 4]), "=&v"(pre_h[u + 5]), "=&v"(pre_h[u + 6]), "=&v"(pre_h[u + 7])
-                       : "v"(src), "n"(u * 8)
+        for (unsigned i = 0; i < DS / 2; i += 4)
+          asm volatile("global_load_dwordx4 %0, %4, %8\n\t"
+                       "global_load_dwordx4 %1, %5, %8\n\t"
+                       "global_load_dwordx4 %2, %6, %8\n\t"
+                       "global_load_dwordx4 %3, %7, %8"
+                       : "=&v"(pre_c[i]), "=&v"(pre_c[i + 1]), "=&v"(pre_c[i + 2]), "=&v"(pre_c[i + 3])
+                       : "v"(co_off[i]), "v"(co_off[i + 1]), "v"(co_off[i + 2]), "v"(co_off[i + 3]), "s"(sb)
                        : "memory");
-        }
-      }
-      else if (staging)
-      {
-#pragma unroll
-        for (unsigned u = 0; u < DS; u++)
-          pre[u] = row[min(pf0 + u, M - 1)];
       }
       unsigned stores_behind = 0; // vector stores issued behind those loads
       if (PAIRSYNC && j >= 1) // chunk j - 1 written, stage[(j + 1) & 1] read: FM wave done with j - 1
@@ -1873,7 +1893,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
             vsumsq += v * v;
             /* ---- pilot PLL (FmDecode.cpp:151-217) ---- */
             float ps, pc;
-            fmd_sincos_p256k(p_phase, sctab, m16, &ps, &pc);
+            fmd_sincos_p256_finish(p_sc, m16, &ps, &pc); // looked up when p_phase was formed
             const float tone = 2 * ps * pc;
             float ph_i = ps * v;
             float ph_q = pc * v;
@@ -1884,7 +1904,11 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
             p_q2 = p_q1;
             p_q1 = ph_q;
             /* :194-201 as selects; the quotient is formed unconditionally and only used in lock */
+#ifdef FMD_DBG_NO_DIV
+            const float ratio = ph_q * 0.5f;
+#else
             const float ratio = ph_q / ph_i;
+#endif
             const float sgn = (ph_q > 0) ? 1.0f : -1.0f;
             const float perr = (ph_i > fabsf(ph_q)) ? ratio : sgn;
             p_level = (ph_i < p_level) ? ph_i : p_level;
@@ -1899,6 +1923,10 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
               const float down = (float)(pd - FMD_K_2PI);
               p_phase = (pd > FMD_K_2PI) ? down : p_phase; // :215-216
             }
+            /* the next sample's table entry: its LDS latency lies under the oscillator and the stores
+             * below (the barrier keeps the compiler from moving those in front of the read) */
+            p_sc = fmd_sincos_p256_lookup(p_phase, sctab);
+            __builtin_amdgcn_sched_barrier(0);
             /* ---- RDS oscillator mix (DownConvert.cpp:436-442, :464-465), imag(input) == 0 ---- */
             float2 osc;
             osc.x = o_re * k.osc_cos - o_im * k.osc_sin;
@@ -1907,11 +1935,21 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
             o_re = gn * osc.x;
             o_im = gn * osc.y;
             const float zero = 0.0f;
+#ifdef FMD_DBG_NO_STORES /* dev aid: the loop without its two stores per sample (results kept alive) */
+            vsum += tone * (2 * v) + ((v * osc.x) - (zero * osc.y)) + ((v * osc.y) + (zero * osc.x));
+#else
             *reinterpret_cast<float2*>(br_rows + row_off) = make_float2(v, tone * (2 * v)); // FmDecode.cpp:456
             *reinterpret_cast<float2*>(mix_rows + row_off) =
                 make_float2((v * osc.x) - (zero * osc.y), (v * osc.y) + (zero * osc.x));
+#endif
             row_off += row_step;
         };
+#ifdef FMD_DBG_NO_2ND /* dev aid (tools/ubench/serial_stage): the FM wave's loop alone */
+        if (true)
+        {
+        }
+        else
+#endif
         if (cnt == (unsigned)DS)
         { // full chunks: two samples per trip (no register copies at the back edge)
 #pragma unroll 1
@@ -1929,24 +1967,18 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
         }
         stores_behind = 2 * cnt;
       }
-      if (BYHAND)
+      if (staging)
       {
-        if (staging)
-        {
-          if (stores_behind >= 64)
-            asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-          else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (stores_behind >= 64)
+          asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-          for (unsigned u = 0; u < DS; u++)
-            stage[(j + 1) & 1][u][lane] = pre_h[u];
+        for (unsigned i = 0; i < DS / 2; i++)
+        { // samples 2 * co_col, 2 * co_col + 1 of channel 4 * i + co_row
+          stage[(j + 1) & 1][2 * co_col][4 * i + co_row] = make_float2(pre_c[i].x, pre_c[i].y);
+          stage[(j + 1) & 1][2 * co_col + 1][4 * i + co_row] = make_float2(pre_c[i].z, pre_c[i].w);
         }
-      }
-      else if (staging)
-      {
-#pragma unroll
-        for (unsigned u = 0; u < DS; u++)
-          stage[(j + 1) & 1][u][lane] = pre[u];
       }
       if (PAIRSYNC)
         lds_publish(done_2nd, j + 1);

@@ -342,6 +342,14 @@ FMD_HD void fmd_atan_table_fill(float* t)
       t[r * 8 + k] = v[r][k];
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+/* two floats as the 64-bit scalar operand of a packed instruction */
+FMD_HD unsigned long long fmd_pack2f(float lo, float hi)
+{
+  return (unsigned long long)fmd_f2u(lo) | ((unsigned long long)fmd_f2u(hi) << 32);
+}
+#endif
+
 /* core: the common-range result and whether this lane needs the literal path instead */
 FMD_HD float fmd_atan2f_tab_core(float y, float x, const float* tab, bool* need_literal)
 {
@@ -385,9 +393,39 @@ FMD_HD float fmd_atan2f_tab_core(float y, float x, const float* tab, bool* need_
   const float xr = fmd_div_midrange(num, den);
   const float z = xr * xr;
   const float w = z * z;
-  const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
-  const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-  const float p = xr * (s1 + s2);
+  /* s1 = z (aT0 + w (aT2 + w (aT4 + w (aT6 + w (aT8 + w aT10))))), s2 = w (aT1 + w (aT3 + w (aT5 +
+   * w (aT7 + w aT9)))) as ONE packed Horner chain (s2's, s1's): s2's chain starts a step later, i.e.
+   * with a leading 0 (0 w + aT9 = aT9 exactly).  On the device one block of eleven packed
+   * instructions with the running pair as the FIRST factor of every multiply: gfx950 needs a wait
+   * slot in front of a packed multiply whose first operand is a broadcast half and whose second is the
+   * previous instruction's result -- the order the compiler picks for this chain (five s_nop) --
+   * and none in this order (what it emits itself for `pair * scalar`). */
+  const fmd_v2f wz = {w, z};
+  fmd_v2f hc;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, %3\n\t"
+      "v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, %4\n\t"
+      "v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, %5\n\t"
+      "v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, %6\n\t"
+      "v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, %7\n\t"
+      "v_pk_mul_f32 %0, %0, %1"
+      : "=&v"(hc)
+      : "v"(wz), "s"(fmd_pack2f(0.0f, aT10)), "s"(fmd_pack2f(aT9, aT8)), "s"(fmd_pack2f(aT7, aT6)),
+        "s"(fmd_pack2f(aT5, aT4)), "s"(fmd_pack2f(aT3, aT2)), "s"(fmd_pack2f(aT1, aT0)));
+#else
+  hc = (fmd_v2f){0.0f, aT10} * w + (fmd_v2f){aT9, aT8};
+  hc = hc * w + (fmd_v2f){aT7, aT6};
+  hc = hc * w + (fmd_v2f){aT5, aT4};
+  hc = hc * w + (fmd_v2f){aT3, aT2};
+  hc = hc * w + (fmd_v2f){aT1, aT0};
+  hc = hc * wz; /* (s2, s1) */
+#endif
+  const float p = xr * (hc[1] + hc[0]);
   const float at = t[4] - ((p - t[5]) - xr); /* atanf(|y/x|) */
   /* quadrant: x >= 0 -> at, x < 0 -> pi - (at - pi_lo); then the sign of y (m = 1, 3 negate) */
   const float left = pi - (at - pi_lo);
@@ -466,16 +504,35 @@ FMD_HD double fmd_fma_const(double x, double a, double b)
 }
 
 #define FMD_SINCOS_P256_SIZE 2048
-/* m16 = -1 / 6: passed in so that a loop can keep it in a vector register (see fmd_fma_const) */
-FMD_HD void fmd_sincos_p256k(float phase, const double* tab /* [2048][2] */, double m16, float* s, float* c)
+/* The two halves of the evaluation, for loops that issue the table read of the NEXT phase as soon as
+ * that phase is known and finish it an iteration later (the read's latency, ~70 cycles for a lone wave,
+ * then lies under independent work instead of at the head of the sample). */
+struct FmdSincosP256
+{
+  double S, C; /* (sin, cos)(k / 256) */
+  float r;     /* phase - k / 256, exact */
+};
+FMD_HD struct FmdSincosP256 fmd_sincos_p256_lookup(float phase, const double* tab /* [2048][2] */)
 {
   const float big = 49152.0f;
   const float t = phase + big;
   const uint32_t k = fmd_f2u(t) & (FMD_SINCOS_P256_SIZE - 1);
   const float kx = t - big;
-  const double r = (double)(phase - kx);
-  const double S = tab[2 * k];
-  const double C = tab[2 * k + 1];
+  struct FmdSincosP256 e;
+  e.r = phase - kx;
+#ifdef FMD_DBG_NO_TABLE
+  e.S = 0.6 + 0 * (double)k, e.C = 0.8;
+  (void)tab;
+#else
+  e.S = tab[2 * k];
+  e.C = tab[2 * k + 1];
+#endif
+  return e;
+}
+/* m16 = -1 / 6: passed in so that a loop can keep it in a vector register (see fmd_fma_const) */
+FMD_HD void fmd_sincos_p256_finish(struct FmdSincosP256 e, double m16, float* s, float* c)
+{
+  const double r = (double)e.r, S = e.S, C = e.C;
   const double r2 = r * r;
   const double sr = __builtin_fma(r * r2, fmd_fma_const(r2, 1.0 / 120.0, m16), r);
   const double cm1 = r2 * __builtin_fma(r2, 1.0 / 24.0, -0.5);
@@ -483,6 +540,10 @@ FMD_HD void fmd_sincos_p256k(float phase, const double* tab /* [2048][2] */, dou
   const double co = C + __builtin_fma(-S, sr, C * cm1);
   *s = (float)so;
   *c = (float)co;
+}
+FMD_HD void fmd_sincos_p256k(float phase, const double* tab /* [2048][2] */, double m16, float* s, float* c)
+{
+  fmd_sincos_p256_finish(fmd_sincos_p256_lookup(phase, tab), m16, s, c);
 }
 FMD_HD void fmd_sincos_p256(float phase, const double* tab /* [2048][2] */, float* s, float* c)
 {

@@ -155,8 +155,9 @@ int main(int argc, char** argv)
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   std::vector<long long> probe(size_t(3) * groups);
-  for (int form = 0; form < 2; form++)
-  { // 0: whole-CU form (two groups per workgroup), 1: shared form (one group per workgroup)
+  for (int form = 0; form < (getenv("SS_ALL_FORMS") ? 4 : 2); form++)
+  { // 0: whole-CU form (two groups per workgroup), 1: shared form (one group per workgroup);
+    // SS_ALL_FORMS=1 also runs 2: <2,false> and 3: <1,true> (what the register claim and the group count each cost)
     CK(hipMemset(d_f, 0, size_t(fmd::F_SLOTS) * CP * 4)); // both forms start from a fresh decoder
     CK(hipMemset(d_i, 0, size_t(fmd::I_SLOTS) * CP * 4));
     {
@@ -174,8 +175,14 @@ int main(int argc, char** argv)
       if (form == 0)
         hipLaunchKernelGGL((fmd::k_demod_serial<2, true>), dim3((groups + 1) / 2), dim3(256), 0, nullptr, d_demod,
                            Mstride, M, C, CP, k, st, brp, Hbb, d_mix, Hmix, d_tab, sct, unsigned(l & 3), d_probe);
-      else
+      else if (form == 1)
         hipLaunchKernelGGL((fmd::k_demod_serial<1, false>), dim3(groups), dim3(128), 0, nullptr, d_demod, Mstride,
+                           M, C, CP, k, st, brp, Hbb, d_mix, Hmix, d_tab, sct, unsigned(l & 3), d_probe);
+      else if (form == 2)
+        hipLaunchKernelGGL((fmd::k_demod_serial<2, false>), dim3((groups + 1) / 2), dim3(256), 0, nullptr, d_demod,
+                           Mstride, M, C, CP, k, st, brp, Hbb, d_mix, Hmix, d_tab, sct, unsigned(l & 3), d_probe);
+      else
+        hipLaunchKernelGGL((fmd::k_demod_serial<1, true>), dim3(groups), dim3(128), 0, nullptr, d_demod, Mstride,
                            M, C, CP, k, st, brp, Hbb, d_mix, Hmix, d_tab, sct, unsigned(l & 3), d_probe);
       CK(hipEventRecord(e1, nullptr));
       CK(hipDeviceSynchronize());
@@ -186,7 +193,7 @@ int main(int argc, char** argv)
         continue; // warm-up
       ms_sum += ms;
       cnt++;
-      const unsigned nwg = form == 0 ? (groups + 1) / 2 : groups;
+      const unsigned nwg = (form == 0 || form == 2) ? (groups + 1) / 2 : groups;
       double s = 0, mx = 0;
       for (unsigned w = 0; w < nwg; w++)
       {
@@ -210,7 +217,7 @@ int main(int argc, char** argv)
     h = fnv(si.data(), si.size() * 4, h);
     printf("%s  C=%u M=%u: %.4f ms per launch, %.4f Mcycles per workgroup (max %.4f), %.1f cycles/sample, "
            "err=%u, hash=%016llx\n",
-           form == 0 ? "k_demod_serial<2,true> " : "k_demod_serial<1,false>", C, M, ms_sum / cnt,
+           form == 0 ? "k_demod_serial<2,true> " : form == 1 ? "k_demod_serial<1,false>" : form == 2 ? "k_demod_serial<2,false>" : "k_demod_serial<1,true> ", C, M, ms_sum / cnt,
            cyc_sum / cnt / 1e6, cyc_max / 1e6, cyc_sum / cnt / M, h_err[0], (unsigned long long)h);
   }
   return 0;
