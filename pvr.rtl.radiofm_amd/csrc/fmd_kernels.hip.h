@@ -1815,10 +1815,6 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     // are the staged chunk's, and nothing in the sample loop waits for them
     __builtin_amdgcn_s_waitcnt(0);
     FmdSincosP256 p_sc = fmd_sincos_p256_lookup(p_phase, sctab); // pilot NCO: one sample ahead
-#ifdef FMD_DBG_DEPHASE
-    if (NG > 1 && grp == 1)
-      __builtin_amdgcn_s_sleep(FMD_DBG_DEPHASE);
-#endif
     float vsum = 0.0f, vsumsq = 0.0f;
     /* The two per-sample stores: wave-uniform row bases plus ONE 32-bit byte offset per lane that
      * advances a row per sample (the row buffers stay below 4 GB).  Padded lanes shadow the last
@@ -1904,11 +1900,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
             p_q2 = p_q1;
             p_q1 = ph_q;
             /* :194-201 as selects; the quotient is formed unconditionally and only used in lock */
-#ifdef FMD_DBG_NO_DIV
-            const float ratio = ph_q * 0.5f;
-#else
             const float ratio = ph_q / ph_i;
-#endif
             const float sgn = (ph_q > 0) ? 1.0f : -1.0f;
             const float perr = (ph_i > fabsf(ph_q)) ? ratio : sgn;
             p_level = (ph_i < p_level) ? ph_i : p_level;

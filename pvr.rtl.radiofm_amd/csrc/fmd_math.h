@@ -520,13 +520,8 @@ FMD_HD struct FmdSincosP256 fmd_sincos_p256_lookup(float phase, const double* ta
   const float kx = t - big;
   struct FmdSincosP256 e;
   e.r = phase - kx;
-#ifdef FMD_DBG_NO_TABLE
-  e.S = 0.6 + 0 * (double)k, e.C = 0.8;
-  (void)tab;
-#else
   e.S = tab[2 * k];
   e.C = tab[2 * k + 1];
-#endif
   return e;
 }
 /* m16 = -1 / 6: passed in so that a loop can keep it in a vector register (see fmd_fma_const) */
