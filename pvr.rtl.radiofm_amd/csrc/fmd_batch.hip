@@ -747,7 +747,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     // that the extra concurrent kernels only stretch the latency-bound serial stage (-4 % at
     // 8192), so they share one stream.  FMD_SPLIT_POST=0/1 overrides.
     b->split_post = b->CP > 16384;
-    // The serial stage owns whole CUs while that costs at most a quarter of the chip (<= 8192
+    // The serial stage takes whole CUs (one role wave per SIMD) while that costs at most a quarter of the chip (<= 8192
     // channels = 64 CUs; +4.4 % at 8192 channels) and the batch is big enough for the bandwidth
     // kernels to notice their neighbours at all.  FMD_SERIAL_EXCLUSIVE=0/1 overrides.
     b->serial_exclusive = b->CP <= 8192 && b->CP >= 1024;
@@ -1253,23 +1253,32 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     k.osc_cos = d.rds_osc_cos;
     k.osc_sin = d.rds_osc_sin;
     // Up to 8192 channels the batch is latency-bound by this stage and needs at most 64 CUs for
-    // it: two channel groups per workgroup, each workgroup owning its CU (k_demod_serial, EXCL).
+    // it: two channel groups per workgroup, one role wave per SIMD of a CU (k_demod_serial).
     // Larger batches need the CUs for throughput and keep the shared form.
     const unsigned groups = CP / 64;
     const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
     const unsigned Hmix = unsigned(d.hb[0].len - 1);
+    /* Two groups per workgroup = one role wave on each SIMD of a CU, 64 CUs for 8192 channels.  The
+     * waves no longer claim their SIMD's whole register file (round 3): since the staging and the table
+     * read were taken off the stage's critical path it has ~10 % slack against the period, and the
+     * bandwidth kernels' waves that now fit beside it (131 of the CU's 160 KB of LDS are the stage's, so
+     * mostly kernels without LDS) gain more than the stage loses: +2.1 %, +-0, +1.4 % whole path on three
+     * boxes, never slower (stage 1.71 -> 1.83 ms, FIR 1.02 -> 0.97 ms inside the pipeline on the
+     * first).  FMD_SERIAL_CLAIM=1 brings the claim back. */
+    static const bool serial_claim = getenv("FMD_SERIAL_CLAIM") && atoi(getenv("FMD_SERIAL_CLAIM")) != 0;
+    auto kser2 = serial_claim ? &fmd::k_demod_serial<2, true> : &fmd::k_demod_serial<2, false>;
     if (b->serial_exclusive && !serial_mode && evset && b->profiling == 1)
       // profiling level 1: the stage's own start and stop too (fmd_batch_debug_timeline)
-      hipExtLaunchKernelGGL((fmd::k_demod_serial<2, true>), dim3((groups + 1) / 2), dim3(256), 0u, sS, evset[2],
+      hipExtLaunchKernelGGL(kser2, dim3((groups + 1) / 2), dim3(256), 0u, sS, evset[2],
                             evset[3], 0u, (const float2*)b->demod[q].p, b->Mstride, M, C, CP, k, b->st,
                             b->brp(q), Hbb, b->mix[q].p, Hmix,
                             (const double*)(b->sctab256.p), sct, unsigned(sq),
                             (long long*)nullptr);
     else if (b->serial_exclusive && !serial_mode)
-      hipLaunchKernelGGL((fmd::k_demod_serial<2, true>), dim3((groups + 1) / 2), dim3(256), 0, sS,
-                         b->demod[q].p, b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p,
-                         Hmix, b->sctab256.p, sct, unsigned(sq),
-                         b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : nullptr);
+      hipLaunchKernelGGL(kser2, dim3((groups + 1) / 2), dim3(256), 0, sS,
+                         (const float2*)b->demod[q].p, b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p,
+                         Hmix, (const double*)b->sctab256.p, sct, unsigned(sq),
+                         b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : (long long*)nullptr);
     else
       hipLaunchKernelGGL((fmd::k_demod_serial<1, false>), dim3(groups), dim3(128), 0, sS, b->demod[q].p,
                          b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p, Hmix,

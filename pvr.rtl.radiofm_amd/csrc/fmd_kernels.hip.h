@@ -1589,16 +1589,20 @@ __global__ __launch_bounds__(64) void k_if_level(const typename IN::elem* __rest
 /*     issues one VALU op every ~4 cycles, so the longest role sets the time per sample.       */
 /* ------------------------------------------------------------------------------------------ */
 
-/* NG = channel groups (of 64) per workgroup, one pair of role waves each.  EXCL: every wave claims
- * the whole register file of its SIMD (512 = 256 arch + 256 acc VGPRs), so with NG = 2 a workgroup
- * owns its CU: no bandwidth kernel's wave shares a SIMD with a role wave (such a wave delays each
- * of the recurrence's dependent instructions by up to one 4-cycle issue), and the CUs left to the
- * bandwidth kernels are whole ones.  Only sensible while the batch needs few workgroups (see the
- * launch). */
+/* NG = channel groups (of 64) per workgroup, one pair of role waves each; NG = 2 puts one role wave
+ * on each SIMD of a CU.  EXCL: every wave claims the whole register file of its SIMD (512 = 256 arch +
+ * 256 acc VGPRs), so that no bandwidth kernel's wave shares a SIMD with a role wave (such a wave
+ * delays the recurrence's instructions by up to one 4-cycle issue each).  That was the default while
+ * the stage was the period of the pipeline; now that it has slack the launch leaves the claim off
+ * (fmd_batch.hip). */
 /* Measured and dropped: four groups per workgroup with the two role waves of a group on ONE
  * SIMD (half the register file each, 32 CUs owned): the waves do not fit into each other's issue
  * gaps, the stage takes 3.5 ms (151 GS/s). */
-constexpr int DS = 32; // samples per LDS chunk
+#ifndef FMD_DS
+#define FMD_DS 32
+#endif
+constexpr int DS = FMD_DS; // samples per LDS chunk (32 or 16)
+static_assert(DS == 32 || DS == 16, "chunk size");
 typedef float fmd_v4f __attribute__((ext_vector_type(4)));
 constexpr int STAGE_RS = 65; // row stride of the staged input in LDS (float2 units)
 constexpr unsigned FM_UNROLL = 4; // samples per trip of the FM wave's loop over a full chunk (1, 2, 4: 651 / 599 / 596 cycles per sample)
@@ -1826,11 +1830,14 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     const unsigned row_step = CP * (unsigned)sizeof(float2);
     // staging (see the chunk loop): this lane's 16 bytes of the rows 4 i + co_row, as 32-bit byte
     // offsets from the chunk's first sample in channel 0's row (the host keeps the buffer below 4 GB)
-    const unsigned co_row = lane >> 4, co_col = lane & 15u;
+    constexpr unsigned CO_LPR = DS / 2;      // lanes per row: a chunk of a row is DS * 8 bytes, 16 per lane
+    constexpr unsigned CO_RPI = 64 / CO_LPR; // rows per instruction
+    const unsigned co_row = lane / CO_LPR, co_col = lane % CO_LPR;
     unsigned co_off[DS / 2];
 #pragma unroll
     for (unsigned i = 0; i < DS / 2; i++)
-      co_off[i] = min((blockIdx.x * NG + grp) * 64 + 4 * i + co_row, C - 1) * (Mstride * (unsigned)sizeof(float2)) +
+      co_off[i] = min((blockIdx.x * NG + grp) * 64 + CO_RPI * i + co_row, C - 1) *
+                      (Mstride * (unsigned)sizeof(float2)) +
                   co_col * 16u;
     for (unsigned j = 0; j <= nchunks; j++)
     {
@@ -1846,8 +1853,8 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
        * LAST operations too -- the two stores of the sample just finished, 3-8 us under load --
        * and a second wave that late makes the FM wave wait (seen per workgroup with the probe: up
        * to +13 % cycles, in a third of the workgroups of a launch).  Vector memory operations
-       * retire in issue order: with the 64 stores of a full chunk behind the 16 loads,
-       * `s_waitcnt vmcnt(63)` is enough, and the oldest of those stores is a chunk old.
+       * retire in issue order: with the 2 DS stores of a full chunk behind the DS / 2 loads,
+       * `s_waitcnt vmcnt(2 DS - 1)` is enough, and the oldest of those stores is a chunk old.
        * (A ragged last chunk is loaded whole: the host leaves DS samples of slack behind the last
        * channel's row; what lies beyond M is never used.) */
       /* The loads are cooperative: a chunk is 64 rows (channels) of 256 contiguous bytes, and a lane
@@ -1961,15 +1968,20 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
       }
       if (staging)
       {
-        if (stores_behind >= 64)
-          asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        if (stores_behind >= 2 * DS)
+        {
+          if (DS == 32)
+            asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(31)" ::: "memory");
+        }
         else
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (unsigned i = 0; i < DS / 2; i++)
-        { // samples 2 * co_col, 2 * co_col + 1 of channel 4 * i + co_row
-          stage[(j + 1) & 1][2 * co_col][4 * i + co_row] = make_float2(pre_c[i].x, pre_c[i].y);
-          stage[(j + 1) & 1][2 * co_col + 1][4 * i + co_row] = make_float2(pre_c[i].z, pre_c[i].w);
+        { // samples 2 * co_col, 2 * co_col + 1 of channel CO_RPI * i + co_row
+          stage[(j + 1) & 1][2 * co_col][CO_RPI * i + co_row] = make_float2(pre_c[i].x, pre_c[i].y);
+          stage[(j + 1) & 1][2 * co_col + 1][CO_RPI * i + co_row] = make_float2(pre_c[i].z, pre_c[i].w);
         }
       }
       if (PAIRSYNC)
