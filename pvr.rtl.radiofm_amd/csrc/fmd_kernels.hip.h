@@ -1686,16 +1686,16 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
          * instructions it issues (one wave per SIMD, ~5 cycles each whatever their class): everything
          * below is written for that count.  Returns whether the sample met a rare input (arctangent
          * outside the table form's range): its result is then meaningless and the caller redoes it. */
-        auto fm_sample = [&](unsigned u) -> bool {
+        auto fm_sample = [&](unsigned u) -> uint32_t {
           const float2 sin_ = stage[j & 1][u][lane]; // staged one chunk ahead by the other wave
           const float sre = sin_.x, sim = sin_.y;
           float sn, cs;
-          fmd_sincos_p256k(nco_phase, sctab, m16, &sn, &cs);
+          fmd_sincos_p256_finish(fmd_sincos_p256_lookup_lds(nco_phase, sctab), m16, &sn, &cs);
           // ComplexType(Cos, Sin) * signal[i] as three packed operations:
           // (cs sre, cs sim) + (-(sn sim), sn sre)  [fmd_pk_add_cross: (a.x - b.y, a.y + b.x)]
           const fmd_v2f dd = fmd_pk_add_cross((fmd_v2f){sre, sim} * cs, (fmd_v2f){sre, sim} * sn);
           const float dre = dd.x, dim = dd.y;
-          bool lit;
+          uint32_t lit; // >= FMD_ATAN_RARE_LIMIT: the sample needs the literal path
           const float err = -fmd_atan2f_tab_core(dim, dre, atab, &lit);
           /* :399-402 as max / min: the same as the reference's two compares for every number; a
            * NaN state (only ever out of non-finite input) goes through the literal path */
@@ -1768,11 +1768,11 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           for (unsigned u = 0; u < (unsigned)DS; u += FM_UNROLL)
           {
             const float phase_g = nco_phase, incr_g = nco_incr;
-            bool any = false;
+            uint32_t worst = 0; // the group's largest rare measure: one unsigned maximum per sample
 #pragma unroll
             for (unsigned v = 0; v < FM_UNROLL; v++)
-              any |= fm_sample(u + v);
-            if (__builtin_expect(any, 0))
+              worst = max(worst, fm_sample(u + v));
+            if (__builtin_expect(FMD_ANY_LANE(worst >= FMD_ATAN_RARE_LIMIT), 0))
             {
               nco_phase = phase_g;
               nco_incr = incr_g;
@@ -1788,7 +1788,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           for (unsigned u = 0; u < cnt; u++)
           {
             const float phase_g = nco_phase, incr_g = nco_incr;
-            if (__builtin_expect(fm_sample(u), 0))
+            if (__builtin_expect(FMD_ANY_LANE(fm_sample(u) >= FMD_ATAN_RARE_LIMIT), 0))
             {
               nco_phase = phase_g;
               nco_incr = incr_g;
@@ -1818,7 +1818,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     // the state is in registers before the chunk loop starts: inside it, the only loads in flight
     // are the staged chunk's, and nothing in the sample loop waits for them
     __builtin_amdgcn_s_waitcnt(0);
-    FmdSincosP256 p_sc = fmd_sincos_p256_lookup(p_phase, sctab); // pilot NCO: one sample ahead
+    FmdSincosP256 p_sc = fmd_sincos_p256_lookup_lds(p_phase, sctab); // pilot NCO: one sample ahead
     float vsum = 0.0f, vsumsq = 0.0f;
     /* The two per-sample stores: wave-uniform row bases plus ONE 32-bit byte offset per lane that
      * advances a row per sample (the row buffers stay below 4 GB).  Padded lanes shadow the last
@@ -1924,7 +1924,7 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
             }
             /* the next sample's table entry: its LDS latency lies under the oscillator and the stores
              * below (the barrier keeps the compiler from moving those in front of the read) */
-            p_sc = fmd_sincos_p256_lookup(p_phase, sctab);
+            p_sc = fmd_sincos_p256_lookup_lds(p_phase, sctab);
             __builtin_amdgcn_sched_barrier(0);
             /* ---- RDS oscillator mix (DownConvert.cpp:436-442, :464-465), imag(input) == 0 ---- */
             float2 osc;

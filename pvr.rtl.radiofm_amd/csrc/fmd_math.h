@@ -351,7 +351,10 @@ FMD_HD unsigned long long fmd_pack2f(float lo, float hi)
 #endif
 
 /* core: the common-range result and whether this lane needs the literal path instead */
-FMD_HD float fmd_atan2f_tab_core(float y, float x, const float* tab, bool* need_literal)
+/* rare_measure: iq - 0x31000000 as an unsigned number; the lane needs the literal function when it is
+ * >= FMD_ATAN_RARE_LIMIT (a loop takes the maximum over a group of samples and tests once) */
+#define FMD_ATAN_RARE_LIMIT (0x4c000000u - 0x31000000u)
+FMD_HD float fmd_atan2f_tab_core(float y, float x, const float* tab, uint32_t* rare_measure)
 {
   const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
               aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
@@ -360,7 +363,7 @@ FMD_HD float fmd_atan2f_tab_core(float y, float x, const float* tab, bool* need_
   const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
   const float q = fabsf(y / x);
   const uint32_t iq = fmd_f2u(q);
-  const bool rare = iq - 0x31000000u >= 0x4c000000u - 0x31000000u; /* see above */
+  const uint32_t rare_m = iq - 0x31000000u; /* >= FMD_ATAN_RARE_LIMIT: see above */
   /* the common-range evaluation runs for every lane (a rare lane computes a value nobody uses:
    * its range index is clamped, nothing here can trap) */
   /* no clamp for the rare lanes: whatever their bits are, the range index below stays within 0..4,
@@ -430,14 +433,15 @@ FMD_HD float fmd_atan2f_tab_core(float y, float x, const float* tab, bool* need_
   /* quadrant: x >= 0 -> at, x < 0 -> pi - (at - pi_lo); then the sign of y (m = 1, 3 negate) */
   const float left = pi - (at - pi_lo);
   const float base = ((int32_t)fmd_f2u(x) < 0) ? left : at;
-  *need_literal = rare;
+  *rare_measure = rare_m;
   return fmd_u2f(fmd_f2u(base) ^ (fmd_f2u(y) & 0x80000000u));
 }
 
 FMD_HD float fmd_atan2f_tab(float y, float x, const float* tab)
 {
-  bool rare;
-  float res = fmd_atan2f_tab_core(y, x, tab, &rare);
+  uint32_t rare_m;
+  float res = fmd_atan2f_tab_core(y, x, tab, &rare_m);
+  const bool rare = rare_m >= FMD_ATAN_RARE_LIMIT;
   if (FMD_ANY_LANE(rare))
   {
     if (rare)
@@ -524,12 +528,46 @@ FMD_HD struct FmdSincosP256 fmd_sincos_p256_lookup(float phase, const double* ta
   e.C = tab[2 * k + 1];
   return e;
 }
+/* The same lookup for a table in LDS: with 2^15 instead of 1.5 * 2^15 as the rounding constant (the
+ * phases here are never negative) the low 24 bits of the sum ARE k, so the entry's byte offset is one
+ * 24-bit multiply instead of a shift and a mask.  A NaN or infinite phase makes an offset beyond the
+ * LDS allocation: such a read returns 0 and the result is NaN through r anyway. */
+FMD_HD struct FmdSincosP256 fmd_sincos_p256_lookup_lds(float phase, const double* tab)
+{
+  const float big = 32768.0f;
+  const float t = phase + big;
+  uint32_t off; /* (the compiler turns a multiply by 16 back into shift + mask) */
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mul_u32_u24 %0, %1, 16" : "=v"(off) : "v"(t));
+#else
+  off = (fmd_f2u(t) & 0xffffffu) * 16u;
+#endif
+  const float kx = t - big;
+  struct FmdSincosP256 e;
+  e.r = phase - kx;
+  typedef double fmd_v2d_ __attribute__((vector_size(16))); /* 16-byte aligned: one 16-byte read */
+  const fmd_v2d_ sc = *(const fmd_v2d_*)((const char*)tab + off);
+  e.S = sc[0];
+  e.C = sc[1];
+  return e;
+}
 /* m16 = -1 / 6: passed in so that a loop can keep it in a vector register (see fmd_fma_const) */
 FMD_HD void fmd_sincos_p256_finish(struct FmdSincosP256 e, double m16, float* s, float* c)
 {
   const double r = (double)e.r, S = e.S, C = e.C;
   const double r2 = r * r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  /* r + r^3 (r^2 / 120 - 1 / 6): both multiply-adds in one block, so that the wait slot the compiler
+   * puts behind an inline-asm result falls on an instruction that does not need it (the next one
+   * here is the cosine series, independent of this) */
+  double sr, st;
+  asm("v_fma_f64 %1, %2, %3, %4\n\t"
+      "v_fma_f64 %0, %5, %1, %6"
+      : "=&v"(sr), "=&v"(st)
+      : "v"(r2), "s"(1.0 / 120.0), "v"(m16), "v"(r * r2), "v"(r));
+#else
   const double sr = __builtin_fma(r * r2, fmd_fma_const(r2, 1.0 / 120.0, m16), r);
+#endif
   const double cm1 = r2 * __builtin_fma(r2, 1.0 / 24.0, -0.5);
   const double so = S + __builtin_fma(C, sr, S * cm1);
   const double co = C + __builtin_fma(-S, sr, C * cm1);

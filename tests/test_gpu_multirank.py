@@ -51,6 +51,14 @@ def test_single_rank_verify_full_shard():
     assert d["n_gpus"] == 1 and d["verify"]["ok"] and d["verify"]["channels_per_rank"] == [0, 1, 4096, 8191]
 
 
+def test_single_rank_verify_with_the_register_claim(monkeypatch):
+    """The serial stage's other whole-CU form (every role wave claims its SIMD's register file,
+    FMD_SERIAL_CLAIM=1: the default until round 3's last change) on the same check."""
+    monkeypatch.setenv("FMD_SERIAL_CLAIM", "1")
+    d = _run_bench(1, ["--steps", "8", "--warmup", "2", "--ring", "4"], 29547)
+    assert d["n_gpus"] == 1 and d["verify"]["ok"]
+
+
 def test_rccl_path_with_a_world_of_one():
     """What one GPU can run of the RCCL path: FMD_BENCH_FORCE_DIST=1 initialises the nccl (= RCCL)
     communicator with a single rank and makes every call of the N > 1 path -- pre-flight gather,
