@@ -1205,7 +1205,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     // ~25 % slower.  The rest of that chain (RDS PLL, matched filter, bit recovery, audio tail) is
     // lane-per-channel work that leaves most CUs idle: the FIR runs beside it.
     // (behind the RDS half only, i.e. beside the resampler and the audio low-pass: measured, the FIR then
-    // takes 1.00 instead of 0.95 ms and the period does not move)
+    // takes 1.00 instead of 0.95 ms and the period does not move; again with the faster serial stage of
+    // round 3's end, which has slack: FIR 1.09 instead of 0.98 ms, period the same 2.00-2.01 ms)
     after(sF, pe2[fmd_batch::EV_HEAVY]);
   }
   {
