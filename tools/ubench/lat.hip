@@ -29,7 +29,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 template <int MODE>
 __global__ void k(long long* out, float* sink, int iters)
 {
-  __shared__ unsigned lds[1024];
+  __shared__ __attribute__((aligned(16))) unsigned lds[8192]; // 32 KB
   for (unsigned i = threadIdx.x; i < 1024; i += blockDim.x)
     lds[i] = (i * 4u) & 0xffcu; // a pointer chain inside the array
   __syncthreads();
@@ -39,6 +39,7 @@ __global__ void k(long long* out, float* sink, int iters)
   double da = a, db = b, dc = c, dd = d, dm = m, dn = n;
   unsigned ia = threadIdx.x, ib = ia + 1, ic = ia + 2, id = ia + 3;
   unsigned la = (threadIdx.x * 4u) & 0xffcu;
+  const unsigned la46 = (threadIdx.x & 63u) * 368u;
   asm volatile("" : "+v"(m), "+v"(n), "+v"(pm), "+v"(pn), "+v"(dm), "+v"(dn));
   long long t0 = __builtin_readcyclecounter();
   for (int i = 0; i < iters; i++)
@@ -92,6 +93,31 @@ __global__ void k(long long* out, float* sink, int iters)
       asm volatile(R60("v_div_scale_f32 %0, vcc, %0, %1, %0\n s_nop 1\n v_div_fmas_f32 %0, %0, %1, %1\n v_div_fixup_f32 %0, %0, %1, %1\n") : "+v"(a) : "v"(m) : "vcc");
     else if (MODE == 22) // s_nop 0 alone
       asm volatile(R240("s_nop 0\n"));
+    else if (MODE == 24 || MODE == 25)
+    { // k_if_fir's long-filter half iteration (16 taps): 16 packed multiplies by SGPR taps, 16 packed
+      // adds in one chain, products two ahead; MODE 25 with the eight 16-byte LDS reads of the next
+      // batch issued in front and waited for at the end, as in fir_long_b128_asm
+#define TAPMUL(t, x) "v_pk_mul_f32 v[" #t ":" #t "+1], v[" #x ":" #x "+1], s[20:21] op_sel_hi:[1,0]\n"
+#define TAPADD(t) "v_pk_add_f32 %0, %0, v[" #t ":" #t "+1]\n"
+#define HALF_READS "ds_read_b128 v[64:67], %1 offset:112\n ds_read_b128 v[68:71], %1 offset:96\n ds_read_b128 v[72:75], %1 offset:80\n ds_read_b128 v[76:79], %1 offset:64\n ds_read_b128 v[80:83], %1 offset:48\n ds_read_b128 v[84:87], %1 offset:32\n ds_read_b128 v[88:91], %1 offset:16\n ds_read_b128 v[92:95], %1\n"
+#define HALF_MAC TAPMUL(128, 96) TAPMUL(130, 98) TAPADD(128) TAPMUL(132, 100) TAPADD(130) TAPMUL(134, 102) TAPADD(132) TAPMUL(128, 104) TAPADD(134) TAPMUL(130, 106) TAPADD(128) TAPMUL(132, 108) TAPADD(130) TAPMUL(134, 110) TAPADD(132) TAPMUL(128, 112) TAPADD(134) TAPMUL(130, 114) TAPADD(128) TAPMUL(132, 116) TAPADD(130) TAPMUL(134, 118) TAPADD(132) TAPMUL(128, 120) TAPADD(134) TAPMUL(130, 122) TAPADD(128) TAPMUL(132, 124) TAPADD(130) TAPMUL(134, 126) TAPADD(132) TAPADD(134)
+      if (MODE == 24)
+        asm volatile("s_mov_b32 s20, 0x3f800000\n s_mov_b32 s21, 0x3f800000\n" R4(HALF_MAC)
+                     : "+v"(pa) : "v"(la)
+                     : "s20", "s21", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106",
+                       "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118",
+                       "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130",
+                       "v131", "v132", "v133", "v134", "v135");
+      else
+        asm volatile("s_mov_b32 s20, 0x3f800000\n s_mov_b32 s21, 0x3f800000\n" R4(HALF_READS HALF_MAC "s_waitcnt lgkmcnt(0)\n")
+                     : "+v"(pa) : "v"(la46) // lanes 46 samples = 368 bytes apart: conflict-free 16-byte reads
+                     : "s20", "s21", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
+                       "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89",
+                       "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102",
+                       "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
+                       "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126",
+                       "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "memory");
+    }
     else if (MODE == 23) // scalar ALU dependent
       asm volatile(R240("s_add_u32 s20, s20, 1\n") ::: "s20", "scc");
   }
@@ -121,7 +147,7 @@ void run(const char* name, int per_trip, int threads)
 
 int main()
 {
-  for (int th : {64, 512})
+  for (int th : {64, 256, 512})
   {
     run<0>("v_fma_f32, each needs the previous one's result", 240, th);
     run<2>("v_fma_f32, two independent chains", 240, th);
@@ -147,6 +173,8 @@ int main()
     run<13>("ds_read_b32 -> s_waitcnt -> its own address (per read)", 60, th);
     run<22>("s_nop 0", 240, th);
     run<23>("s_add_u32 dependent", 240, th);
+    run<24>("long-filter half iteration, 16 taps = 32 packed instructions (per half)", 4, th);
+    run<25>("the same with its 8 ds_read_b128 + s_waitcnt (per half)", 4, th);
   }
   return 0;
 }
