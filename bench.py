@@ -194,6 +194,12 @@ def main():
                          "On by default with more than one rank (a multi-GPU number is only reported for "
                          "a gather that was checked); --no-verify turns it off")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--side-stream", action="store_true",
+                    help="development: submit from a non-default torch stream (the null stream orders itself "
+                         "against every blocking stream of the process)")
+    ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE",
+                    help="development switch of the batch (fmd_batch_debug_set), e.g. resampler=0; "
+                         "recorded in the JSON line; the reported figures use none")
     ap.add_argument("--watchdog", type=int, default=900,
                     help="seconds after which a run that has not finished kills itself (a hung "
                          "collective or kernel must not keep the box busy)")
@@ -230,6 +236,8 @@ def main():
         local_rank = 0  # development aid, see below
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.side_stream:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     # RCCL ("nccl") on a real multi-GPU node.  FMD_BENCH_BACKEND=gloo + FMD_BENCH_SHARE_GPU=1 is a
     # development aid: several ranks on ONE GPU with a host-staged gather, to exercise the N > 1
     # control flow where only one GPU exists.
@@ -309,6 +317,9 @@ def main():
                                       table_size=table, if_filter_order=order,
                                       fir_reduction=args.fir_reduction),
                       C, tuning_shifts=shifts, device=local_rank, record_callbacks=False)
+    for kv in args.debug_set:
+        key, _, val = kv.partition("=")
+        batch.debug_set(key, int(val))
     a_stride = (batch.max_audio_floats(N) + 63) // 64 * 64
     NBUF = args.lag + 3  # outputs are consumed LAG steps after they are produced, then gathered
     audio = [torch.zeros((C, a_stride), dtype=torch.float32, device=dev) for _ in range(NBUF)]
@@ -685,6 +696,8 @@ def main():
                     and t.get("samples_per_call") == N):
                 out["roofline"]["traffic"] = t["bytes_per_launch"]
                 out["roofline"]["traffic_source"] = t["source"]
+        if args.debug_set:
+            out["config"]["debug_set"] = args.debug_set
         if verify is not None:
             out["verify"] = verify
         if per_rank is not None:

@@ -306,6 +306,13 @@ int fmd_batch_debug_timeline(fmd_batch* b, float* out, unsigned cap_calls);
 /* Test aid: bound (in polls) of the serial stage's LDS hand-off waits for the calls that follow;
  * 0 makes every wait time out at once, which exercises the device-side error path. */
 int fmd_batch_debug_set_spin_limit(fmd_batch* b, unsigned limit);
+/* Development switches of one batch, by name (the shipped library reads NO environment variable).
+ * They select between implementations that give identical results, or add instrumentation; they
+ * apply to the calls that follow and may be changed while no call is in flight.  Returns FMD_ERR_ARG
+ * for an unknown key.  Keys: see fmd_batch_debug_set in csrc/fmd_batch.hip ("resampler": -1 the
+ * library decides, 0 window per wave (k_resample), 1 LDS ring (k_resample_ring) wherever the
+ * geometry allows it; ...). */
+int fmd_batch_debug_set(fmd_batch* b, const char* key, int value);
 
 const char* fmd_last_error(void);
 const char* fmd_version(void);

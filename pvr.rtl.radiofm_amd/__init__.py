@@ -112,7 +112,7 @@ EXPORTS = [
     "fmd_version", "fmd_group_decoder_create", "fmd_group_decoder_destroy",
     "fmd_group_decoder_reset", "fmd_group_decoder_push", "fmd_uecp_stuff_frame",
     "fmd_batch_take_rds_lost", "fmd_batch_status_call_index",
-    "fmd_batch_debug_set_spin_limit", "fmd_batch_debug_timeline",
+    "fmd_batch_debug_set_spin_limit", "fmd_batch_debug_timeline", "fmd_batch_debug_set",
 ]
 
 
@@ -201,6 +201,7 @@ def lib():
         L.fmd_batch_status_call_index.argtypes = [vp, u, C.POINTER(C.c_uint32)]
         L.fmd_batch_debug_set_spin_limit.argtypes = [vp, u]
         L.fmd_batch_debug_timeline.argtypes = [vp, vp, u]
+        L.fmd_batch_debug_set.argtypes = [vp, C.c_char_p, i]
         _LIB = L
     return _LIB
 
@@ -368,6 +369,10 @@ class Batch:
 
     def debug_set_spin_limit(self, limit):
         _check(lib().fmd_batch_debug_set_spin_limit(self._h, limit))
+
+    def debug_set(self, key, value):
+        """Development switch of this batch by name (fmd_batch_debug_set)."""
+        _check(lib().fmd_batch_debug_set(self._h, key.encode(), int(value)))
 
     def status(self, channel=0):
         st = FmdStatus()

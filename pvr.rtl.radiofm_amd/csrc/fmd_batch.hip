@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -117,8 +118,18 @@ struct fmd_batch
   DevBuf<float> rpll, rmf, tap_sync;
   DevBuf<double> sctab, sctab256; // fmd_sincos_tab / fmd_sincos_p256 (the serial stage's two NCOs)
   DevBuf<int> pidx;
-  float2* brp(int q) const { return br[q].p + size_t(2 * fmd::RS_B) * CP; } // row 0 of br[q]
+  static constexpr unsigned kBrFront = 32; // rows of zeros in front of the history rows (both resamplers reach below)
+  float2* brp(int q) const { return br[q].p + size_t(kBrFront) * CP; } // first history row of br[q]
   unsigned rs_margin = 0, rs_row = 0; // ktab: zero entries around each output's taps, row length
+  // k_resample_ring (large batches): outputs per wave (0 = this geometry does not fit the CU's LDS),
+  // ring batches, batches per group in the tap table, row offset; plan buffers; -1 auto / 0 off / 1 on
+  int rsr_R = 0, rsr_NW = 0;
+  unsigned rsr_nbr = 0, rsr_nbm = 0, rsr_exp = 0, rsr_pace = 0;
+  int rsr_rb = 0;
+  DevBuf<float> rsr_tab;
+  DevBuf<int> rsr_head, rsr_steps;
+  int rsr_mode = -1;
+  int n_cus = 256;
   DevBuf<long long> serial_probe; // FMD_SERIAL_PROBE=1: per-workgroup timing of the serial stage
   DevBuf<float> fstate; // all float state arrays, CP each
   DevBuf<int> istate;
@@ -204,6 +215,7 @@ struct fmd_batch
   // (fmd::HostStatusWord): what the getters read -- no device call, no batch bookkeeping touched,
   // so they are safe from any thread while another one is inside a process call.
   unsigned* h_status = nullptr;
+  DevBuf<unsigned> d_status; // the same record in device memory: what the kernels write (k_status_publish copies)
   unsigned host_seq = 0; // tags of snapshot updates made by the host (create, reset)
 
   ~fmd_batch()
@@ -233,6 +245,9 @@ struct fmd_batch
     mf_taps2.release();
     audio_taps.release();
     ktab.release();
+    rsr_tab.release();
+    rsr_head.release();
+    rsr_steps.release();
     rpll.release();
     rmf.release();
     tap_sync.release();
@@ -274,6 +289,7 @@ struct fmd_batch
       (void)hipHostFree(h_err);
     if (h_status)
       (void)hipHostFree(h_status);
+    d_status.release();
     for (auto& e : ev)
       (void)hipEventDestroy(e);
   }
@@ -301,6 +317,7 @@ void bind_state(fmd_batch* b)
   void* dhs = nullptr;
   if (b->h_status && hipHostGetDevicePointer(&dhs, b->h_status, 0) == hipSuccess)
     b->st.hs = static_cast<unsigned*>(dhs);
+  b->st.ds = b->d_status.p;
   // bound of the serial stage's LDS hand-off waits (~0.1 s; fmd_batch_debug_set_spin_limit)
   b->st.spin_limit = b->spin_limit;
 }
@@ -446,6 +463,10 @@ int do_reset(fmd_batch* b)
   b->fail_msg.clear();
   // the getters' snapshot follows: the meters Reset clears (FmDecode.cpp:326-338) read zero, pilot
   // level and the receiver's audio meter stay
+  if (b->d_status.p)
+    for (int w : {fmd::HS_IF_LEVEL, fmd::HS_BB_MEAN, fmd::HS_BB_LEVEL, fmd::HS_STEREO, fmd::HS_R_STATE})
+      if (hipMemset(b->d_status.p + size_t(w) * CP, 0, CP * sizeof(unsigned)) != hipSuccess)
+        return -1;
   if (b->h_status)
     host_status_update(b, [](unsigned* h, size_t CP) {
       for (int w : {fmd::HS_IF_LEVEL, fmd::HS_BB_MEAN, fmd::HS_BB_LEVEL, fmd::HS_STEREO, fmd::HS_R_STATE})
@@ -499,6 +520,33 @@ int pick_independent_streams(int n, const int* priority, hipStream_t* out)
   for (hipStream_t s : rejected)
     (void)hipStreamDestroy(s);
   return have == n ? 0 : -1;
+}
+
+/* k_resample_ring's geometry for one of its forms (outputs per wave x waves): does a step's window
+ * (+ alignment, + the even-count batch) fit 39 ring batches of 4 KB, and a step's new rows the
+ * registers that carry them?  Leaves rsr_R = 0 when not. */
+bool rsr_configure(fmd_batch* b, int form)
+{
+  // 2 x 8 first: two waves per SIMD cover each other's waits (0.30 ms alone at 8192 channels against 0.36
+  // for 4 x 4; 2 x 4, half the outputs per step, is what longer windows still fit: 0.87 ms)
+  static const int forms[3][2] = {{2, 8}, {4, 4}, {2, 4}};
+  const fmd::Design& d = b->des;
+  const int R = forms[form][0], NW = forms[form][1];
+  const double step = double(d.rs_step);
+  const unsigned per_step = unsigned(NW * R);
+  const unsigned span = d.rs_order + 1u + unsigned(std::ceil((per_step - 1) * step)) + 1u;
+  const unsigned nbr = (span - 1u + 7u) / 8u + 2u;
+  const unsigned new_rows = unsigned(std::ceil(per_step * step)) + 8u;
+  b->rsr_R = 0;
+  if (nbr > 39u || new_rows > unsigned(fmd::RSR_ROWS))
+    return false;
+  b->rsr_R = R;
+  b->rsr_NW = NW;
+  b->rsr_nbr = nbr;
+  b->rsr_rb = int((d.rs_order + 7u) / 8u * 8u + 8u);
+  const unsigned gspan = d.rs_order + 1u + unsigned(std::ceil((R - 1) * step)) + 1u;
+  b->rsr_nbm = (gspan - 1u + 7u) / 8u + 2u + 1u; // + 1: the walk's dummy last load
+  return true;
 }
 
 } // namespace
@@ -643,9 +691,11 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->demod[1].alloc(size_t(b->Mstride) * C + fmd::DS);
   bad |= b->if_coeff.alloc(d.if_coeff.size() + 64); // zero padding: fir_long_e1_asm's dummy load
   bad |= b->rs_coeff.alloc(d.rs_coeff.size());
-  // RS_B rows of zeros in front: the resampler's last batch may reach that far below its window
-  bad |= b->br[0].alloc(size_t(2 * fmd::RS_B + d.rs_order + b->Mmax) * CP);
-  bad |= b->br[1].alloc(size_t(2 * fmd::RS_B + d.rs_order + b->Mmax) * CP);
+  // rows of zeros in front: the resamplers' last batch reaches below the window (k_resample: RS_B rows,
+  // k_resample_ring: down to the batch border below, + one batch); 8 rows behind: its top batch
+  static_assert(fmd_batch::kBrFront >= 2 * fmd::RS_B, "front rows of br");
+  bad |= b->br[0].alloc(size_t(fmd_batch::kBrFront + d.rs_order + b->Mmax + 8) * CP);
+  bad |= b->br[1].alloc(size_t(fmd_batch::kBrFront + d.rs_order + b->Mmax + 8) * CP);
   if (d.hb.empty())
     return fail(FMD_ERR_ARG, "baseband rate too low for the RDS decimation chain");
   bad |= b->mix[0].alloc(size_t(d.hb[0].len - 1 + b->Mmax) * CP);
@@ -669,6 +719,34 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   b->rs_row = d.rs_order + 1 + 2 * b->rs_margin;
   bad |= b->ktab.alloc(size_t(b->Amax) * b->rs_row + 64);
   bad |= b->pidx.alloc(b->Amax);
+  { // k_resample_ring
+    hipDeviceProp_t prop{};
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+      b->n_cus = prop.multiProcessorCount;
+    size_t tab_floats = 0, head_ints = 0, step_ints = 0;
+    for (int form = 0; form < 3; form++)
+      if (rsr_configure(b.get(), form))
+      {
+        const size_t per_step = size_t(b->rsr_NW) * b->rsr_R;
+        const size_t nsteps = (size_t(b->Amax) + per_step - 1) / per_step;
+        tab_floats = std::max(tab_floats, nsteps * b->rsr_NW * b->rsr_nbm * 8 * b->rsr_R + 256);
+        head_ints = std::max(head_ints, nsteps * b->rsr_NW * fmd::RSR_HEAD);
+        step_ints = std::max(step_ints, nsteps * 2);
+      }
+    for (int form = 0; form < 3 && !rsr_configure(b.get(), form); form++) // the first form that fits stays
+      ;
+    if (tab_floats)
+    {
+      bad |= b->rsr_tab.alloc(tab_floats);
+      bad |= b->rsr_head.alloc(head_ints);
+      bad |= b->rsr_steps.alloc(step_ints);
+      const void* fns[] = {reinterpret_cast<const void*>(&fmd::k_resample_ring<4, 4>),
+                           reinterpret_cast<const void*>(&fmd::k_resample_ring<2, 8>),
+                           reinterpret_cast<const void*>(&fmd::k_resample_ring<2, 4>)};
+      for (const void* f : fns)
+        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    }
+  }
   if (getenv("FMD_SERIAL_PROBE") && atoi(getenv("FMD_SERIAL_PROBE")))
     bad |= b->serial_probe.alloc(size_t(8) * 3 * (b->CP / 64)); // the last 8 launches
   bad |= b->sctab.alloc(d.sincos_tab.size());
@@ -713,6 +791,8 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
                     hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
     return fail(FMD_ERR_DEVICE, "host-mapped status snapshot allocation failed");
   std::fill_n(b->h_status, size_t(fmd::HS_WORDS) * CP, 0u); // a fresh decoder: all meters zero
+  if (b->d_status.alloc(size_t(fmd::HS_WORDS) * CP))
+    return fail(FMD_ERR_DEVICE, "status record allocation failed");
   bind_state(b.get());
   if (!b->st.err || !b->st.hs)
     return fail(FMD_ERR_DEVICE, "host-mapped memory has no device address");
@@ -1008,7 +1088,7 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     k.bs_a2 = d.bitsync.a2;
     k.mf_taps = int(T_mf);
     const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
-    hipLaunchKernelGGL(fmd::k_rds_pll, dim3(CP / 64), dim3(64), 0, s, b->rlpf[j.q].p, j.R, C, CP, k, b->st,
+    hipLaunchKernelGGL(fmd::k_rds_pll, dim3((CP / 64 + fmd::RP_WAVES - 1) / fmd::RP_WAVES), dim3(64, fmd::RP_WAVES), 0, s, b->rlpf[j.q].p, j.R, C, CP, k, b->st,
                        b->rpll.p, T_mf - 1, b->sctab.p, sct);
     if (T_mf >= unsigned(fmd::RG))
       hipLaunchKernelGGL(fmd::k_ring_fir4<float>, dim3(CP / 64, (j.R + 4 * fmd::RG - 1) / (4 * fmd::RG)),
@@ -1045,6 +1125,7 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     else
       hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, s, b->alp[j.q].p, j.A, C, CP, k,
                          b->st, j.d_audio, j.audio_stride, unsigned(j.sq), j.call_index);
+    hipLaunchKernelGGL(fmd::k_status_publish, dim3((C + 255) / 256), dim3(256), 0, s, b->st, C, j.call_index);
   }
   if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_AUD], s) != hipSuccess)
     mark_failed(b, "hipEventRecord failed behind the audio tail of a call");
@@ -1417,7 +1498,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       k.bs_a2 = d.bitsync.a2;
       k.mf_taps = int(T_mf);
       const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
-      hipLaunchKernelGGL(fmd::k_rds_pll, dim3(CP / 64), dim3(64), 0, sR, b->rlpf[q].p, R, C, CP, k,
+      hipLaunchKernelGGL(fmd::k_rds_pll, dim3((CP / 64 + fmd::RP_WAVES - 1) / fmd::RP_WAVES), dim3(64, fmd::RP_WAVES), 0, sR, b->rlpf[q].p, R, C, CP, k,
                          b->st, b->rpll.p, T_mf - 1, b->sctab.p, sct);
       if (T_mf >= unsigned(fmd::RG))
         hipLaunchKernelGGL(fmd::k_ring_fir4<float>, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)),
@@ -1439,11 +1520,45 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     after(sA, ce[fmd_batch::EV_SER]);
     if (heavy_par)
       post_delay(sA);
-    hipLaunchKernelGGL(fmd::k_rs_table, dim3(A), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p,
-                       pstep, A, b->ktab.p, b->rs_row, b->rs_margin, b->pidx.p);
-    hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
-                       dim3(64, 4), 0, sA, b->brp(q), Hbb, d.rs_order, b->ktab.p, b->rs_row,
-                       b->rs_margin, b->pidx.p, A, b->rs.p, T_alp - 1, C, CP);
+    /* Large batches stream the rows through an LDS ring (k_resample_ring: every row crosses the fabric
+     * once per segment instead of ~6 times); small ones, short calls and geometries whose window does
+     * not fit a CU's LDS keep the window-per-wave form, which has more workgroups to offer. */
+    const unsigned per_step = unsigned(std::max(b->rsr_NW * b->rsr_R, 1));
+    const unsigned rs_steps = (A + per_step - 1) / per_step;
+    const bool ring = b->rsr_R != 0 && b->rsr_mode != 0 &&
+                      (b->rsr_mode == 1 || (CP / 64 >= 64 && rs_steps >= 24 && per_step >= 16));
+    if (ring)
+    {
+      // segments: about two workgroups for every CU the serial stage leaves free, >= 8 steps each
+      const unsigned groups = CP / 64;
+      const unsigned ncu = unsigned(b->n_cus) - ((b->serial_exclusive && !serial_mode) ? (groups + 1) / 2 : 0u);
+      unsigned S = std::max(1u, std::min(8u, (2u * ncu + groups / 2u) / groups));
+      S = std::max(1u, std::min(S, rs_steps / 8u));
+      const unsigned per_seg = (rs_steps + S - 1) / S;
+      S = (rs_steps + per_seg - 1) / per_seg;
+      const unsigned lds = b->rsr_nbr * 4096u;
+      auto go = [&](auto plan, auto kern) {
+        hipLaunchKernelGGL(plan, dim3(rs_steps * b->rsr_NW), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p, pstep,
+                           A, b->rsr_rb, b->rsr_nbr, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p);
+        hipLaunchKernelGGL(kern, dim3(groups, S), dim3(64, b->rsr_NW + 1), lds, sA, b->brp(q), Hbb, b->rsr_rb,
+                           d.rs_order, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p, rs_steps, per_seg,
+                           b->rsr_nbr, A, b->rs.p, T_alp - 1, C, CP, b->rsr_exp, b->rsr_pace);
+      };
+      if (b->rsr_R == 4)
+        go(&fmd::k_rs_plan<4, 4>, &fmd::k_resample_ring<4, 4>);
+      else if (b->rsr_NW == 8)
+        go(&fmd::k_rs_plan<2, 8>, &fmd::k_resample_ring<2, 8>);
+      else
+        go(&fmd::k_rs_plan<2, 4>, &fmd::k_resample_ring<2, 4>);
+    }
+    else
+    {
+      hipLaunchKernelGGL(fmd::k_rs_table, dim3(A), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p,
+                         pstep, A, b->ktab.p, b->rs_row, b->rs_margin, b->pidx.p);
+      hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
+                         dim3(64, 4), 0, sA, b->brp(q), Hbb, d.rs_order, b->ktab.p, b->rs_row,
+                         b->rs_margin, b->pidx.p, A, b->rs.p, T_alp - 1, C, CP);
+    }
     roll_later(b->brp(q), b->brp(q ^ 1), Hbb, M); // with the low-pass's own roll, at the chain's end
     mark(6);
     static const int ring4a = getenv("FMD_RING4") ? atoi(getenv("FMD_RING4")) : 1;
@@ -1479,9 +1594,10 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     mark(5);
     audio_heavy();
     audio_light();
-    signal(ce[fmd_batch::EV_AUD], sA);
     mark(8);
-    after(sA, ce[fmd_batch::EV_RDS]);
+    after(sA, ce[fmd_batch::EV_RDS]); // the record's RDS state is the other chain's
+    hipLaunchKernelGGL(fmd::k_status_publish, dim3((C + 255) / 256), dim3(256), 0, sA, b->st, C, ci);
+    signal(ce[fmd_batch::EV_AUD], sA);
     signal(ce[fmd_batch::EV_HEAVY], sA);
   }
   else
@@ -1621,6 +1737,58 @@ int fmd_batch_debug_set_spin_limit(fmd_batch* b, unsigned limit)
     return fail(FMD_ERR_ARG, "null batch");
   b->spin_limit = limit;
   b->st.spin_limit = limit;
+  return FMD_OK;
+}
+
+int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
+{
+  if (!b || !key)
+    return fail(FMD_ERR_ARG, "null argument");
+  const std::string k(key);
+  if (k == "resampler")
+  {
+    if (value > 0 && b->rsr_R == 0)
+      return fail(FMD_ERR_ARG, "fmd_batch_debug_set: no form of k_resample_ring fits this geometry");
+    b->rsr_mode = value < 0 ? -1 : (value ? 1 : 0);
+  }
+  else if (k == "rsr_form") // 0: 2 outputs x 8 waves, 1: 4 x 4, 2: 2 x 4 (falls through to the next that fits)
+  {
+    bool ok = false;
+    for (int f = std::max(0, std::min(2, value)); f < 3 && !ok; f++)
+      ok = rsr_configure(b, f);
+  }
+  else if (k == "cu_partition")
+  { /* Experiment: the serial stage and the light chain on `value` CUs of their own (CU-mask bit i is a
+     * CU of XCC i % 8: the first `value` bits are value / 8 CUs of every XCC), IF FIR and the heavy
+     * chain on all the others -- nothing of the light chain then holds LDS where the ring resampler's
+     * whole-CU workgroups go.  Replaces the four internal streams; only while no call is in flight. */
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (value <= 0 || value >= b->n_cus || value % 8)
+      return fail(FMD_ERR_ARG, "cu_partition: a multiple of 8 below the CU count");
+    const int words = (b->n_cus + 31) / 32;
+    std::vector<uint32_t> ma(size_t(words), 0u), mb(size_t(words), 0u);
+    for (int i = 0; i < b->n_cus; i++)
+      (i < value ? ma : mb)[size_t(i / 32)] |= 1u << (i % 32);
+    hipStream_t ns[4] = {nullptr, nullptr, nullptr, nullptr};
+    const uint32_t* masks[4] = {mb.data(), ma.data(), mb.data(), ma.data()}; // fir, serial, heavy, light
+    for (int i = 0; i < 4; i++)
+      HIPCHK(hipExtStreamCreateWithCUMask(&ns[i], uint32_t(words), masks[i]));
+    (void)hipStreamDestroy(b->s_fir);
+    (void)hipStreamDestroy(b->s_ser);
+    (void)hipStreamDestroy(b->s_post);
+    (void)hipStreamDestroy(b->s_rds);
+    b->s_fir = ns[0];
+    b->s_ser = ns[1];
+    b->s_post = ns[2];
+    b->s_rds = ns[3];
+  }
+  else if (k == "rsr_pace") // k_resample_ring's tap warmer: 64-cycle sleeps per batch
+    b->rsr_pace = unsigned(std::max(0, value));
+  else if (k == "rsr_exp") // timing experiments of k_resample_ring (results are wrong with them)
+    b->rsr_exp = unsigned(value);
+  else
+    return fail(FMD_ERR_ARG, "fmd_batch_debug_set: unknown key '" + k + "'");
   return FMD_OK;
 }
 

@@ -82,10 +82,11 @@ enum DevErr : unsigned
   DEVERR_RDS_QUEUE_FULL = 1u    // err[1], k_rds_bits / k_rds_export: a group did not fit (lost)
 };
 /* Status snapshot of every channel in host-mapped memory, [HS_WORDS][CP] 32-bit words: what the
- * cFmDecoder getters (FmDecode.h:140-165) and cRadioReceiver's audio meter return, written by the
- * last kernel of a call (k_audio_tail) so that the host reads them without touching the device.
- * HS_SEQ_BEGIN is written first and HS_SEQ_END last (both = the call's index); a reader takes END,
- * the fields, then BEGIN, and has a consistent record when the two are equal. */
+ * cFmDecoder getters (FmDecode.h:140-165) and cRadioReceiver's audio meter return.  The kernels of a
+ * call leave the record in device memory (ChannelState::ds: k_audio_tail, k_rds_bits); the last
+ * kernel of the call (k_status_publish) copies it out so that the host reads it without touching the
+ * device.  HS_SEQ_BEGIN is written first and HS_SEQ_END last (both = the call's index); a reader
+ * takes END, the fields, then BEGIN, and has a consistent record when the two are equal. */
 enum HostStatusWord
 {
   HS_SEQ_BEGIN, HS_IF_LEVEL, HS_BB_MEAN, HS_BB_LEVEL, HS_P_LEVEL, HS_STEREO, HS_R_STATE,
@@ -97,7 +98,8 @@ struct ChannelState
   int* i;           // [I_SLOTS][CP]
   uint16_t* r_data; // [4][CP]   block words of the group being assembled
   unsigned* err;    // the batch's two error words (DevErr)
-  unsigned* hs;     // [HS_WORDS][CP] status snapshot in host-mapped memory
+  unsigned* hs;     // [HS_WORDS][CP] status snapshot in host-mapped memory (written by k_status_publish)
+  unsigned* ds;     // [HS_WORDS][CP] the same record in device memory: what the kernels write
   unsigned spin_limit; // bound of the LDS hand-off waits (0 = every wait times out: test knob)
   unsigned CP;
   __host__ __device__ float* F(int slot) const { return f + (size_t)slot * CP; }
@@ -2461,18 +2463,21 @@ __device__ __forceinline__ uint32_t rds_check_block(uint32_t& in_bits, uint32_t 
 }
 
 /* K5a: ProcessRdsPll (RDSProcess.cpp:222-270), one lane per channel.  Output = de-rotated
- *      imaginary part, written behind the T_mf-1 history rows the matched filter needs. */
-__global__ __launch_bounds__(64) void k_rds_pll(const float2* __restrict__ lpf, unsigned R, unsigned C,
+ *      imaginary part, written behind the T_mf-1 history rows the matched filter needs.
+ *      Four waves (one per SIMD) share the 16 KB sine / cosine table of a workgroup: a quarter as many
+ *      CUs carry one during the 0.2-0.5 ms the kernel runs, which matters to the whole-CU resampler. */
+constexpr int RP_WAVES = 4;
+__global__ __launch_bounds__(64 * RP_WAVES) void k_rds_pll(const float2* __restrict__ lpf, unsigned R, unsigned C,
                                                 unsigned CP, RdsConsts k, ChannelState st,
                                                 float* __restrict__ rpll, unsigned Hout,
                                                 const double* __restrict__ sctab_g, FmdSincosTab sct)
 {
   __shared__ double sctab[2 * FMD_SINCOS_TAB_SIZE];
   __builtin_amdgcn_s_setprio(3);
-  for (unsigned i = threadIdx.x; i < 2 * FMD_SINCOS_TAB_SIZE; i += 64)
+  for (unsigned i = threadIdx.y * 64 + threadIdx.x; i < 2 * FMD_SINCOS_TAB_SIZE; i += 64 * RP_WAVES)
     sctab[i] = sctab_g[i];
   __syncthreads();
-  const unsigned c = blockIdx.x * 64 + threadIdx.x;
+  const unsigned c = (blockIdx.x * RP_WAVES + threadIdx.y) * 64 + threadIdx.x;
   if (c >= C)
     return;
   float phase = st.F(F_R_PHASE)[c], freq = st.F(F_R_FREQ)[c];
@@ -2713,7 +2718,7 @@ __global__ __launch_bounds__(64) void k_rds_bits(const float* __restrict__ mf, u
   // the status snapshot's RDS state (not a cFmDecoder getter) is this kernel's to write: a word of its
   // own, outside the audio tail's sequence-locked record, so that the tail need not wait for the RDS
   // chain where the two run on different streams
-  reinterpret_cast<volatile unsigned*>(st.hs)[(size_t)HS_R_STATE * st.CP + c] = (unsigned)state;
+  st.ds[(size_t)HS_R_STATE * st.CP + c] = (unsigned)state;
   st.I(I_R_BOFF)[c] = boff;
   st.I(I_R_ERRORS)[c] = errors;
 #pragma unroll
@@ -2889,19 +2894,358 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br,
  * slower at 32768 (waves idle at the barriers outside their own window). */
 
 /* ------------------------------------------------------------------------------------------ */
+/* K6'/K7': the same two resamplers as ONE STREAM over an LDS ring (large batches).             */
+/*                                                                                              */
+/* k_resample above lets every wave fetch its own 240-row window through L1 / L2: at 8192       */
+/* channels the ~1100 workgroups in flight span 76 MB of rows, the L2s hold 32 MB, and every    */
+/* row crosses the fabric 5.8 times.  Here a workgroup owns 64 channels and a third (1 / S) of   */
+/* the call's outputs and walks them in time order: the rows it needs live in a ring in LDS      */
+/* (NBR batches of 8 rows x 512 B, up to 160 KB -- the whole CU), every row is fetched from      */
+/* memory ONCE per segment (1 + 219 / (4.55 * outputs per segment) = 1.11 at S = 3).  A step =   */
+/* NW * R outputs: wave w adds up outputs R (s NW + w) .. + R - 1 over the union of their        */
+/* windows (rs_walk_asm: taps scalar, R outputs share every row read), the rows of the next      */
+/* step are fetched into registers meanwhile and go into the ring between two barriers.          */
+/* Absolute row rr = call row + RB (RB a multiple of 8 >= the history rows + 8, so that batch    */
+/* borders do not move with the call); batch = rr / 8 lives in ring slot batch % NBR, as row     */
+/* pairs: [pair][lane][2] float2, so that ds_read_b128 gives a lane two adjacent rows.           */
+/* Zero taps meet rows outside an output's own window: exact for finite samples only, so the     */
+/* loader looks at every value it brings in and a workgroup that has seen an infinity or a NaN   */
+/* takes the literal loop (per-row tests) for the rest of its segment.                           */
+/* ------------------------------------------------------------------------------------------ */
+constexpr int RSR_ROWS = 96;    // rows a workgroup can hold in registers for the next step
+constexpr int RSR_HEAD = 4 + 4; // ints per group header: top batch, batches, ring offset, -, pidx[R]
+
+template <int R>
+__device__ __forceinline__ void rs_walk_asm(fmd_f2v (&acc)[R], unsigned& off, unsigned& cnt, unsigned lane16,
+                                            unsigned wrap, unsigned klo, unsigned khi, unsigned kinc);
+template <>
+__device__ __forceinline__ void rs_walk_asm<4>(fmd_f2v (&acc)[4], unsigned& off, unsigned& cnt, unsigned lane16,
+                                               unsigned wrap, unsigned klo, unsigned khi, unsigned kinc)
+{
+#include "fmd_rs_walk_r4.inc"
+}
+template <>
+__device__ __forceinline__ void rs_walk_asm<2>(fmd_f2v (&acc)[2], unsigned& off, unsigned& cnt, unsigned lane16,
+                                               unsigned wrap, unsigned klo, unsigned khi, unsigned kinc)
+{
+#include "fmd_rs_walk_r2.inc"
+}
+
+template <int R, int NW>
+__device__ __forceinline__ void rs_warm_asm(unsigned tlo, unsigned thi, unsigned gstride, unsigned rounds,
+                                            unsigned pace);
+template <>
+__device__ __forceinline__ void rs_warm_asm<4, 4>(unsigned tlo, unsigned thi, unsigned gstride, unsigned rounds,
+                                                  unsigned pace)
+{
+#include "fmd_rs_warm_r4w4.inc"
+}
+template <>
+__device__ __forceinline__ void rs_warm_asm<2, 8>(unsigned tlo, unsigned thi, unsigned gstride, unsigned rounds,
+                                                  unsigned pace)
+{
+#include "fmd_rs_warm_r2w8.inc"
+}
+template <>
+__device__ __forceinline__ void rs_warm_asm<2, 4>(unsigned tlo, unsigned thi, unsigned gstride, unsigned rounds,
+                                                  unsigned pace)
+{
+#include "fmd_rs_warm_r2w4.inc"
+}
+
+/* The call's plan, one block per group of R outputs (positions are batch-uniform): header, the
+ * group's taps by (batch, row, output) with zeros outside each output's window, and per step the
+ * batches its NW groups touch.  pf / pi / k0 / k1 as in k_rs_table (DownConvert.cpp:205-212). */
+template <int R, int RSR_NW>
+__global__ __launch_bounds__(64) void k_rs_plan(const float* __restrict__ coeff, unsigned order, float p,
+                                                float pstep, unsigned A, int RB, unsigned NBR,
+                                                float* __restrict__ tab, unsigned nbm,
+                                                int* __restrict__ head, int* __restrict__ steptab)
+{
+  const unsigned g = blockIdx.x;
+  auto pidx_of = [&](unsigned i) { return (int)(p + (float)i * pstep); };
+  auto extent = [&](unsigned gg, int& top, int& nb) { // batches of group gg, top one first, an even count
+    const unsigned i0 = gg * R;
+    if (i0 >= A)
+    {
+      top = 0;
+      nb = 0;
+      return;
+    }
+    const unsigned il = min(i0 + R - 1, A - 1);
+    top = (pidx_of(il) + RB) >> 3;
+    const int bot = (pidx_of(i0) - (int)order + RB) >> 3;
+    nb = top - bot + 1;
+    nb += nb & 1;
+  };
+  int top, nb;
+  extent(g, top, nb);
+  float k0[R], k1[R];
+  int pi[R];
+#pragma unroll
+  for (int r = 0; r < R; r++)
+  {
+    const unsigned i = min(g * R + r, A - 1);
+    const float pf = p + (float)i * pstep;
+    pi[r] = (int)pf;
+    k1[r] = pf - (float)pi[r];
+    k0[r] = 1 - k1[r];
+  }
+  for (int idx = threadIdx.x; idx < nb * 8 * R; idx += 64)
+  {
+    const int b = idx / (8 * R), q = (idx / R) & 7, r = idx % R;
+    const int row = (top - b) * 8 + 7 - q - RB; // call row
+    float v = 0.0f;
+#pragma unroll
+    for (int rr = 0; rr < R; rr++)
+      if (rr == r)
+      {
+        const int j = pi[rr] - row;
+        if (j >= 0 && j <= (int)order)
+          v = coeff[j] * k0[rr] + coeff[j + 1] * k1[rr];
+      }
+    tab[((size_t)g * nbm + b) * (8 * R) + (idx % (8 * R))] = v;
+  }
+  if (threadIdx.x == 0)
+  {
+    int* h = head + (size_t)g * RSR_HEAD;
+    h[0] = top;
+    h[1] = nb;
+    h[2] = (int)(((unsigned)top % NBR) * 4096u);
+    h[3] = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      h[4 + r] = pi[r];
+    if (g % RSR_NW == 0)
+    { // the step's batches: [bot, top] over its NW groups (the last non-empty group has the top)
+      int stop = 0, sbot = 0x7fffffff;
+      for (unsigned w = 0; w < (unsigned)RSR_NW; w++)
+      {
+        int t, n;
+        extent(g + w, t, n);
+        if (n > 0)
+        {
+          stop = t;
+          sbot = min(sbot, t - n + 1);
+        }
+      }
+      steptab[2 * (g / RSR_NW)] = stop;
+      steptab[2 * (g / RSR_NW) + 1] = sbot;
+    }
+  }
+}
+
+template <int R, int RSR_NW>
+__global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
+    const float2* __restrict__ br, unsigned Hbb, int RB, unsigned order, const float* __restrict__ tab,
+    unsigned nbm, const int* __restrict__ head, const int* __restrict__ steptab, unsigned nsteps,
+    unsigned steps_per_seg, unsigned NBR, unsigned A, float2* __restrict__ out, unsigned Hout, unsigned C,
+    unsigned CP, unsigned exp, unsigned pace)
+{
+  constexpr int RSR_PRE = RSR_ROWS / RSR_NW; // rows a wave can hold for the next step
+  constexpr int LEAD = 3;                    // batches the tap warmer runs ahead of the walk
+  extern __shared__ __align__(16) unsigned char rsr_smem[]; // the ring: [NBR][4 pairs][64 lanes][2 rows] float2
+  __shared__ unsigned nonfinite_s;
+  const unsigned lane = threadIdx.x;
+  const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
+  const unsigned c = blockIdx.x * 64 + lane;
+  const unsigned s0 = blockIdx.y * steps_per_seg;
+  if (s0 >= nsteps)
+    return;
+  const unsigned s1 = min(s0 + steps_per_seg, nsteps);
+  const unsigned ring_pairs = NBR * 4;
+  // absolute row rr in memory: wave-uniform row pointer + 32-bit lane offset; and in the ring
+  const char* const gbase = reinterpret_cast<const char*>(br + ((ptrdiff_t)Hbb - (ptrdiff_t)RB) * (ptrdiff_t)CP);
+  const unsigned lane_off = c * (unsigned)sizeof(float2);
+  const size_t row_bytes = (size_t)CP * sizeof(float2);
+  // a value is finite iff its exponent field is not all ones: the largest magnitude word seen decides
+  unsigned emax = 0u;
+  auto look = [&](float2 v) {
+    emax = max(emax, max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu));
+  };
+  auto ring_addr = [&](unsigned pair_slot, unsigned odd) {
+    return reinterpret_cast<float2*>(rsr_smem + (size_t)pair_slot * 1024 + lane * 16 + odd * 8);
+  };
+  const bool live = c < C; // padding lanes hold whatever: they must not trip the non-finite flag
+  // this wave's share of the rows r0, r0 + 1, ... r0 + n_rows - 1 (r0 a multiple of 8): rows r0 + w + NW n,
+  // fetched into registers with all loads in flight, and put into the ring later
+  float2 pre[RSR_PRE];
+  auto fetch = [&](int r0, int mine) {
+    const char* rp = gbase + (size_t)(r0 + (int)w) * row_bytes;
+#pragma unroll
+    for (int n = 0; n < RSR_PRE; n++)
+      if (n < mine)
+      { // read once: must not push the tap table out of the L2
+        if (exp & 32u)
+          pre[n] = *reinterpret_cast<const float2*>(rp + lane_off);
+        else
+        {
+          const fmd_f2v v = __builtin_nontemporal_load(reinterpret_cast<const fmd_f2v*>(rp + lane_off));
+          pre[n] = make_float2(v.x, v.y);
+        }
+        rp += RSR_NW * row_bytes;
+      }
+  };
+  auto stash = [&](int r0, int mine) {
+    unsigned ps = ((unsigned)(r0 + (int)w) >> 1) % ring_pairs; // pairs 2 apart, the row's parity is w's
+#pragma unroll
+    for (int n = 0; n < RSR_PRE; n++)
+      if (n < mine)
+      {
+        look(pre[n]);
+        *ring_addr(ps, w & 1u) = pre[n];
+        ps += RSR_NW / 2;
+        ps = ps >= ring_pairs ? ps - ring_pairs : ps;
+      }
+    if (emax >= 0x7f800000u && live)
+      nonfinite_s = 1u;
+  };
+  auto share = [&](int n_rows) { return (n_rows - (int)w + RSR_NW - 1) / RSR_NW; };
+  /* Wave NW computes nothing: it keeps the taps the other waves are about to load in the CU's scalar
+   * cache.  Their scalar loads run one batch ahead of the arithmetic (all a wave can afford: every wait
+   * is lgkmcnt(0), which also waits for whatever else it has in flight), a table line is used once, and
+   * a miss takes about two batches.  The warmer touches the lines LEAD batches ahead of where the walk
+   * should be, at the walk's pace (it and the walk start a step at the same barrier). */
+  const bool warmer = w == (unsigned)RSR_NW;
+  auto warm = [&](unsigned step, int b0, int rounds) { // batches b0 .. b0 + rounds - 1 of every group of the step
+    if (rounds <= 0)
+      return;
+    const uint64_t ta = reinterpret_cast<uint64_t>(tab) + ((uint64_t)step * RSR_NW * nbm + (uint64_t)b0) * (32 * R);
+    rs_warm_asm<R, RSR_NW>((unsigned)ta, (unsigned)(ta >> 32), nbm * (32u * R), (unsigned)rounds, pace);
+  };
+  if (threadIdx.x == 0 && threadIdx.y == 0)
+    nonfinite_s = 0u;
+  __syncthreads();
+  int topb = steptab[2 * s0];
+  if (!(exp & 64u))
+  { /* The taps arrive by scalar loads one batch ahead; a load that misses the L2 (the plan kernel wrote the
+     * table on some other XCD) takes longer than that.  So the workgroups of an XCD (equal blockIdx.x % 8
+     * under round-robin placement: speed only) first read their segment's part of the table through
+     * the vector path, a sixteenth each, which leaves it in their L2. */
+    const size_t gsz = (size_t)nbm * (8 * R) * sizeof(float);
+    const char* t0 = reinterpret_cast<const char*>(tab) + (size_t)s0 * RSR_NW * gsz;
+    const size_t bytes = (size_t)(s1 - s0) * RSR_NW * gsz;
+    const unsigned nx = (gridDim.x + 7u) / 8u, part = blockIdx.x / 8u;
+    const size_t per = ((bytes + nx - 1) / nx + 15) & ~(size_t)15;
+    const size_t lo = min(bytes, part * per), hi = min(bytes, lo + per);
+    unsigned sink = 0;
+    for (size_t o = lo + (size_t)(threadIdx.y * 64 + lane) * 16; o + 16 <= hi; o += (size_t)(RSR_NW + 1) * 64 * 16)
+    {
+      const uint4 v = *reinterpret_cast<const uint4*>(t0 + o);
+      sink |= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (sink == 0x7fc12345u) // never (keeps the loads)
+      nonfinite_s = sink;
+  }
+  { // the first step's whole window
+    const int r_hi = topb * 8 + 7;
+    for (int r0 = steptab[2 * s0 + 1] * 8; r0 <= r_hi && !(exp & 16u); r0 += RSR_NW * RSR_PRE)
+    {
+      const int mine = warmer ? 0 : share(min(r_hi + 1 - r0, RSR_NW * RSR_PRE));
+      fetch(r0, mine);
+      stash(r0, mine);
+    }
+    if (warmer && !(exp & 128u))
+      warm(s0, 0, LEAD);
+  }
+  __syncthreads();
+  for (unsigned s = s0; s < s1; s++)
+  {
+    // rows of the next step: in flight during this step's arithmetic
+    const int ntop = s + 1 < s1 ? steptab[2 * (s + 1)] : topb;
+    const int r_new0 = topb * 8 + 8;
+    const int mine = (exp & 4u) || warmer ? 0 : share((ntop - topb) * 8);
+    fetch(r_new0, mine);
+    if (warmer)
+    {
+      if (!(exp & 128u))
+      {
+        warm(s, LEAD, (int)nbm - 1 - LEAD);
+        if (s + 1 < s1)
+          warm(s + 1, 0, LEAD);
+      }
+      lds_barrier();
+      topb = ntop;
+      lds_barrier();
+      continue;
+    }
+    const unsigned g = s * RSR_NW + w;
+    const int* __restrict__ h = head + (size_t)g * RSR_HEAD;
+    const int gtop = h[0], nb = h[1];
+    fmd_f2v acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      acc[r] = fmd_f2v{0.0f, 0.0f};
+    if (nb > 0 && !(exp & 8u))
+    {
+      const float* __restrict__ kp = tab + (size_t)g * nbm * (8 * R);
+      if (__builtin_expect(nonfinite_s == 0u, 1))
+      {
+        unsigned off = (unsigned)h[2], cnt = (unsigned)nb >> 1;
+        const uint64_t ka = reinterpret_cast<uint64_t>(kp);
+        // (the low half of a generic LDS pointer is the LDS byte address)
+        rs_walk_asm<R>(acc, off, cnt, (unsigned)(size_t)rsr_smem + lane * 16u, (NBR - 1u) * 4096u, (unsigned)ka,
+                       (unsigned)(ka >> 32), (exp & 1u) ? 0u : 32u * R);
+      }
+      else
+      { // literal: only the rows of an output's own window, j ascending
+        for (int b = 0; b < nb; b++)
+        {
+          const unsigned slot = (unsigned)(gtop - b) % NBR;
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+          {
+            const int rowb = 7 - q;
+            const float2 x = *ring_addr(slot * 4 + (unsigned)(rowb >> 1), (unsigned)rowb & 1u);
+            const int row = (gtop - b) * 8 + rowb - RB;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+            {
+              const int j = h[4 + r] - row;
+              if (j >= 0 && j <= (int)order)
+              {
+                const float k = kp[(size_t)b * (8 * R) + q * R + r];
+                acc[r].x += k * x.x;
+                acc[r].y += k * x.y;
+              }
+            }
+          }
+        }
+      }
+      if (live && !(exp & 2u))
+      {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          if (g * R + r < A) // (stereo, mono) = ProcessTwo's (A, B): x came from baseband -> mono
+            out[(size_t)(Hout + g * R + r) * CP + c] = make_float2(acc[r].y, acc[r].x);
+      }
+    }
+    lds_barrier(); // every wave is done with this step's rows
+    stash(r_new0, mine);
+    topb = ntop;
+    lds_barrier();
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* K8: audio tail, one lane per channel: ProcessDeemphasisFilter (FmDecode.cpp:348-359),        */
 /*     19 kHz notch cIirFilter::ProcessTwo (IirFilter.cpp:89-105), L/R matrix (:473-499).       */
 /* ------------------------------------------------------------------------------------------ */
-constexpr int AT_STEPS = 16; // audio frames buffered per lane before a coalesced store
+constexpr int AT_STEPS = 16; // rows in flight per lane (32: slower inside the pipeline, 0.83 against 0.65 ms)
 
+/* One lane per channel.  The channel-major output ([C][stride], what ProcessStream's caller gets) is
+ * written by every lane into its own channel's row, one frame (8 B) per store: the 16 stores that
+ * fill a 128-byte line follow each other within ~2000 cycles and meet in the L2.  (Until round 4 the
+ * frames went through an LDS tile for 64-byte segments per store; the tile's 8.7 KB kept the
+ * whole-CU resampler off every CU an audio tail was on, and the stores are not what bounds a
+ * lane-per-channel recurrence.)  The status record goes to device memory; k_status_publish takes it
+ * to the host. */
 __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp, unsigned A,
                                                    unsigned C, unsigned CP, AudioConsts k,
                                                    ChannelState st, float* __restrict__ audio,
                                                    size_t audio_stride, unsigned stereo_q,
                                                    unsigned call_index)
 {
-  // [channel lane][AT_STEPS frames + pad]: one row = 128 B of a channel's interleaved L/R output
-  __shared__ float2 tile[64][AT_STEPS + 1];
   __builtin_amdgcn_s_setprio(3);
   const unsigned lane = threadIdx.x;
   const unsigned c0 = blockIdx.x * 64 + lane;
@@ -2936,25 +3280,7 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
     vsumsq += o.y * o.y;
     return o;
   };
-  // 8 lanes write one channel's frames (8 B each) as consecutive pieces: 64-B segments
-  auto flush = [&](unsigned i0, unsigned cnt) {
-    lds_wave_sync(); // single wave: the LDS writes above are ordered before these reads
-#pragma unroll
-    for (unsigned q = 0; q < 8; q++)
-    {
-      const unsigned ch = q * 8 + (lane >> 3);
-      const unsigned cg = blockIdx.x * 64 + ch;
-      float2* __restrict__ o = reinterpret_cast<float2*>(audio + (size_t)cg * audio_stride) + i0;
-#pragma unroll
-      for (unsigned f0 = 0; f0 < AT_STEPS; f0 += 8)
-      {
-        const unsigned f = f0 + (lane & 7u);
-        if (f < cnt && cg < C)
-          o[f] = tile[ch][f];
-      }
-    }
-    lds_wave_sync();
-  };
+  float2* __restrict__ o = reinterpret_cast<float2*>(audio + (size_t)c * audio_stride);
 
   unsigned i0 = 0;
   // full tiles: the loads of the next tile are in flight while this one goes through the recurrence
@@ -2974,8 +3300,11 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
       vnext[u] = lp[(size_t)min(i0 + AT_STEPS + u, A - 1) * CP + c];
 #pragma unroll
     for (unsigned u = 0; u < AT_STEPS; u++)
-      tile[lane][u] = frame(vin[u]);
-    flush(i0, AT_STEPS);
+    {
+      const float2 f = frame(vin[u]);
+      if (active)
+        o[i0 + u] = f;
+    }
   }
   if (i0 < A)
   {
@@ -2983,8 +3312,11 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
 #pragma unroll
     for (unsigned u = 0; u < AT_STEPS; u++) // the ragged last tile is already in vnext
       if (u < cnt)
-        tile[lane][u] = frame(vnext[u]);
-    flush(i0, cnt);
+      {
+        const float2 f = frame(vnext[u]);
+        if (active)
+          o[i0 + u] = f;
+      }
   }
   if (active)
   {
@@ -3003,15 +3335,13 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
     st.F(F_AUDIO_MEAN)[c] = mean;
     st.F(F_AUDIO_RMS)[c] = rms;
     st.F(F_AUDIO_LEVEL)[c] = level;
-    /* The call is complete for this channel: its status goes to the host's snapshot (see
-     * HostStatusWord).  The level meters are the state arrays as they stand now; the stereo flag is
-     * this call's own copy.  With overlapped calls (concurrency 2) the next call's IF / baseband
-     * meters may already be in -- the reference's status thread reads its decoder mid-call too
-     * (RadioReceiver.cpp:544-572 against :524, no common lock). */
-    volatile unsigned* h = st.hs + c;
-    const unsigned CPs = st.CP;
-    h[HS_SEQ_BEGIN * CPs] = call_index;
-    __threadfence_system();
+    /* The call is complete for this channel: its status record (see HostStatusWord).  The level
+     * meters are the state arrays as they stand now; the stereo flag is this call's own copy.  With
+     * overlapped calls (concurrency 2) the next call's IF / baseband meters may already be in -- the
+     * reference's status thread reads its decoder mid-call too (RadioReceiver.cpp:544-572 against
+     * :524, no common lock). */
+    unsigned* __restrict__ h = st.ds + c;
+    const size_t CPs = st.CP;
     h[HS_IF_LEVEL * CPs] = __float_as_uint(st.F(F_IF_LEVEL)[c]);
     h[HS_BB_MEAN * CPs] = __float_as_uint(st.F(F_BB_MEAN)[c]);
     h[HS_BB_LEVEL * CPs] = __float_as_uint(st.F(F_BB_LEVEL)[c]);
@@ -3020,9 +3350,30 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
     h[HS_AUDIO_MEAN * CPs] = __float_as_uint(mean);
     h[HS_AUDIO_RMS * CPs] = __float_as_uint(rms);
     h[HS_AUDIO_LEVEL * CPs] = __float_as_uint(level);
-    __threadfence_system();
-    h[HS_SEQ_END * CPs] = call_index;
   }
+}
+
+/* The last kernel of a call: every channel's status record from device memory to the host's snapshot
+ * under the per-channel sequence lock (HostStatusWord), a thread per channel -- one kernel of a few
+ * waves pays the two system-scope fences, not the latency-bound audio tail. */
+__global__ __launch_bounds__(256) void k_status_publish(ChannelState st, unsigned C, unsigned call_index)
+{
+  const unsigned c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C)
+    return;
+  const size_t CPs = st.CP;
+  unsigned v[HS_WORDS];
+#pragma unroll
+  for (int w = HS_SEQ_BEGIN + 1; w < HS_SEQ_END; w++)
+    v[w] = st.ds[(size_t)w * CPs + c];
+  volatile unsigned* h = st.hs + c;
+  h[HS_SEQ_BEGIN * CPs] = call_index;
+  __threadfence_system();
+#pragma unroll
+  for (int w = HS_SEQ_BEGIN + 1; w < HS_SEQ_END; w++)
+    h[(size_t)w * CPs] = v[w];
+  __threadfence_system();
+  h[HS_SEQ_END * CPs] = call_index;
 }
 
 /* ------------------------------------------------------------------------------------------ */
