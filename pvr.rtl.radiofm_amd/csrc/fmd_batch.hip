@@ -130,6 +130,18 @@ struct fmd_batch
   DevBuf<int> rsr_head, rsr_steps;
   int rsr_mode = -1;
   int n_cus = 256;
+  // k_halfband_chain (large batches, the usual three-stage chains): step lists by (inputs, stretches),
+  // uploaded the first time a call size is seen; the stages' last outputs on their way to the history
+  // rows; -1 auto / 0 off / 1 on
+  struct HbfPlan
+  {
+    unsigned n_in = 0, S = 0;
+    DevBuf<fmd::HbStep> steps;
+    DevBuf<int> seg_first;
+  };
+  std::vector<std::unique_ptr<HbfPlan>> hbf_plans;
+  DevBuf<float2> hbf_tail1, hbf_tail2;
+  int hbf_mode = -1;
   DevBuf<long long> serial_probe; // FMD_SERIAL_PROBE=1: per-workgroup timing of the serial stage
   DevBuf<float> fstate; // all float state arrays, CP each
   DevBuf<int> istate;
@@ -246,6 +258,13 @@ struct fmd_batch
     audio_taps.release();
     ktab.release();
     rsr_tab.release();
+    for (auto& pl : hbf_plans)
+    {
+      pl->steps.release();
+      pl->seg_first.release();
+    }
+    hbf_tail1.release();
+    hbf_tail2.release();
     rsr_head.release();
     rsr_steps.release();
     rpll.release();
@@ -522,6 +541,63 @@ int pick_independent_streams(int n, const int* priority, hipStream_t* out)
   return have == n ? 0 : -1;
 }
 
+/* The steps of k_halfband_chain for a call of n_in inputs cut into S stretches of the last stage's
+ * outputs (see the kernel): per step how far each stage runs -- at most 16 / 8 / 4 outputs, no further
+ * than its input ring has rows for, and never onto a ring row the next stage still needs. */
+fmd_batch::HbfPlan* hbf_plan(fmd_batch* b, unsigned n_in, unsigned S)
+{
+  for (auto& pl : b->hbf_plans)
+    if (pl->n_in == n_in && pl->S == S)
+      return pl.get();
+  const fmd::Design& d = b->des;
+  const int L1H = d.hb[1].len - 1, L2H = d.hb[2].len - 1, RING = fmd::HBF_RING;
+  const int n0 = int(n_in + 1) / 2, n1 = (n0 + 1) / 2, n2 = (n1 + 1) / 2;
+  std::vector<fmd::HbStep> steps;
+  std::vector<int> first;
+  const int per = (n2 + int(S) - 1) / int(S);
+  for (int a = 0; a < n2; a += per)
+  {
+    first.push_back(int(steps.size()));
+    const int e = std::min(n2, a + per);
+    // what the stretch's outputs need of stages 1 and 0; the call's last stretch also computes the outputs
+    // behind that (they are part of the delay lines the next call starts from)
+    const bool last = e == n2;
+    const int need1 = last ? n1 : 2 * (e - 1) + 1, need0 = last ? n0 : 2 * (need1 - 1) + 1;
+    int d2 = a, d1 = std::max(0, 2 * a - L2H), d0 = std::max(0, 2 * d1 - L1H);
+    while (d2 < e || d1 < need1 || d0 < need0)
+    {
+      const int a_hi = std::max(d0, std::min({d0 + 16, need0, 2 * d1 - L1H + RING}));
+      const int b_hi = std::max(d1, std::min({d1 + 8, need1, a_hi > 0 ? (a_hi - 1) / 2 + 1 : 0, 2 * d2 - L2H + RING}));
+      const int c_hi = std::max(d2, std::min({d2 + 4, e, b_hi > 0 ? (b_hi - 1) / 2 + 1 : 0}));
+      if (a_hi == d0 && b_hi == d1 && c_hi == d2)
+        return nullptr; // cannot happen: a stage can always move
+      steps.push_back(fmd::HbStep{d0, a_hi - d0, d1, b_hi - d1, d2, c_hi - d2, 0, 0});
+      d0 = a_hi;
+      d1 = b_hi;
+      d2 = c_hi;
+    }
+    while ((steps.size() - size_t(first.back())) % 4) // the kernel takes a stretch's steps four at a time
+      steps.push_back(fmd::HbStep{d0, 0, d1, 0, d2, 0, 0, 0});
+  }
+  first.push_back(int(steps.size()));
+  std::unique_ptr<fmd_batch::HbfPlan> pl(new fmd_batch::HbfPlan);
+  pl->n_in = n_in;
+  pl->S = unsigned(first.size() - 1);
+  if (pl->steps.alloc(steps.size()) || pl->seg_first.alloc(first.size()) ||
+      upload(pl->steps.p, steps.data(), steps.size() * sizeof(fmd::HbStep)) ||
+      upload(pl->seg_first.p, first.data(), first.size() * sizeof(int)))
+    return nullptr;
+  if (b->hbf_plans.size() >= 16) // call sizes keep changing: forget the oldest list
+  {
+    (void)hipDeviceSynchronize();
+    b->hbf_plans.front()->steps.release();
+    b->hbf_plans.front()->seg_first.release();
+    b->hbf_plans.erase(b->hbf_plans.begin());
+  }
+  b->hbf_plans.push_back(std::move(pl));
+  return b->hbf_plans.back().get();
+}
+
 /* k_resample_ring's geometry for one of its forms (outputs per wave x waves): does a step's window
  * (+ alignment, + the even-count batch) fit 39 ring batches of 4 KB, and a step's new rows the
  * registers that carry them?  Leaves rsr_R = 0 when not. */
@@ -703,6 +779,11 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   b->hbbuf.resize(d.hb.size() - 1);
   for (size_t s = 1; s < d.hb.size(); s++)
     bad |= b->hbbuf[s - 1].alloc(size_t(d.hb[s].len - 1 + b->hb_nmax[s]) * CP);
+  if (d.hb.size() == 3)
+  {
+    bad |= b->hbf_tail1.alloc(size_t(d.hb[1].len - 1) * CP);
+    bad |= b->hbf_tail2.alloc(size_t(d.hb[2].len - 1) * CP);
+  }
   bad |= b->rdsraw.alloc(size_t(T_lpf - 1 + b->Rmax) * CP);
   bad |= b->rlpf[0].alloc(size_t(b->Rmax) * CP);
   bad |= b->rlpf[1].alloc(size_t(b->Rmax) * CP);
@@ -1415,6 +1496,40 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     /* ---- RDS branch  (stream R): half-bands, 75-tap LPF, PLL, matched filter, bits ---- */
     after(sR, ce[fmd_batch::EV_SER]);
     post_delay(sR);
+    /* Large batches in the usual geometries: the three stages as one stream, intermediate rows in LDS
+     * (k_halfband_chain).  Everything else -- short calls with a stage outside its normal regime, the
+     * 11-tap class, chains of another length, small batches -- keeps one launch per stage. */
+    bool chain_done = false;
+    if (hb_all_normal && d.hb.size() == 3 && b->hbf_mode != 0 && (b->hbf_mode == 1 || CP / 64 >= 64))
+    {
+      const int h0 = (d.hb[0].len - 1) / 2, h1 = (d.hb[1].len - 1) / 2, h2 = (d.hb[2].len - 1) / 2;
+      const unsigned groups = CP / 64;
+      const unsigned ncu = unsigned(b->n_cus) - ((b->serial_exclusive && !serial_mode) ? (groups + 1) / 2 : 0u);
+      const unsigned S = std::max(1u, std::min({8u, (2u * ncu + groups / 2u) / groups, R / 32u}));
+      fmd_batch::HbfPlan* pl = nullptr;
+      auto kern = &fmd::k_halfband_chain<7, 11, 21>;
+      bool known = true;
+      if (h0 == 7 && h1 == 11 && h2 == 21)
+        kern = &fmd::k_halfband_chain<7, 11, 21>;
+      else if (h0 == 7 && h1 == 9 && h2 == 17)
+        kern = &fmd::k_halfband_chain<7, 9, 17>;
+      else
+        known = false;
+      if (known)
+        pl = hbf_plan(b, hb_in[0], S);
+      if (pl)
+      {
+        const unsigned n0 = (hb_in[0] + 1) / 2, n1 = (n0 + 1) / 2;
+        hipLaunchKernelGGL(kern, dim3(groups, pl->S), dim3(64, 4), 0, sR, b->mix[q].p, b->hbbuf[0].p,
+                           b->hbbuf[1].p, b->rdsraw.p, T_lpf - 1, b->hbf_tail1.p, b->hbf_tail2.p, b->hbcoef[0],
+                           b->hbcoef[1], b->hbcoef[2], pl->steps.p, pl->seg_first.p, hb_in[0], n0, n1, C, CP);
+        roll_later(b->mix[q].p, b->mix[q ^ 1].p, unsigned(d.hb[0].len - 1), hb_in[0]);
+        roll_later(b->hbf_tail1.p, b->hbbuf[0].p, unsigned(d.hb[1].len - 1), 0u);
+        roll_later(b->hbf_tail2.p, b->hbbuf[1].p, unsigned(d.hb[2].len - 1), 0u);
+        chain_done = true;
+      }
+    }
+    if (!chain_done)
     {
       const float2* in = b->mix[q].p;
       for (size_t s = 0; s < d.hb.size(); s++)
@@ -1751,6 +1866,8 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
       return fail(FMD_ERR_ARG, "fmd_batch_debug_set: no form of k_resample_ring fits this geometry");
     b->rsr_mode = value < 0 ? -1 : (value ? 1 : 0);
   }
+  else if (k == "halfband_chain") // -1 the library decides, 0 a launch per stage, 1 k_halfband_chain wherever it applies
+    b->hbf_mode = value < 0 ? -1 : (value ? 1 : 0);
   else if (k == "rsr_form") // 0: 2 outputs x 8 waves, 1: 4 x 4, 2: 2 x 4 (falls through to the next that fits)
   {
     bool ok = false;

@@ -2263,6 +2263,178 @@ __global__ __launch_bounds__(256) void k_halfband4(const float2* __restrict__ in
   }
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* K3': the three half-band stages of the usual chains as ONE stream (large batches).            */
+/*                                                                                              */
+/* Three launches of k_halfband4 move the intermediate rows through memory twice (write, read:    */
+/* 0.7 GB per call at 8192 channels for 0.44 GB of input and output).  Here a workgroup owns 64  */
+/* channels and a stretch of the last stage's outputs and walks it in time order; the outputs of */
+/* stage 0 and stage 1 only ever exist in two LDS rings of 64 rows ([row][lane] float2).  A step  */
+/* = up to 16 / 8 / 4 outputs of stage 0 / 1 / 2, a group of 4 / 2 / 1 per wave (hb_rows: the     */
+/* same sums in the same order as hb_group), two barriers.  The steps of a stretch -- how far      */
+/* each stage may run given what its input ring holds and what its output ring can take -- are    */
+/* the same for every channel: the host lists them (HbStep).  A stretch that does not start at   */
+/* the call's first output computes the 22 + 2 * 42 stage-0 outputs (+ 42 of stage 1) in front of */
+/* it again; the call's first rows find the previous call's last outputs in the rings (loaded     */
+/* from the history rows of the stage buffers, which the per-stage kernels keep too: the two      */
+/* forms can follow each other), and the last outputs of stages 0 and 1 go to `tail1` / `tail2`, */
+/* from where the chain's roll moves them into those history rows.  Stage 0's rows are fetched    */
+/* a step ahead (15 rows per wave and step in registers).                                         */
+/* ------------------------------------------------------------------------------------------ */
+struct HbStep
+{
+  int a_lo, a_n, b_lo, b_n, c_lo, c_n; // outputs of stage 0 / 1 / 2 this step computes (first, count)
+  int pad0, pad1;
+};
+constexpr int HBF_RING = 64; // rows per ring (power of two): >= L - 1 + two steps' outputs of the stage before
+
+/* RR consecutive outputs of one stage from the rows `ld` delivers (row = index into the stage's input
+ * with its L - 1 history rows in front: output k takes rows 2k .. 2k + L - 1).  Order of the sum as in
+ * hb_group: tap 0 twice, the even taps ascending, the centre tap last (DownConvert.cpp:526-543). */
+template <int RR, int HALF, class LD>
+__device__ __forceinline__ void hb_rows(LD ld, const HbCoef& hc, float2 (&acc)[RR])
+{
+  static_assert(HALF >= RR, "half-band group");
+#pragma unroll
+  for (int u = 0; u < RR + HALF; u++) // even row u: output r takes it with tap e[u - r]
+  {
+    const float2 x = ld(2 * u);
+#pragma unroll
+    for (int r = 0; r < RR; r++)
+    {
+      const int j = u - r;
+      if (j == 0)
+      {
+        acc[r] = rf_mul(hc.e[0], x);
+        rf_acc(acc[r], hc.e[0], x);
+      }
+      else if (j > 0 && j <= HALF)
+        rf_acc(acc[r], hc.e[j], x);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RR; r++)
+    rf_acc(acc[r], hc.c[HALF], ld(2 * r + HALF));
+}
+
+template <int H0, int H1, int H2>
+__global__ __launch_bounds__(256) void k_halfband_chain(
+    const float2* __restrict__ mix, const float2* __restrict__ hist1, const float2* __restrict__ hist2,
+    float2* __restrict__ out, unsigned Hout, float2* __restrict__ tail1, float2* __restrict__ tail2,
+    HbCoef hc0, HbCoef hc1, HbCoef hc2, const HbStep* __restrict__ steps, const int* __restrict__ seg_first,
+    unsigned n_in, unsigned n0, unsigned n1, unsigned C, unsigned CP)
+{
+  __shared__ float2 ring1[HBF_RING][64]; // stage 0's outputs, row i0 (>= -2 H1: history) at slot i0 & 63
+  __shared__ float2 ring2[HBF_RING][64]; // stage 1's outputs
+  constexpr int L1H = 2 * H1, L2H = 2 * H2; // history rows of stages 1 and 2
+  static_assert(L1H + 34 <= HBF_RING && L2H + 18 <= HBF_RING, "ring size");
+  const unsigned lane = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+  const unsigned c0 = blockIdx.x * 64 + lane;
+  const bool live = c0 < C;
+  const unsigned c = live ? c0 : C - 1;
+  const int s_begin = seg_first[blockIdx.y], s_end = seg_first[blockIdx.y + 1];
+  if (s_begin >= s_end)
+    return;
+  const float2* __restrict__ mp = mix + c;
+  const size_t rowstride = CP;
+  // stage 0's input rows of this wave's group of a step: even rows 0, 2, .. 2 (3 + H0) and the four centres
+  constexpr int NA = 4 + H0 + 4;
+  constexpr int NSET = 4; // register sets: the rows of a step are fetched NSET - 1 steps ahead
+  float2 xs[NSET][NA];
+  /* Always all fifteen loads, rows clamped, never branched (a group at the end of the input has fewer
+   * than four outputs, a step may have none for this wave): the compiler can only wait for "all but the
+   * N youngest" loads, and it knows N -- the three younger sets that are still in flight -- only if every
+   * path issues the same number. */
+  auto fetch_a = [&](float2 (&x)[NA], const HbStep& st) {
+    const int k0 = st.a_lo + 4 * w;
+    const int last = 2 * H0 + (int)n_in - 1;
+#pragma unroll
+    for (int u = 0; u < 4 + H0; u++)
+      x[u] = mp[(size_t)min(2 * k0 + 2 * u, last) * rowstride];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      x[4 + H0 + r] = mp[(size_t)min(2 * k0 + 2 * r + H0, last) * rowstride];
+  };
+  // the rings' history (the first stretch of a call): rows -L1H .. -1 / -L2H .. -1
+  {
+    const HbStep f = steps[s_begin];
+    if (2 * f.b_lo - L1H < 0)
+      for (int i = w; i < L1H; i += 4)
+        ring1[(i - L1H) & (HBF_RING - 1)][lane] = hist1[(size_t)i * rowstride + c];
+    if (2 * f.c_lo - L2H < 0)
+      for (int i = w; i < L2H; i += 4)
+        ring2[(i - L2H) & (HBF_RING - 1)][lane] = hist2[(size_t)i * rowstride + c];
+#pragma unroll
+    for (int k = 0; k < NSET - 1; k++) // (a stretch's list has a multiple of NSET steps, empty ones at its end)
+      fetch_a(xs[k], steps[s_begin + k]);
+  }
+  __syncthreads();
+  // the step lists travel a step ahead of their use too (a scalar load is a round trip to the L2 for a lone wave)
+  HbStep cur = steps[s_begin], far = steps[min(s_begin + NSET - 1, s_end - 1)];
+  auto step = [&](int s, float2 (&x)[NA], float2 (&xn)[NA]) { // step s out of x; step s + NSET - 1's rows into xn
+    const HbStep st = cur;
+    const HbStep cur_next = steps[min(s + 1, s_end - 1)], far_next = steps[min(s + NSET, s_end - 1)];
+    fetch_a(xn, far);
+    { // stage 0: four outputs per wave out of registers
+      const int k0 = st.a_lo + 4 * w;
+      const int nr = min(4, st.a_lo + st.a_n - k0);
+      if (nr > 0)
+      {
+        float2 acc[4];
+        hb_rows<4, H0>([&](int row) { return (row & 1) ? x[4 + H0 + (row - H0) / 2] : x[row / 2]; }, hc0, acc);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (r < nr)
+          {
+            const int i0 = k0 + r;
+            ring1[i0 & (HBF_RING - 1)][lane] = acc[r];
+            if (live && i0 >= (int)n0 - L1H)
+              tail1[(size_t)(i0 - ((int)n0 - L1H)) * rowstride + c] = acc[r];
+          }
+      }
+    }
+    lds_barrier();
+    { // stage 1: two outputs per wave out of ring 1 (row = output index of stage 0 + L1H)
+      const int k0 = st.b_lo + 2 * w;
+      const int nr = min(2, st.b_lo + st.b_n - k0);
+      if (nr > 0)
+      {
+        float2 acc[2];
+        hb_rows<2, H1>([&](int row) { return ring1[(2 * k0 + row - L1H) & (HBF_RING - 1)][lane]; }, hc1, acc);
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+          if (r < nr)
+          {
+            const int i1 = k0 + r;
+            ring2[i1 & (HBF_RING - 1)][lane] = acc[r];
+            if (live && i1 >= (int)n1 - L2H)
+              tail2[(size_t)(i1 - ((int)n1 - L2H)) * rowstride + c] = acc[r];
+          }
+      }
+    }
+    lds_barrier();
+    { // stage 2: one output per wave out of ring 2
+      const int k0 = st.c_lo + w;
+      if (k0 < st.c_lo + st.c_n)
+      {
+        float2 acc[1];
+        hb_rows<1, H2>([&](int row) { return ring2[(2 * k0 + row - L2H) & (HBF_RING - 1)][lane]; }, hc2, acc);
+        if (live)
+          out[(size_t)(Hout + (unsigned)k0) * rowstride + c] = acc[0];
+      }
+    }
+    cur = cur_next;
+    far = far_next;
+  };
+  for (int s = s_begin; s < s_end; s += NSET)
+  {
+#pragma unroll
+    for (int k = 0; k < NSET; k++)
+      step(s + k, xs[k], xs[(k + NSET - 1) % NSET]);
+  }
+}
+
 /* Workgroup = 64 channels x RF_TI outputs.  The T-1+RF_TI input rows of the tile are staged once
  * in LDS ([row][channel]: conflict-free reads), because every input row is needed by T different
  * outputs and re-reading it from L2 for each made the kernel L2-bandwidth bound.
