@@ -315,7 +315,7 @@ def main():
     shifts = (np.arange(C, dtype=np.int32) % table) - table // 2 if shared else None
     batch = pkg.Batch(pkg.make_params(FS, 0.0 if shared else -0.15 * FS, 48000.0, 15000.0, D,
                                       table_size=table, if_filter_order=order,
-                                      fir_reduction=args.fir_reduction),
+                                      fir_reduction=0x101 if args.fir_reduction else 0),
                       C, tuning_shifts=shifts, device=local_rank, record_callbacks=False)
     for kv in args.debug_set:
         key, _, val = kv.partition("=")
@@ -556,7 +556,7 @@ def main():
     if use_export:
         total_groups = int(group_acc.item())  # rank 0: groups that arrived from every rank
     serial_probe = None
-    if os.environ.get("FMD_SERIAL_PROBE"):  # dev aid: per-workgroup timing of the serial stage
+    if "serial_probe=1" in args.debug_set:  # dev aid: per-workgroup timing of the serial stage
         pr = batch.debug_serial_probe()
         where = pr[:, :, 2] >> 40          # CU/SH/SE byte of HW_ID, XCC id above it
         pr[:, :, 2] &= (1 << 40) - 1

@@ -55,6 +55,8 @@ extern "C" {
 /* Constructor arguments of cFmDecoder (FmDecode.h:110-116).  table_size / if_filter_order are
  * the two internal constants BASELINE configs 3 and 5 override; 0 selects the reference
  * values 64 (FmDecode.cpp:249) and 8*downsample (FmDecode.cpp:262). */
+#define FMD_FIR_SEQUENTIAL 0
+#define FMD_FIR_SHUFFLE_PARITY_WAIVED 0x101
 typedef struct fmd_params
 {
   double sample_rate_if;
@@ -65,12 +67,14 @@ typedef struct fmd_params
   int us_version;
   unsigned table_size;
   unsigned if_filter_order;
-  /* How the IF FIR adds up an output's taps.  0 (default): one lane per output, taps in the
-   * reference's order (DownConvert.cpp:117-121) -- bit-identical results.  1: the sum split over four
-   * lanes and combined with wavefront shuffles (the reduction BASELINE's north star names): a
-   * different order of float additions, so results are close to but not identical with the
-   * reference's (audio ~1e-6..1e-5 RMS apart); opt-in, headline window
-   * layout (odd downsample, power-of-two tuner table) only, other geometries ignore it. */
+  /* How the IF FIR adds up an output's taps.  FMD_FIR_SEQUENTIAL (0, the default and the only mode
+   * under the parity contract): one lane per output, taps in the reference's order
+   * (DownConvert.cpp:117-121) -- bit-identical results.  FMD_FIR_SHUFFLE_PARITY_WAIVED: the sum split
+   * over four lanes and combined with wavefront shuffles (the reduction BASELINE's north star names):
+   * a different order of float additions.  Measured on BASELINE config 2 (6 s): audio 1.2e-5 RMS from
+   * the reference (worst block 3.5e-5) -- ABOVE the 1e-5 RMS the contract allows -- and 3x slower, so
+   * whoever asks for it says in the value itself that parity is waived; a plain 1 is refused.
+   * Headline window layout only (odd downsample, power-of-two tuner table), other geometries ignore it. */
   int fir_reduction;
 } fmd_params;
 

@@ -216,6 +216,10 @@ def _check(rc):
     return rc
 
 
+FIR_SEQUENTIAL = 0
+FIR_SHUFFLE_PARITY_WAIVED = 0x101  # include/fmd.h: the shuffle-reduced IF FIR, outside the parity contract
+
+
 def make_params(sample_rate_if, tuning_offset, sample_rate_pcm=48000.0, bandwidth_pcm=15000.0,
                 downsample=1, us_version=False, table_size=0, if_filter_order=0, fir_reduction=0):
     return FmdParams(sample_rate_if, tuning_offset, sample_rate_pcm, bandwidth_pcm, downsample,

@@ -142,6 +142,13 @@ struct fmd_batch
   std::vector<std::unique_ptr<HbfPlan>> hbf_plans;
   DevBuf<float2> hbf_tail1, hbf_tail2;
   int hbf_mode = -1;
+  // development switches (fmd_batch_debug_set; the library reads no environment variable)
+  int dbg_fir_nt = 0;          // tiles per IF FIR workgroup (0: the library decides)
+  int dbg_fir_b128 = 1;        // long filters: 16-byte window reads where the layout allows
+  int dbg_serial_claim = 0;    // whole-CU serial stage: every role wave claims its SIMD's register file
+  int dbg_post_delay_us = 20;  // the post chain starts this long behind the serial stage's end
+  int dbg_hb4 = 1, dbg_ring4 = 1; // 0: the generic half-band / ring-FIR kernels where the unrolled ones would run
+  int dbg_prof_dump = 0;
   DevBuf<long long> serial_probe; // FMD_SERIAL_PROBE=1: per-workgroup timing of the serial stage
   DevBuf<float> fstate; // all float state arrays, CP each
   DevBuf<int> istate;
@@ -190,10 +197,7 @@ struct fmd_batch
   //   concurrency 2: as 1, but the caller's stream is only ordered after a call by fmd_batch_wait /
   //                  fmd_batch_collect_rds; lets call k+1's FIR overlap call k's serial stages
   int concurrency = 1;
-  hipStream_t s_fir = nullptr, s_ser = nullptr, s_post = nullptr, s_rds = nullptr, s_aud = nullptr;
-  // The two heavy chains behind the serial stage -- RDS decimator (bandwidth-bound) and resampler +
-  // audio low-pass (issue-bound) -- side by side on s_post and s_aud instead of one after the other
-  bool heavy_par = false;
+  hipStream_t s_fir = nullptr, s_ser = nullptr, s_post = nullptr, s_rds = nullptr;
   // What the light part of a call's post chain (RDS PLL, matched filter, bit recovery, audio tail)
   // needs to know about its call: see launch_light.
   struct LightJob
@@ -207,7 +211,7 @@ struct fmd_batch
   };
   bool split_post = false;
   bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
-  enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_HEAVY_A, EV_RDSH, EV_N };
+  enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_RDSH, EV_N };
   hipEvent_t cev[NSLOT][EV_N] = {};
   bool cev_ready = false;
   uint32_t slot_call[NSLOT] = {}; // call index that last used the slot (0 = never)
@@ -299,8 +303,6 @@ struct fmd_batch
       (void)hipStreamDestroy(s_post);
       if (s_rds)
         (void)hipStreamDestroy(s_rds);
-      if (s_aud)
-        (void)hipStreamDestroy(s_aud);
     }
     h_iq.release();
     h_audio.release();
@@ -667,9 +669,11 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   b->params.us_version = params->us_version != 0;
   b->params.table_size = params->table_size;
   b->params.if_filter_order = params->if_filter_order;
-  b->params.fir_reduction = params->fir_reduction;
-  if (params->fir_reduction != 0 && params->fir_reduction != 1)
-    return fail(FMD_ERR_ARG, "fmd_batch_create: fir_reduction must be 0 (sequential) or 1 (shuffle)");
+  if (params->fir_reduction != FMD_FIR_SEQUENTIAL && params->fir_reduction != FMD_FIR_SHUFFLE_PARITY_WAIVED)
+    return fail(FMD_ERR_ARG, "fmd_batch_create: fir_reduction must be 0 (sequential, the parity mode) or "
+                             "FMD_FIR_SHUFFLE_PARITY_WAIVED (shuffle-reduced: 1.2e-5 RMS from the reference, "
+                             "outside the 1e-5 contract)");
+  b->params.fir_reduction = params->fir_reduction == FMD_FIR_SHUFFLE_PARITY_WAIVED ? 1 : 0;
   try
   {
     b->des = fmd::make_design(b->params);
@@ -708,7 +712,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     }
     const unsigned long long need = 1ull * mmin * d.D;
     if (need > FMD_MAX_BLOCK)
-      return fail(FMD_ERR_ARG, "this geometry needs calls longer than FMD_MAX_BLOCK");
+      return fail(FMD_ERR_ARG, "this geometry needs calls longer than the largest block (65536 samples)");
     b->min_samples = unsigned(need);
   }
   if (cb)
@@ -828,8 +832,6 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
         (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     }
   }
-  if (getenv("FMD_SERIAL_PROBE") && atoi(getenv("FMD_SERIAL_PROBE")))
-    bad |= b->serial_probe.alloc(size_t(8) * 3 * (b->CP / 64)); // the last 8 launches
   bad |= b->sctab.alloc(d.sincos_tab.size());
   bad |= b->sctab256.alloc(d.sincos_tab256.size());
   bad |= b->fstate.alloc(size_t(fmd::F_SLOTS) * CP);
@@ -888,10 +890,9 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     // post chain has slack every call and goes last
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi)); // lo = least, hi = greatest priority
-    // FMD_HEAVY_PAR=1 (measured slower, off by default) needs a fifth stream; without it none is
-    // created: every extra stream competes for the few hardware queues (GPU_MAX_HW_QUEUES)
-    b->heavy_par = getenv("FMD_HEAVY_PAR") ? atoi(getenv("FMD_HEAVY_PAR")) != 0 : false;
-    const int nstreams = b->heavy_par ? 5 : 4;
+    // (the two heavy chains side by side on a fifth stream: measured slower in rounds 1-3, removed; every
+    // extra stream competes for the few hardware queues, GPU_MAX_HW_QUEUES)
+    const int nstreams = 4;
     // (the light chain's stream at the high priority too: measured twice, no difference)
     const int prio[5] = {hi, hi, lo, lo, lo};
     hipStream_t st4[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -901,21 +902,16 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     b->s_ser = st4[1];
     b->s_post = st4[2];
     b->s_rds = st4[3];
-    b->s_aud = st4[4];
     // RDS chain and audio chain behind the serial stage are independent.  With more channels than
     // the chip holds serial-stage workgroups (256 CUs x 64 channels) the batch is throughput-bound
     // and they run side by side on two streams (+10 % at 24 576, +12 % at 32 768 channels); below
     // that the extra concurrent kernels only stretch the latency-bound serial stage (-4 % at
-    // 8192), so they share one stream.  FMD_SPLIT_POST=0/1 overrides.
+    // 8192), so they share one stream ("split_post" of fmd_batch_debug_set overrides).
     b->split_post = b->CP > 16384;
     // The serial stage takes whole CUs (one role wave per SIMD) while that costs at most a quarter of the chip (<= 8192
     // channels = 64 CUs; +4.4 % at 8192 channels) and the batch is big enough for the bandwidth
-    // kernels to notice their neighbours at all.  FMD_SERIAL_EXCLUSIVE=0/1 overrides.
+    // kernels to notice their neighbours at all ("serial_exclusive" of fmd_batch_debug_set overrides).
     b->serial_exclusive = b->CP <= 8192 && b->CP >= 1024;
-    if (const char* e = getenv("FMD_SERIAL_EXCLUSIVE"))
-      b->serial_exclusive = atoi(e) != 0;
-    if (const char* e = getenv("FMD_SPLIT_POST"))
-      b->split_post = atoi(e) != 0;
   }
   for (auto& row : b->cev)
     for (auto& e : row)
@@ -1027,13 +1023,12 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   // several tiles per workgroup with the next tile's loads in flight during the tap loop
   // (k_if_fir_mt): the headline geometry only.  Two tiles: 0.94-0.95 ms inside the pipeline against
   // 0.98-1.00 (one tile per workgroup) on the same box, the same alone; 3, 4, 8 tiles: no better
-  // than one.  FMD_FIR_NT overrides (1 = k_if_fir).
+  // than one ("fir_nt" of fmd_batch_debug_set overrides, 1 = k_if_fir).
   // With the chip to itself (calls not overlapped) one tile per workgroup is the faster form (0.77
   // against 0.83 ms), and in the throughput-bound regime (> 8192 channels) the faster FIR only
   // takes from the kernels beside it (32 768 channels: 228 against 236 GS/s): two tiles only beside
   // the whole-CU serial stage.
-  static const int fir_nt_env = getenv("FMD_FIR_NT") ? atoi(getenv("FMD_FIR_NT")) : 0;
-  const int fir_nt = fir_nt_env ? fir_nt_env : (b->concurrency == 2 && b->serial_exclusive ? 2 : 1);
+  const int fir_nt = b->dbg_fir_nt ? b->dbg_fir_nt : (b->concurrency == 2 && b->serial_exclusive ? 2 : 1);
   unsigned nblocks = C * ntiles;
   if (TILE == 64 && E == 0 && pow2 && rounds == 7 && fir_nt > 1 && !shfl)
   {
@@ -1081,9 +1076,9 @@ int launch_if_stage_e(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
     return launch_if_stage_t<IN, TILE, 0>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
   if (D % 4 != 0)
   { // D = 2 * odd.  Long filters: plain window read two samples at a time (fir_long_b128_asm: the b128
-    // lane groups are conflict-free at this stride); otherwise the two-region window.  FMD_FIR_B128=0
+    // lane groups are conflict-free at this stride); otherwise the two-region window.  "fir_b128" = 0
     // keeps the two-region form for long filters too (fir_long_e1_asm).
-    static const int b128 = getenv("FMD_FIR_B128") ? atoi(getenv("FMD_FIR_B128")) : 1;
+    const int b128 = b->dbg_fir_b128;
     const unsigned T = b->des.table_size;
     const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
     if (b128 && TILE == 256 && b->des.if_order >= 512 && pow2)
@@ -1094,7 +1089,7 @@ int launch_if_stage_e(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
     // that the lane stride inside a region stays EVEN and two adjacent positions come with one
     // 16-byte read (fir_long_e1_b128_asm / fir_long_e2_b128_asm); FMD_FIR_B128=0 keeps the 8-byte reads
     // of the four-region window (fir_long_e2_asm).  Short filters: four regions (odd stride for 4 * odd).
-    static const int b128 = getenv("FMD_FIR_B128") ? atoi(getenv("FMD_FIR_B128")) : 1;
+    const int b128 = b->dbg_fir_b128;
     const unsigned T = b->des.table_size;
     const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
     if (b128 && TILE == 256 && b->des.if_order >= 512 && pow2)
@@ -1225,7 +1220,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   if (!b || !d_iq || !d_audio)
     return fail(FMD_ERR_ARG, "fmd_batch_process_device: null argument");
   if (samples > FMD_MAX_BLOCK || samples < b->min_samples)
-    return fail(FMD_ERR_SIZE, "samples must be within [fmd_batch_min_samples(), FMD_MAX_BLOCK] = [" +
+    return fail(FMD_ERR_SIZE, "samples must be within [fmd_batch_min_samples(), the largest block] = [" +
                                   std::to_string(b->min_samples) + ", 65536]");
   // a lane loads two IQ samples at a time: every channel's stream has to start on a pair boundary
   {
@@ -1317,8 +1312,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   hipStream_t sF = serial_mode ? stream : b->s_fir;
   hipStream_t sS = serial_mode ? stream : b->s_ser;
   hipStream_t sP = serial_mode ? stream : b->s_post;
-  const bool heavy_par = !serial_mode && !b->split_post && b->heavy_par;
-  hipStream_t sA = heavy_par ? b->s_aud : sP, sR = (!serial_mode && b->split_post) ? b->s_rds : sP;
+  hipStream_t sA = sP, sR = (!serial_mode && b->split_post) ? b->s_rds : sP;
   // one-stream form: the light parts of the post chain go to their own stream (see below)
   hipStream_t sL = serial_mode ? stream : b->s_rds;
   hipEvent_t* ce = b->cev[es];
@@ -1427,8 +1421,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
      * bandwidth kernels' waves that now fit beside it (131 of the CU's 160 KB of LDS are the stage's, so
      * mostly kernels without LDS) gain more than the stage loses: +2.1 %, +-0, +1.4 % whole path on three
      * boxes, never slower (stage 1.71 -> 1.83 ms, FIR 1.02 -> 0.97 ms inside the pipeline on the
-     * first).  FMD_SERIAL_CLAIM=1 brings the claim back. */
-    static const bool serial_claim = getenv("FMD_SERIAL_CLAIM") && atoi(getenv("FMD_SERIAL_CLAIM")) != 0;
+     * first).  "serial_claim" = 1 of fmd_batch_debug_set brings the claim back. */
+    const bool serial_claim = b->dbg_serial_claim != 0;
     auto kser2 = serial_claim ? &fmd::k_demod_serial<2, true> : &fmd::k_demod_serial<2, false>;
     if (b->serial_exclusive && !serial_mode && evset && b->profiling == 1)
       // profiling level 1: the stage's own start and stop too (fmd_batch_debug_timeline)
@@ -1461,8 +1455,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
    * workgroups have drained (measured: 136 us after its predecessor ended, every call).  So the
    * post chain and the light part start behind a single wave that idles for a few microseconds:
    * the serial stage is dispatched first (30-50 us after its predecessor, period 2.50 -> 2.42 ms).
-   * FMD_POST_DELAY_US overrides (0 = off). */
-  static const int post_delay_us = getenv("FMD_POST_DELAY_US") ? atoi(getenv("FMD_POST_DELAY_US")) : 20;
+   * "post_delay_us" of fmd_batch_debug_set overrides (0 = off). */
+  const int post_delay_us = b->dbg_post_delay_us;
   auto post_delay = [&](hipStream_t s) {
     if (post_delay_us > 0 && b->serial_exclusive && !serial_mode && b->concurrency == 2)
       hipLaunchKernelGGL(fmd::k_delay, dim3(1), dim3(64), 0, s, unsigned(post_delay_us) * 100u);
@@ -1539,7 +1533,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
         const bool last = (s + 1 == d.hb.size());
         float2* outp = last ? b->rdsraw.p : b->hbbuf[s].p;
         const unsigned Hout = last ? (T_lpf - 1) : unsigned(d.hb[s + 1].len - 1);
-        static const int hb4 = getenv("FMD_HB4") ? atoi(getenv("FMD_HB4")) : 1;
+        const int hb4 = b->dbg_hb4;
         const unsigned Hs = unsigned(d.hb[s].len - 1);
         float2* const hist_dst = s == 0 ? b->mix[q ^ 1].p : b->hbbuf[s - 1].p; // where the delay line lives
         if (hb_mode[s] == HB_PASS)
@@ -1580,7 +1574,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       }
     }
     mark(3);
-    static const int ring4 = getenv("FMD_RING4") ? atoi(getenv("FMD_RING4")) : 1;
+    const int ring4 = b->dbg_ring4;
     if (ring4 && T_lpf >= unsigned(fmd::RG))
       hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
                          sR, b->rdsraw.p, b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C,
@@ -1633,8 +1627,6 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
 
     /* ---- audio branch  (stream A): resamplers, 15 kHz LPF, de-emphasis / notch / matrix ---- */
     after(sA, ce[fmd_batch::EV_SER]);
-    if (heavy_par)
-      post_delay(sA);
     /* Large batches stream the rows through an LDS ring (k_resample_ring: every row crosses the fabric
      * once per segment instead of ~6 times); small ones, short calls and geometries whose window does
      * not fit a CU's LDS keep the window-per-wave form, which has more workgroups to offer. */
@@ -1676,7 +1668,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     }
     roll_later(b->brp(q), b->brp(q ^ 1), Hbb, M); // with the low-pass's own roll, at the chain's end
     mark(6);
-    static const int ring4a = getenv("FMD_RING4") ? atoi(getenv("FMD_RING4")) : 1;
+    const int ring4a = b->dbg_ring4;
     if (ring4a && T_alp >= unsigned(fmd::RG))
       hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (A + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
                          sA, b->rs.p, b->alp[q].p, A, int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
@@ -1728,11 +1720,6 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     rds_heavy();
     signal(ce[fmd_batch::EV_RDSH], sR);
     audio_heavy();
-    if (heavy_par)
-    { // EV_HEAVY = both chains done
-      signal(ce[fmd_batch::EV_HEAVY_A], sA);
-      after(sP, ce[fmd_batch::EV_HEAVY_A]);
-    }
     signal(ce[fmd_batch::EV_HEAVY], sP);
     fmd_batch::LightJob job;
     job.R = R;
@@ -1865,6 +1852,32 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
     if (value > 0 && b->rsr_R == 0)
       return fail(FMD_ERR_ARG, "fmd_batch_debug_set: no form of k_resample_ring fits this geometry");
     b->rsr_mode = value < 0 ? -1 : (value ? 1 : 0);
+  }
+  else if (k == "fir_nt")
+    b->dbg_fir_nt = std::max(0, value);
+  else if (k == "fir_b128")
+    b->dbg_fir_b128 = value != 0;
+  else if (k == "serial_claim")
+    b->dbg_serial_claim = value != 0;
+  else if (k == "serial_exclusive")
+    b->serial_exclusive = value != 0;
+  else if (k == "split_post")
+    b->split_post = value != 0;
+  else if (k == "post_delay_us")
+    b->dbg_post_delay_us = std::max(0, value);
+  else if (k == "hb4")
+    b->dbg_hb4 = value != 0;
+  else if (k == "ring4")
+    b->dbg_ring4 = value != 0;
+  else if (k == "prof_dump")
+    b->dbg_prof_dump = value != 0;
+  else if (k == "serial_probe")
+  { // per-workgroup timing of the serial stage's last 8 launches (fmd_batch_debug_serial_probe)
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipDeviceSynchronize());
+    b->serial_probe.release();
+    if (value && b->serial_probe.alloc(size_t(8) * 3 * (b->CP / 64)))
+      return fail(FMD_ERR_DEVICE, "serial probe allocation failed");
   }
   else if (k == "halfband_chain") // -1 the library decides, 0 a launch per stage, 1 k_halfband_chain wherever it applies
     b->hbf_mode = value < 0 ? -1 : (value ? 1 : 0);
@@ -2325,9 +2338,9 @@ int fmd_batch_get_stage_ms(fmd_batch* b, float* out, unsigned cap)
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
   const int nst = b->profiling >= 2 ? ST_COUNT : 1;
-  if (getenv("FMD_PROF_DUMP")) // dev aid: the IF FIR's duration call by call
+  if (b->dbg_prof_dump) // dev aid: the IF FIR's duration call by call
   {
-    fprintf(stderr, "FMD_PROF_DUMP if_fir ms per call:");
+    fprintf(stderr, "prof_dump: if_fir ms per call:");
     for (unsigned c = 0; c < b->prof_calls; c++)
     {
       float ms = 0;

@@ -161,3 +161,17 @@ def test_cpp_header_drops_into_reference_declaration_order():
                           os.path.join(ROOT, "tests", "cpp", "receiver_demo.cpp")],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+
+
+def test_the_library_reads_no_environment_variable():
+    """Development switches are per batch and by API (fmd_batch_debug_set): the shipped library neither
+    imports getenv nor carries the name of a switch."""
+    import subprocess
+    from __graft_entry__ import PKG_DIR
+    so = os.path.join(PKG_DIR, "libfmd_hip.so")
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    names = subprocess.run(["strings", so], capture_output=True, text=True, check=True).stdout
+    # (error messages may name a constant of include/fmd.h; nothing else that looks like a variable)
+    declared = set(re.findall(r"FMD_[A-Z0-9_]+", open(os.path.join(ROOT, "include", "fmd.h")).read()))
+    assert set(re.findall(r"FMD_[A-Z0-9_]+", names)) <= declared

@@ -1,8 +1,10 @@
-"""The opt-in shuffle-reduced IF FIR (fmd_params::fir_reduction = 1): BASELINE's north star words
+"""The opt-in shuffle-reduced IF FIR (fmd_params::fir_reduction = FMD_FIR_SHUFFLE_PARITY_WAIVED): BASELINE's north star words
 the per-tap reduction as wavefront shuffles; that changes the order of the float additions, so it
 cannot be bit-identical to the reference's sequential sum (DownConvert.cpp:117-121).  This test
 measures how far it lands from the parity mode on BASELINE config 2 (one stereo + RDS channel,
-2.4 MS/s, 220 blocks = 6 s) and pins the order of magnitude; the default stays the parity mode."""
+2.4 MS/s, 220 blocks = 6 s): 1.17e-5 RMS, worst block 3.46e-5 -- above the north star's own 1e-5
+gate, which is why the mode has to be asked for by a value that says parity is waived (a plain 1 is
+refused) and why every reported figure uses the sequential sum."""
 import numpy as np
 import pytest
 
@@ -17,7 +19,10 @@ def test_shuffle_reduction_distance_from_parity_mode(fmsig, capsys):
     fs, D, nblk = 2.4e6, 11, 220
     p = fmsig.default_params(fs, noise_sigma=0.005)
     exact = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 1)
-    fast = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D, fir_reduction=1), 1)
+    with pytest.raises(pkg.FmdError):  # a plain 1 does not get the mode
+        pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D, fir_reduction=1), 1)
+    fast = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D,
+                                     fir_reduction=pkg.FIR_SHUFFLE_PARITY_WAIVED), 1)
     exact.enable_taps()
     fast.enable_taps()
     se = sa = 0.0
@@ -46,8 +51,8 @@ def test_shuffle_reduction_distance_from_parity_mode(fmsig, capsys):
               "(worst block %.3g, signal RMS %.3g), FIR output relative difference %.3g"
               % (nblk - 1, rms, worst_blk, np.sqrt(sa / n), fir_rel))
     # the float32 noise floor of the two feedback PLLs (5e-6 .. 1.2e-5 for a
-    # 1-ulp input perturbation): the fast mode sits AT the north star's 1e-5 gate, not safely below it
-    assert 0.0 < rms < 5e-5
+    # 1-ulp input perturbation): what include/fmd.h documents for the mode, with a margin of a quarter
+    assert 0.0 < rms < 1.5e-5 and worst_blk < 4.5e-5
     assert exact.sink.frames.get(0, []) == fast.sink.frames.get(0, [])  # RDS content survives
     assert exact.status().stereo_detected == fast.status().stereo_detected == 1
     exact.close()

@@ -51,11 +51,10 @@ def test_single_rank_verify_full_shard():
     assert d["n_gpus"] == 1 and d["verify"]["ok"] and d["verify"]["channels_per_rank"] == [0, 1, 4096, 8191]
 
 
-def test_single_rank_verify_with_the_register_claim(monkeypatch):
+def test_single_rank_verify_with_the_register_claim():
     """The serial stage's other whole-CU form (every role wave claims its SIMD's register file,
-    FMD_SERIAL_CLAIM=1: the default until round 3's last change) on the same check."""
-    monkeypatch.setenv("FMD_SERIAL_CLAIM", "1")
-    d = _run_bench(1, ["--steps", "8", "--warmup", "2", "--ring", "4"], 29547)
+    "serial_claim" of fmd_batch_debug_set: the default until round 3's last change) on the same check."""
+    d = _run_bench(1, ["--steps", "8", "--warmup", "2", "--ring", "4", "--debug-set", "serial_claim=1"], 29547)
     assert d["n_gpus"] == 1 and d["verify"]["ok"]
 
 

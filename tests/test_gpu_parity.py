@@ -340,9 +340,10 @@ def test_degenerate_inputs_whole_cu_form(pkg, oracle):
     b.close()
 
 
-def test_serial_stage_probe(pkg, fmsig, monkeypatch):
-    """The per-workgroup probe of the serial stage (dev aid): off by default, and with
-    FMD_SERIAL_PROBE=1 one (start, end, cycles) record per workgroup and launch, in both forms."""
+def test_serial_stage_probe(pkg, fmsig):
+    """The per-workgroup probe of the serial stage (dev aid): off by default, and with the
+    "serial_probe" switch of fmd_batch_debug_set one (start, end, cycles) record per workgroup and
+    launch, in both forms."""
     fs, D = 2.4e6, 11
     p = fmsig.default_params(fs, noise_sigma=0.01)
     iq = fmsig.generate_f32(p, 0, N).view(np.complex64)
@@ -350,9 +351,9 @@ def test_serial_stage_probe(pkg, fmsig, monkeypatch):
     b.process_host(np.stack([iq, iq]))
     assert b.debug_serial_probe().shape[1] == 0
     b.close()
-    monkeypatch.setenv("FMD_SERIAL_PROBE", "1")
     for C, wgs in ((2, 1), (1100, 9)):  # shared form: one workgroup per 64 channels; whole-CU form: per 128
         b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
+        b.debug_set("serial_probe", 1)
         b.process_host(np.broadcast_to(iq, (C, N)).copy())
         b.process_host(np.broadcast_to(iq, (C, N)).copy())
         pr = b.debug_serial_probe()
@@ -396,4 +397,27 @@ def test_ragged_block_sizes_overlapped_calls(pkg, oracle, fmsig):
         for c in range(C):
             r = refs[c].process_stream(ins[i][c])
             assert nfs[i] == r.size and _bits_equal(a[c, :nfs[i]], r), (i, n, c)
+    b.close()
+
+
+def test_generic_filter_kernels_bit_exact(pkg, oracle, fmsig):
+    """The generic half-band and ring-FIR kernels (what geometries outside the unrolled kernels' range run:
+    very short or very long half-bands, filters shorter than a group of outputs), forced here on the
+    usual geometry ("hb4" / "ring4" = 0 of fmd_batch_debug_set): every stage tap bit-exact."""
+    fs, D = 2.4e6, 11
+    p = fmsig.default_params(fs, noise_sigma=0.01, seed=19)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 1)
+    b.debug_set("hb4", 0)
+    b.debug_set("ring4", 0)
+    b.debug_set("halfband_chain", 0)
+    b.enable_taps()
+    for blk, n in enumerate([N, N, 30000, N, 2000, N]):
+        iq = fmsig.generate_f32(p, blk * N, n)
+        a_ref = o.process_stream(iq)
+        a_gpu = b.process_host(iq.view(np.complex64), shared=True)[0]
+        taps = o.taps()
+        for name in STAGES:
+            assert _bits_equal(b.tap(name).view(np.float32), taps[name].view(np.float32)), (blk, name)
+        assert _bits_equal(a_gpu, a_ref), blk
     b.close()
