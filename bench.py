@@ -127,25 +127,65 @@ def _spawn_ranks(n):
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
-    for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0", ROLE_RANK=str(r))
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
-                                      stderr=None))
+    import signal
     import threading
+
+    def _end_children(grace=3.0):
+        """terminate(), then kill(), exactly the children started here (each is its own session:
+        its process group goes with it)"""
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            try:
+                os.killpg(p.pid, signal.SIGTERM)
+            except (ProcessLookupError, PermissionError):
+                pass
+        t_end = time.time() + grace
+        while time.time() < t_end and any(p.poll() is None for p in live):
+            time.sleep(0.05)
+        for p in live:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    def _on_signal(signum, _frame):
+        # a driver's timeout, Ctrl-C, a cancelled job: the ranks must not outlive the launcher (they
+        # would hold every GPU until their own watchdog fires)
+        _end_children()
+        raise SystemExit(128 + signum)
+
+    old_handlers = {sg: signal.signal(sg, _on_signal) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    watchdog = 900
+    for i, a in enumerate(sys.argv):
+        if a == "--watchdog" and i + 1 < len(sys.argv):
+            watchdog = int(sys.argv[i + 1])
+        elif a.startswith("--watchdog="):
+            watchdog = int(a.split("=", 1)[1])
+    launcher_deadline = time.time() + watchdog + 30.0  # the ranks' own watchdog, plus a grace period
     chunks = []
-    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-    rd.start()
-    # a rank that dies leaves its peers inside a rendezvous or a collective: give them a grace period,
-    # then end exactly the processes started here
-    deadline = None
-    while any(p.poll() is None for p in procs):
-        if deadline is None and any(p.poll() not in (None, 0) for p in procs):
-            deadline = time.time() + 20.0
-        if deadline is not None and time.time() > deadline:
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()
-        time.sleep(0.05)
+    try:
+        for r in range(n):
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0", ROLE_RANK=str(r))
+            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                          stderr=None, start_new_session=True))
+        sys.stderr.write("bench.py: started ranks, pids %s\n" % " ".join(str(p.pid) for p in procs))
+        sys.stderr.flush()
+        rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        rd.start()
+        # a rank that dies leaves its peers inside a rendezvous or a collective: give them a grace
+        # period, then end exactly the processes started here
+        deadline = None
+        while any(p.poll() is None for p in procs):
+            if deadline is None and any(p.poll() not in (None, 0) for p in procs):
+                deadline = time.time() + 20.0
+            if (deadline is not None and time.time() > deadline) or time.time() > launcher_deadline:
+                _end_children()
+            time.sleep(0.05)
+    finally:
+        _end_children(grace=1.0)  # no-op when every rank has exited
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     rcs = [p.wait() for p in procs]
     rd.join(timeout=10.0)
     out0 = b"".join(c for c in chunks if c)
@@ -208,6 +248,8 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _spawn_ranks(args.gpus)  # does not return
+    if os.environ.get("FMD_BENCH_TEST_HANG") == "1" and os.environ.get("FMD_BENCH_SPAWNED") == "1":
+        time.sleep(600)  # test aid (tests/test_bench_launcher.py): a rank that never finishes
 
     import threading
 

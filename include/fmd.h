@@ -169,7 +169,9 @@ int fmd_batch_process_device_u8(fmd_batch* b, const uint8_t* d_iq_u8, size_t iq_
                                 unsigned* out_floats, void* stream);
 
 /* Host-buffer call: copies in, runs fmd_batch_process_device, copies audio out, collects RDS
- * groups and runs the UECP group decoder (callbacks fire here).  Synchronous. */
+ * groups and runs the UECP group decoder (callbacks fire here).  Synchronous.  Returns FMD_OK, a
+ * negative error, or FMD_WARN_RDS_LOST (once) when groups were dropped because a queue was full:
+ * audio and channel state are intact. */
 int fmd_batch_process_host(fmd_batch* b, const float* iq, size_t iq_channel_stride,
                            unsigned samples, float* audio, size_t audio_channel_stride,
                            unsigned* out_floats);
@@ -179,7 +181,9 @@ int fmd_batch_process_host_u8(fmd_batch* b, const uint8_t* iq_u8, size_t iq_chan
 
 /* Copies the queued RDS groups (all channels, call order) to `out`, waits for `stream`.
  * Returns the number of groups (<= cap) or a negative error.  When run_group_decoder != 0
- * each group is also fed to that channel's UECP group decoder (callbacks fire). */
+ * each group is also fed to that channel's UECP group decoder (callbacks fire).  The return value is
+ * a count, so a loss of groups is not reported here: the flag stays for fmd_batch_wait /
+ * fmd_batch_take_rds_lost / fmd_batch_process_host. */
 int fmd_batch_collect_rds(fmd_batch* b, fmd_rds_group* out, unsigned cap, int run_group_decoder,
                           void* stream);
 

@@ -170,7 +170,11 @@ struct fmd_batch
   // the next call that appends to the same queue (NSLOT calls later) when it is empty
   hipEvent_t ev_drained[NSLOT] = {};
   bool drained_pending[NSLOT] = {};
+  // running row count of one export (k_rds_export): a cursor per call out of a ring, so that two exports
+  // on different streams never share one
+  static constexpr unsigned kExportCursors = 16;
   DevBuf<unsigned> export_cursor;
+  unsigned export_seq = 0;
   fmd::ChannelState st{};
   std::vector<fmd::HbCoef> hbcoef;
 
@@ -411,12 +415,12 @@ int check_device_errors(fmd_batch* b)
 
 /* RDS groups that did not fit a queue or the caller's record buffer are lost, nothing else: audio and
  * channel state are intact and the batch stays usable.  Reported once (FMD_WARN_RDS_LOST), then
- * cleared; a kernel setting the flag again at the same moment is seen by the next query. */
+ * cleared (atomically: a kernel setting the flag again at that moment is seen by the next query). */
 int take_lost_groups(fmd_batch* b)
 {
-  if (!b->h_err || !__atomic_load_n(&b->h_err[1], __ATOMIC_ACQUIRE))
+  // one exchange: a kernel that ORs the flag in between a load and a store would have its loss wiped
+  if (!b->h_err || !__atomic_exchange_n(&b->h_err[1], 0u, __ATOMIC_ACQ_REL))
     return FMD_OK;
-  __atomic_store_n(&b->h_err[1], 0u, __ATOMIC_RELEASE);
   g_err = "RDS groups were lost: a call's group queue or the export buffer was full (drain every call's "
           "groups with fmd_batch_collect_rds / fmd_batch_export_rds_device, with cap >= the groups queued)";
   return FMD_WARN_RDS_LOST;
@@ -843,7 +847,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->queue_counts.alloc(fmd_batch::NSLOT);
   bad |= hipHostMalloc(reinterpret_cast<void**>(&b->h_counts), fmd_batch::NSLOT * sizeof(unsigned),
                        hipHostMallocDefault) != hipSuccess;
-  bad |= b->export_cursor.alloc(1);
+  bad |= b->export_cursor.alloc(fmd_batch::kExportCursors);
   if (bad)
     return fail(FMD_ERR_DEVICE, std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError()));
 
@@ -1807,7 +1811,8 @@ static bool slot_eligible(const fmd_batch* b, int q, int lag)
   return b->slot_call[q] != 0 && b->slot_call[q] + uint32_t(lag) <= b->call_index;
 }
 
-int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream_)
+/* take_lost = false: the recoverable flag (groups lost) stays for whoever reports it */
+static int wait_impl(fmd_batch* b, int lag, void* stream_, bool take_lost)
 {
   if (!b || lag < 0 || lag > 4)
     return fail(FMD_ERR_ARG, "fmd_batch_wait: bad argument (lag must be 0..4)");
@@ -1823,7 +1828,12 @@ int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream_)
   // asynchronous: reports what the device has flagged so far (calls that have finished)
   if (int rc = check_device_errors(b))
     return rc;
-  return take_lost_groups(b);
+  return take_lost ? take_lost_groups(b) : FMD_OK;
+}
+
+int fmd_batch_wait_lagged(fmd_batch* b, int lag, void* stream_)
+{
+  return wait_impl(b, lag, stream_, true);
 }
 
 int fmd_batch_take_rds_lost(fmd_batch* b)
@@ -2048,15 +2058,15 @@ int fmd_batch_export_rds_device(fmd_batch* b, int32_t* d_records, unsigned cap, 
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipMemsetAsync(d_records, 0, size_t(cap) * 4 * sizeof(int32_t), stream));
-  HIPCHK(hipMemsetAsync(b->export_cursor.p, 0, sizeof(unsigned), stream));
+  unsigned* const cursor = b->export_cursor.p + (b->export_seq++ % fmd_batch::kExportCursors);
+  HIPCHK(hipMemsetAsync(cursor, 0, sizeof(unsigned), stream));
   for (int q = 0; q < fmd_batch::NSLOT; q++)
   {
     if (!slot_to_drain(b, q, lag))
       continue; // also: already exported for its call -- one launch per call, not one per slot
     HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_RDS], 0));
     hipLaunchKernelGGL(fmd::k_rds_export, dim3(1), dim3(256), 0, stream, b->queue[q].p, b->qcount(q),
-                       b->queue_cap, reinterpret_cast<int4*>(d_records), cap, b->export_cursor.p,
-                       channel_offset, b->st.err);
+                       b->queue_cap, reinterpret_cast<int4*>(d_records), cap, cursor, channel_offset, b->st.err);
     HIPCHK(hipEventRecord(b->ev_drained[q], stream));
     b->drained_pending[q] = true;
     b->drained_call[q] = b->slot_call[q];
@@ -2109,7 +2119,7 @@ static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t 
     return fail(FMD_ERR_ARG, "audio_channel_stride smaller than the audio produced");
   // Synchronous entry point in every concurrency mode: in mode 2 the null stream is not ordered after
   // the call -- order it behind the whole call before copying the audio out.
-  rc = fmd_batch_wait(b, nullptr);
+  rc = wait_impl(b, 0, nullptr, false); // the groups-lost flag is this call's to report, at its end
   if (rc < 0)
     return rc;
   HIPCHK(hipMemcpy2D(audio, (C > 1 ? audio_channel_stride : size_t(nf)) * sizeof(float), b->h_audio.p,
@@ -2119,7 +2129,7 @@ static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t 
     return rc;
   if (out_floats)
     *out_floats = nf;
-  return FMD_OK;
+  return take_lost_groups(b); // FMD_OK, or FMD_WARN_RDS_LOST once: audio and state are intact
 }
 
 int fmd_batch_process_host(fmd_batch* b, const float* iq, size_t iq_channel_stride, unsigned samples,
@@ -2407,7 +2417,7 @@ int fmd_process_stream(fmd_decoder* d, const float* iq, unsigned samples, float*
     return fail(FMD_ERR_ARG, "null decoder");
   unsigned nf = 0;
   int rc = fmd_batch_process_host(d->b, iq, 0, samples, audio, 0, &nf);
-  return rc == FMD_OK ? int(nf) : rc;
+  return rc < 0 ? rc : int(nf); // (a groups-lost warning does not touch the audio: fmd_last_error has it)
 }
 
 int fmd_process_stream_u8(fmd_decoder* d, const uint8_t* buf, unsigned samples, float* audio)
@@ -2416,7 +2426,7 @@ int fmd_process_stream_u8(fmd_decoder* d, const uint8_t* buf, unsigned samples, 
     return fail(FMD_ERR_ARG, "null decoder");
   unsigned nf = 0;
   int rc = fmd_batch_process_host_u8(d->b, buf, 0, samples, audio, 0, &nf);
-  return rc == FMD_OK ? int(nf) : rc;
+  return rc < 0 ? rc : int(nf); // (a groups-lost warning does not touch the audio: fmd_last_error has it)
 }
 
 int fmd_get_status(fmd_decoder* d, fmd_status* st)

@@ -1617,8 +1617,14 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     unsigned stereo_q, long long* __restrict__ wg_probe)
 {
   // sctab_g: (sin, cos)(k / 256), 2048 entries (fmd_sincos_p256)
-  // dev aid (FMD_SERIAL_PROBE=1): when each workgroup started and ended on the 100 MHz clock, and
-  // its shader-clock cycles in between
+  // dev aid ("serial_probe" of fmd_batch_debug_set): when each workgroup started and ended on the
+  // 100 MHz clock, and its shader-clock cycles in between
+  /* LDS per workgroup: tables 32 KB + 2.5 KB, per group chunk 16 KB + staged input 33 KB: 84 KB with one
+   * group (NG = 1, the shared form above 8192 channels and in serialised mode), 133 KB with two.  84 KB
+   * is more than half a CU's 160 KB: ONE one-group workgroup (2 waves) per CU, so 32 768 channels = 512
+   * workgroups take two rounds on 256 CUs.  Measured at 32 768 channels (profiles/r*_bench_32768ch.json):
+   * the batch is throughput-bound by the bandwidth kernels there and shows no loss against the 66 KB of
+   * round 2 (1024-entry table, rows of 64), which did fit twice; whoever grows this further should look. */
   const long long probe_r0 = wg_probe ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   const long long probe_c0 = wg_probe ? (long long)__builtin_readcyclecounter() : 0;
   __shared__ float chunk_all[NG][2][DS][64];  // baseband, FM role -> pilot/RDS role

@@ -97,10 +97,13 @@ public:
   /* a few blocks up front, from the thread that opens the stream (page-locking takes milliseconds:
    * not something the source thread should do in the middle of a delivery) */
   void prime(unsigned blocks, size_t bytes)
-  {
+  { // all of them taken first, then given back: a block recycled at once would be the next one taken
+    std::vector<IqBlock*> got;
     for (unsigned i = 0; i < blocks; i++)
       if (IqBlock* blk = take_free(bytes))
-        recycle(blk);
+        got.push_back(blk);
+    for (IqBlock* blk : got)
+      recycle(blk);
   }
 
   /* copies `bytes` bytes into a recycled (or new) pinned block and appends it; false = out of

@@ -23,3 +23,36 @@ def test_launcher_reports_failed_ranks_without_a_gpu():
     assert out.returncode != 0
     assert "ranks failed" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]  # no result line
+
+
+def test_launcher_takes_its_ranks_with_it_when_it_is_terminated():
+    """A driver's timeout or a cancelled job sends the launcher SIGTERM: the ranks it started (here: two
+    that never finish) must be gone with it, not left holding the GPUs until their own watchdog fires."""
+    import re
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FMD_BENCH_TEST_HANG"] = "1"
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
+                         env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    line = ""
+    t_end = time.time() + 30
+    while "started ranks" not in line and time.time() < t_end:
+        line = p.stderr.readline()
+    pids = [int(x) for x in re.findall(r"\d+", line.split("pids", 1)[1])]
+    assert len(pids) == 2
+    time.sleep(0.5)
+    assert all(os.path.exists("/proc/%d" % q) for q in pids)
+    p.send_signal(signal.SIGTERM)
+    rc = p.wait(timeout=15)
+    assert rc == 128 + signal.SIGTERM
+    t_end = time.time() + 5
+    def gone(q):
+        try:
+            return open("/proc/%d/stat" % q).read().split()[2] == "Z"
+        except OSError:
+            return True
+    while not all(gone(q) for q in pids) and time.time() < t_end:
+        time.sleep(0.05)
+    assert all(gone(q) for q in pids)
