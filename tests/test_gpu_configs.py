@@ -135,3 +135,45 @@ def test_config4_full_shard_properties(oracle, fmsig):
                       zip(g["channel"], g["call_index"], g["blocks"]) if ch == c)
         assert mine == sorted((k, tuple(bl)) for k, bl in refs[c].rds_groups()), c
     b.close()
+
+
+def test_config5_full_size_against_oracle(oracle, fmsig):
+    """BASELINE configs[4] at its full size: 4096 channels @10 MS/s, D = 46, 4096-tap IF FIR, 65536 IQ
+    per call, device-generated input, calls overlapped like bench.py.  8 channels incl. the first and
+    the last against the oracle bit for bit on the very bytes the device generator produced (the
+    oracle's cDownsampleFilter takes any order, like the reference's: DownConvert.h:36-39), and the
+    size-independent property over the whole batch: channels c and c + 2048 carry the same station."""
+    import torch
+    pkg = load_package()
+    fs, D, order, C, nblk, LAG = 10e6, 46, 4096, 4096, 5, 2
+    chans = [fmsig.channel_params(fs, c % 2048) for c in range(C)]
+    gen = fmsig.DeviceGenerator(chans, "cuda")
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D, if_filter_order=order), C,
+                  record_callbacks=False)
+    b.set_concurrency(2)
+    a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
+    iq = [torch.empty((C, N, 2), dtype=torch.float32, device="cuda") for _ in range(nblk)]
+    audio = [torch.zeros((C, a_stride), dtype=torch.float32, device="cuda") for _ in range(nblk)]
+    for k in range(nblk):
+        gen.generate(iq[k], k * N, N)
+    st = torch.cuda.current_stream().cuda_stream
+    nf = []
+    for k in range(nblk):
+        nf.append(b.process_device(iq[k].data_ptr(), N, N, audio[k].data_ptr(), a_stride, st))
+        if k >= LAG:
+            b.wait(stream=st, lag=LAG)
+    b.wait(stream=st)
+    torch.cuda.synchronize()
+    check = [0, 1, 63, 64, 2047, 2048, 4094, 4095]
+    refs = {c: oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D, if_filter_order=order) for c in check}
+    for k in range(nblk):
+        a = audio[k][:, :nf[k]].cpu().numpy()
+        for c in check:
+            r = refs[c].process_stream(iq[k][c].cpu().numpy().reshape(-1))
+            assert _bits_equal(a[c], r), (k, c)
+        assert np.array_equal(a[:2048].view(np.uint32), a[2048:].view(np.uint32)), k
+    for c in check:
+        so, sg = refs[c].status(), b.status(c)
+        assert sg.stereo_detected == so.stereo
+        assert np.float32(sg.pilot_level) == np.float32(so.pilot_level)
+    b.close()

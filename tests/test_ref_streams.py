@@ -1,0 +1,114 @@
+"""What the REFERENCE BINARY returned (tests/golden/ref_streams.npz, written by
+`python tools/ref_crosscheck.py --emit ...` in the build container: the reference's own DSP sources,
+compiled there, driven over 13 generator streams / 503 calls) against
+
+  * the CPU oracle (`-m "not gpu"`): the restatement meets the reference's recorded outputs on every
+    CPU run, not only when somebody re-runs the cross-check tool;
+  * the HIP path through the C ABI (`-m gpu`): audio, getters, UECP frames and channel name straight
+    against the reference's records -- no oracle in between.
+
+The fixture is data: per call the SHA-256 of the audio block (ProcessStream's output,
+/root/reference/src/FmDecode.cpp:417-502), its length, the stereo flag and the four getters' bits
+(FmDecode.h:140-165); per stream the frames handed to AddUECPDataFrame and the last name handed to
+SetChannelName (RadioReceiver.h:77,115), the stream's definition and the SHA-256 of its generated IQ
+(generator drift would show there first).  By the task's rules it still pins nothing: the reference
+only compiles with four stand-in headers (tools/ref_crosscheck.py)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import ROOT, load_package
+
+FIXTURE = os.path.join(ROOT, "tests", "golden", "ref_streams.npz")
+
+
+def _streams():
+    z = np.load(FIXTURE)
+    n = len([k for k in z.files if k.endswith("_def")])
+    out = []
+    for i in range(n):
+        d = json.loads(str(z["s%02d_def" % i]))
+        lens = z["s%02d_frame_len" % i]
+        raw = z["s%02d_frames" % i].tobytes()
+        frames, at = [], 0
+        for l in lens:
+            frames.append(raw[at:at + int(l)])
+            at += int(l)
+        out.append((d, z["s%02d_audio_sha256" % i], z["s%02d_meta" % i], frames, str(z["s%02d_name" % i])))
+    return out
+
+
+STREAMS = _streams()
+IDS = [s[0]["name"].replace(" ", "_")[:48] for s in STREAMS]
+
+
+def _blocks(fmsig, d):
+    gen = dict(d["gen"])
+    mono = gen.pop("mono", False)
+    p = (fmsig.mono_params if mono else fmsig.default_params)(d["fs"], **{"noise_sigma": 0.01, **gen})
+    blocks, pos, sha = [], 0, hashlib.sha256()
+    for n in d["calls"]:
+        if n < 0:
+            blocks.append(None)
+        else:
+            b = fmsig.generate_f32(p, pos, n)
+            sha.update(np.ascontiguousarray(b, dtype=np.float32).tobytes())
+            blocks.append(b)
+            pos += n
+    assert sha.hexdigest() == d["iq_sha256"], "the signal generator no longer produces the fixture's input"
+    return blocks
+
+
+def _check_call(k, audio, stereo, getters, sha_ref, meta_ref):
+    assert audio.size == int(meta_ref[0]), (k, audio.size, int(meta_ref[0]))
+    got = np.frombuffer(hashlib.sha256(np.ascontiguousarray(audio, dtype=np.float32).tobytes()).digest(), np.uint8)
+    assert np.array_equal(got, sha_ref), "call %d: audio differs from the reference's" % k
+    assert int(stereo) == int(meta_ref[1]), k
+    # NaN meters (the reference divides by zero on blocks that leave a stage empty) compare as bits
+    assert np.array_equal(np.array(getters, np.float32).view(np.uint32), meta_ref[2:6]), (k, getters)
+
+
+@pytest.mark.parametrize("stream", STREAMS, ids=IDS)
+def test_oracle_reproduces_the_reference_records(oracle, fmsig, stream):
+    d, sha, meta, frames, name = stream
+    o = oracle.OracleDecoder(d["fs"], -0.15 * d["fs"], 48000.0, 15000.0, d["D"], us_version=bool(d["us"]))
+    for k, b in enumerate(_blocks(fmsig, d)):
+        if b is None:
+            o.reset()
+            a = np.zeros(0, np.float32)
+        else:
+            a = o.process_stream(b)
+        s = o.status()
+        _check_call(k, a, s.stereo, [s.tuning_offset, s.if_level, s.baseband_level, s.pilot_level], sha[k], meta[k])
+    assert o.uecp_frames() == frames
+    assert o.channel_name()[:8] == name[:8]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stream", STREAMS, ids=IDS)
+def test_hip_path_reproduces_the_reference_records(fmsig, stream):
+    pkg = load_package()
+    d, sha, meta, frames, name = stream
+    dec = pkg.FmDecoder(d["fs"], -0.15 * d["fs"], 48000.0, 15000.0, d["D"], bool(d["us"]))
+    smallest = min(n for n in d["calls"] if n >= 0)
+    probe = pkg.Batch(pkg.make_params(d["fs"], -0.15 * d["fs"], 48000.0, 15000.0, d["D"], bool(d["us"])), 1)
+    min_samples = probe.min_samples()
+    probe.close()
+    if smallest < min_samples:
+        # calls so short that a stage is left without a sample: the reference divides by zero in its
+        # meters there; the product refuses them, so the stream cannot be replayed
+        pytest.skip("calls of %d samples: below fmd_batch_min_samples() = %d" % (smallest, min_samples))
+    for k, b in enumerate(_blocks(fmsig, d)):
+        if b is None:
+            dec.Reset()
+            a = np.zeros(0, np.float32)
+        else:
+            a = dec.ProcessStream(b.view(np.complex64))
+        _check_call(k, a, dec.StereoDetected(),
+                    [dec.GetTuningOffset(), dec.GetInterfaceLevel(), dec.GetBasebandLevel(), dec.GetPilotLevel()],
+                    sha[k], meta[k])
+    assert dec.sink.frames.get(0, []) == frames
+    assert dec.sink.names.get(0, "")[:8] == name[:8]

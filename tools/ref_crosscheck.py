@@ -2,7 +2,7 @@
 """Cross-check of the CPU oracle (oracle/fmd_oracle.c) against the REFERENCE ITSELF -- build
 container only.
 
-    python tools/ref_crosscheck.py [--keep] [--quick]
+    python tools/ref_crosscheck.py [--keep] [--quick] [--emit tests/golden/ref_streams.npz]
 
 What it does, every time from scratch, in a temporary directory that is deleted afterwards:
   1. copies the six DSP sources of the reference's ProcessStream path (and the headers they include)
@@ -16,6 +16,12 @@ What it does, every time from scratch, in a temporary directory that is deleted 
      BIT FOR BIT: every audio block, the five getters after every call, every UECP frame handed to
      AddUECPDataFrame and the channel name handed to SetChannelName.
 
+--emit writes what the REFERENCE BINARY returned for every stream as a fixture (data only: per call the
+SHA-256 of the audio block, its length, the stereo flag and the four getters' bits; the UECP frames and
+the channel name; the stream's definition and the SHA-256 of its generated IQ).  tests/
+test_ref_streams.py compares the oracle (CPU suite) and the HIP path (GPU suite) with those records
+directly -- the HIP path meets the reference's own outputs without the oracle in between.
+
 What it is NOT: a pin of the oracle in the sense of the task's rules.  A reference build that needs
 stand-in headers counts as unbuildable there, and DESIGN.md keeps saying "parity unpinned beyond SURVEY
 8(c)'s recorded outputs".  This tool makes the claim "the restatement is faithful" something anybody
@@ -24,6 +30,8 @@ never copies reference text into the repository, nothing of it travels to the GP
 /root/reference there; the tool exits with a message), and no test imports it.
 """
 import argparse
+import hashlib
+import json
 import os
 import shutil
 import struct
@@ -177,7 +185,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--keep", action="store_true", help="keep the temporary directory (prints its path)")
     ap.add_argument("--quick", action="store_true", help="a fifth of every stream")
+    ap.add_argument("--emit", metavar="NPZ", help="write the reference binary's outputs as a fixture")
     args = ap.parse_args()
+    emit = {}
     if not os.path.isdir(REF):
         print("ref_crosscheck: %s does not exist -- this tool only runs in the build container" % REF)
         return 2
@@ -217,6 +227,11 @@ def main():
             raw = open(fout, "rb").read()
             o = oracle_py.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D, us_version=bool(us))
             at, nbad = 0, 0
+            rec_sha, rec_meta = [], []
+            iq_sha = hashlib.sha256()
+            for b in blocks:
+                if b is not None:
+                    iq_sha.update(np.ascontiguousarray(b, dtype=np.float32).tobytes())
             for k, (n, b) in enumerate(zip(calls, blocks)):
                 (nf,) = struct.unpack_from("<I", raw, at)
                 at += 4
@@ -225,6 +240,8 @@ def main():
                 st_ref = struct.unpack_from("<i", raw, at)[0]
                 g_ref = np.frombuffer(raw, dtype=np.uint32, count=4, offset=at + 4)
                 at += 20
+                rec_sha.append(np.frombuffer(hashlib.sha256(a_ref.tobytes()).digest(), dtype=np.uint8))
+                rec_meta.append([nf, st_ref & 0xffffffff] + [int(x) for x in g_ref])
                 if b is None:
                     o.reset()
                     a_o = np.zeros(0, np.float32)
@@ -255,6 +272,16 @@ def main():
                 (l,) = struct.unpack_from("<I", raw, at)
                 names.append(raw[at + 4:at + 4 + l].decode("latin1"))
                 at += 4 + l
+            if args.emit:
+                i = len(emit) // 6
+                emit["s%02d_def" % i] = np.array(json.dumps(
+                    {"name": name, "fs": fs, "D": D, "us": us, "gen": dict(kw, mono=mono), "calls": calls,
+                     "iq_sha256": iq_sha.hexdigest()}))
+                emit["s%02d_audio_sha256" % i] = np.stack(rec_sha)
+                emit["s%02d_meta" % i] = np.array(rec_meta, dtype=np.uint32)  # nfloats, stereo, 4 getters' bits
+                emit["s%02d_frames" % i] = np.frombuffer(b"".join(fr_ref), dtype=np.uint8)
+                emit["s%02d_frame_len" % i] = np.array([len(f) for f in fr_ref], dtype=np.uint32)
+                emit["s%02d_name" % i] = np.array(names[-1] if names else "")
             fr_o = o.uecp_frames()
             frames_ok = fr_o == fr_ref
             name_ok = (names[-1][:8] if names else "") == o.channel_name()[:8]
@@ -264,6 +291,9 @@ def main():
                 "equal" if name_ok else "DIFFERS (oracle %r)" % o.channel_name()))
             bad += nbad + (not frames_ok) + (not name_ok)
         print("ref_crosscheck: %s" % ("oracle == reference on every stream" if not bad else "%d MISMATCHES" % bad))
+        if args.emit and not args.quick:
+            np.savez_compressed(args.emit, **emit)
+            print("wrote %s (%d streams)" % (args.emit, len(emit) // 6))
         return 1 if bad else 0
     finally:
         if args.keep:
