@@ -375,10 +375,20 @@ def main():
     g_audio = g_rds = None
     if rank == 0 and (dist_on or args.verify):
         on = dev if (backend == "nccl" or not dist_on) else "cpu"
-        g_audio = [[torch.empty((C, a_stride), dtype=torch.float32, device=on) for _ in range(world)]
-                   for _ in range(NBUF)]
-        g_rds = [[torch.empty((RCAP, 4), dtype=torch.int32, device=on) for _ in range(world)]
-                 for _ in range(NBUF)]
+        # one tensor per slot, [world][...]: g_audio[slot][r] is rank r's part (the C++ gather writes at
+        # rank * size; torch.distributed.gather takes the list of the parts)
+        g_audio = [torch.empty((world, C, a_stride), dtype=torch.float32, device=on) for _ in range(NBUF)]
+        g_rds = [torch.empty((world, RCAP, 4), dtype=torch.int32, device=on) for _ in range(NBUF)]
+    # RCCL: the data path is the C++ gather of include/fmd_gather.h (grouped ncclSend / ncclRecv on a
+    # stream of its own); its communicator's id travels over the torch.distributed rendezvous
+    gth = None
+    if dist_on and backend == "nccl":
+        gmod = importlib.import_module(pkg.__name__ + ".gather")
+        uid = torch.zeros(gmod.ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(gmod.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        gth = gmod.Gather(bytes(uid.cpu().numpy().tobytes()), rank, world, local_rank, C * a_stride, RCAP)
     group_acc = torch.zeros((), dtype=torch.int64, device=dev)  # groups counted on the device
     stream = torch.cuda.current_stream().cuda_stream
     pending = [None] * NBUF
@@ -401,38 +411,27 @@ def main():
         RDS records are gathered to rank 0 over RCCL on the side stream (overlapping the next steps'
         compute); rank 0 counts the groups that arrived."""
         slot = i % NBUF
-        if use_export:
+        if gth is not None:
+            # export of the RDS records (on the torch stream) + the step's sends / receives (on the
+            # library's stream, behind the torch stream as it stands now): one C call
+            pending[slot] = ("ticket", gth.step(batch, lag, rank * C, audio[slot].data_ptr(), rds_dev[slot].data_ptr(),
+                                                g_audio[slot].data_ptr() if rank == 0 else None,
+                                                g_rds[slot].data_ptr() if rank == 0 else None, stream))
+        elif use_export:
             batch.export_rds_device(rds_dev[slot].data_ptr(), RCAP, channel_offset=rank * C,
                                     stream=stream, lag=lag)
-        if dist_on:
+        if dist_on and gth is None:
             ev = torch.cuda.Event()
             ev.record()
-            if backend == "nccl":
-                with torch.cuda.stream(comm_stream):
-                    comm_stream.wait_event(ev)
-                    g0 = torch.cuda.Event(enable_timing=True)
-                    g0.record(comm_stream)
-                    # blocking for the side stream only: the host does not wait
-                    dg.gather_step(audio[slot], rds_dev[slot], g_audio[slot] if rank == 0 else None,
-                                   g_rds[slot] if rank == 0 else None, dst=0, async_op=False)
-                    g1 = torch.cuda.Event(enable_timing=True)
-                    g1.record(comm_stream)
-                    gather_events.append((g0, g1))  # the two gather calls alone, on the side stream
-                    if rank == 0:
-                        for r in range(world):
-                            group_acc.add_((g_rds[slot][r][:, 0] != 0).sum())
-                    done = torch.cuda.Event()
-                    done.record(comm_stream)
-                pending[slot] = done
-            else:  # host-staged over gloo (development aid: several ranks on one GPU)
+            if True:  # host-staged over gloo (development aid: several ranks on one GPU)
                 tg0 = time.perf_counter()
                 ev.synchronize()
                 a_h, r_h = audio[slot].cpu(), rds_dev[slot].cpu()
-                w = dg.gather_step(a_h, r_h, g_audio[slot] if rank == 0 else None,
-                                   g_rds[slot] if rank == 0 else None, dst=0, async_op=True)
+                w = dg.gather_step(a_h, r_h, list(g_audio[slot]) if rank == 0 else None,
+                                   list(g_rds[slot]) if rank == 0 else None, dst=0, async_op=True)
                 pending[slot] = list(w)
                 host_t["gather_host"] = host_t.get("gather_host", 0.0) + (time.perf_counter() - tg0)
-        elif use_export:  # one rank, --verify: "gathered" = this rank's own outputs
+        elif use_export and gth is None:  # one rank, --verify: "gathered" = this rank's own outputs
             g_audio[slot][0].copy_(audio[slot], non_blocking=True)
             g_rds[slot][0].copy_(rds_dev[slot], non_blocking=True)
             group_acc.add_((rds_dev[slot][:, 0] != 0).sum())
@@ -442,11 +441,15 @@ def main():
         """Before a slot's buffers are written again: its gather must have read them."""
         if pending[slot] is None:
             return
-        if isinstance(pending[slot], list):
+        if isinstance(pending[slot], tuple):  # the C++ gather: order the torch stream behind that step
+            gth.wait_for(pending[slot][1], stream)
+            if rank == 0:
+                group_acc.add_((g_rds[slot][:, :, 0] != 0).sum())
+        elif isinstance(pending[slot], list):
             for w in pending[slot]:
                 w.wait()
             if rank == 0:
-                group_acc.add_(int(sum((t[:, 0] != 0).sum() for t in g_rds[slot])))
+                group_acc.add_(int((g_rds[slot][:, :, 0] != 0).sum()))
         else:
             torch.cuda.current_stream().wait_event(pending[slot])  # device-side wait
         pending[slot] = None
@@ -574,6 +577,8 @@ def main():
     drain()
     host_t["process"] = host_t["collect"] = host_t["wait"] = host_t["gather_host"] = 0.0
     gather_events.clear()
+    if gth is not None:
+        gth.ms_per_step()  # forget the warm-up's
     batch.set_profiling(1)  # HIP events around the IF FIR kernel of every timed call
     total_groups = 0
     group_acc.zero_()
@@ -645,7 +650,9 @@ def main():
     # what makes an N > 1 run explain itself: every rank's own time per step and FIR time, and what the
     # gather costs on the side stream (on rank 0: receiving from every peer; elsewhere: sending)
     gather_ms = None
-    if gather_events:
+    if gth is not None:
+        gather_ms = gth.ms_per_step()
+    elif gather_events:
         torch.cuda.synchronize()
         gather_ms = sum(a.elapsed_time(b) for a, b in gather_events) / len(gather_events)
     elif host_t.get("gather_host"):
@@ -709,7 +716,8 @@ def main():
                        "channels_per_gpu": C, "samples_per_call": N, "input_ring_blocks": ring,
                        "audio_floats_per_channel_step": nf, "rds_groups_in_timed_region": total_groups,
                        "gather": ("rank-0 gather of audio + RDS records per step over %s (%d rank%s)"
-                                  % ("RCCL" if backend == "nccl" else backend, world, "" if world == 1 else "s"))
+                                  % ("RCCL, grouped ncclSend / ncclRecv from C++ (include/fmd_gather.h)"
+                                     if backend == "nccl" else backend, world, "" if world == 1 else "s"))
                        if dist_on else "none (1 GPU)",
                        "host_ms_per_step": {"submit": round(host_ms["process"], 3),
                                             "wait": round(host_ms.get("wait", 0.0), 3),

@@ -1,0 +1,74 @@
+/*
+ * fmd_gather.h -- C ABI of the whole-node step: one process per GPU, every rank decodes its own
+ * channels (include/fmd.h, no exchange during compute) and rank 0 receives every rank's float audio
+ * and RDS group records once per step over RCCL (xGMI).  libfmd_gather.so = this + librccl; a
+ * single-GPU user of libfmd_hip.so never loads it.
+ *
+ * The reference has no counterpart: cRadioReceiver decodes one station on one CPU thread
+ * (/root/reference/src/RadioReceiver.cpp:515-538).  What is gathered is what its DemuxRead hands on
+ * per channel: the interleaved float audio of a ProcessStream call (FmDecode.cpp:473-501) and the
+ * RDS groups the signal processor found in it (RDSProcess.cpp:312,355).
+ *
+ * RCCL has no gather: a step is one group of ncclSend (every rank, its two buffers) / ncclRecv (rank 0,
+ * two per rank), so that each peer uses its own xGMI link to rank 0.  It runs on a stream of the
+ * library's own, behind an event on the caller's stream, and overlaps the next steps' compute; the
+ * caller orders a stream behind it (fmd_gather_wait) before it reuses the buffers.
+ */
+#ifndef FMD_GATHER_H
+#define FMD_GATHER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "fmd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMD_GATHER_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+
+typedef struct fmd_gather fmd_gather;
+
+/* Message of the last failed fmd_gather_* call on this thread. */
+const char* fmd_gather_last_error(void);
+
+/* Rank 0 makes the communicator's id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by
+ * whatever means the job has (a file, an environment variable, MPI, a torch store). */
+int fmd_gather_unique_id(uint8_t id[FMD_GATHER_ID_BYTES]);
+
+/* Collective over all `world` ranks (ncclCommInitRank).  audio_floats / rds_rows: size of one rank's
+ * message per step -- [channels][audio_stride] floats and rds_rows x 4 int32 records
+ * (fmd_batch_export_rds_device's rows) -- the same on every rank. */
+int fmd_gather_create(const uint8_t id[FMD_GATHER_ID_BYTES], int rank, int world, int device,
+                      size_t audio_floats, unsigned rds_rows, fmd_gather** out);
+void fmd_gather_destroy(fmd_gather* g);
+
+/* One step's outputs on their way to rank 0.  The RDS groups of every call of `batch` at least `lag`
+ * calls old are first drained into d_rds as records (fmd_batch_export_rds_device, channel numbers
+ * offset by channel_offset, on `stream`); then, behind everything `stream` has been given so far
+ * (the caller has ordered it behind the calls whose audio is in d_audio: fmd_batch_wait_lagged), the
+ * library's own stream sends d_audio and d_rds; rank 0 receives rank r's into
+ * d_all_audio + r * audio_floats and d_all_rds + r * rds_rows * 4 (its own by a device copy).  Returns
+ * at once; FMD_WARN_RDS_LOST like the export.  batch may be NULL (d_rds is sent as it is). */
+int fmd_gather_step(fmd_gather* g, fmd_batch* batch, int lag, unsigned channel_offset, const float* d_audio,
+                    int32_t* d_rds, float* d_all_audio, int32_t* d_all_rds, void* stream);
+
+/* Orders `stream` behind every step issued so far (before d_audio / d_rds / the receive buffers are
+ * written again or read); _lagged: behind all but the `lag` (< 16) youngest -- a caller that rotates
+ * its buffers waits only for the step that last used the one it is about to write. */
+int fmd_gather_wait(fmd_gather* g, void* stream);
+int fmd_gather_wait_lagged(fmd_gather* g, unsigned lag, void* stream);
+
+/* All ranks meet (an all-reduce of one word on the communicator's stream, then a host wait): the
+ * barrier around a timed region.  *max_value = the largest `value` over the ranks (may be NULL). */
+int fmd_gather_barrier(fmd_gather* g, double value, double* max_value);
+
+/* Mean duration of a step's send / receive group on the library's stream, in ms, over the steps issued
+ * since the last call (device events); < 0 when there was none.  Synchronises that stream. */
+float fmd_gather_ms_per_step(fmd_gather* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

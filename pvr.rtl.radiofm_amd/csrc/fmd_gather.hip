@@ -1,0 +1,242 @@
+/*
+ * fmd_gather.hip -- rank-0 gather of float audio and RDS records over RCCL (include/fmd_gather.h).
+ * Host code only (no kernel of its own); its own library so that libfmd_hip.so does not need RCCL.
+ *
+ * Build: hipcc --offload-arch=gfx950 -O2 -fPIC -shared fmd_gather.hip -o libfmd_gather.so
+ *        -L.. -lfmd_hip -lrccl
+ */
+#include "../../include/fmd_gather.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace
+{
+
+thread_local std::string g_gerr;
+
+int gfail(int code, const std::string& msg)
+{
+  g_gerr = msg;
+  return code;
+}
+
+#define GHIP(expr)                                                                              \
+  do                                                                                            \
+  {                                                                                             \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return gfail(FMD_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+#define GNCCL(expr)                                                                             \
+  do                                                                                            \
+  {                                                                                             \
+    ncclResult_t r_ = (expr);                                                                   \
+    if (r_ != ncclSuccess)                                                                      \
+      return gfail(FMD_ERR_DEVICE, std::string(#expr) + ": " + ncclGetErrorString(r_));         \
+  } while (0)
+
+static_assert(sizeof(ncclUniqueId) == FMD_GATHER_ID_BYTES, "ncclUniqueId size");
+
+} // namespace
+
+struct fmd_gather
+{
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  size_t audio_floats = 0;
+  unsigned rds_rows = 0;
+  hipStream_t side = nullptr;      // the gathers' own stream: they overlap the next steps' compute
+  hipEvent_t ready = nullptr;      // caller's stream -> side
+  static constexpr unsigned kRing = 16;
+  hipEvent_t done[kRing] = {};     // side -> whoever reuses the buffers, one per step in flight
+  uint64_t issued = 0;
+  std::vector<hipEvent_t> t0, t1;  // timing of the steps since the last query
+  size_t timed = 0;
+  double* d_word = nullptr;        // the barrier's all-reduce
+};
+
+extern "C" {
+
+const char* fmd_gather_last_error(void)
+{
+  return g_gerr.c_str();
+}
+
+int fmd_gather_unique_id(uint8_t id[FMD_GATHER_ID_BYTES])
+{
+  if (!id)
+    return gfail(FMD_ERR_ARG, "null id");
+  ncclUniqueId u;
+  GNCCL(ncclGetUniqueId(&u));
+  std::memcpy(id, &u, sizeof u);
+  return FMD_OK;
+}
+
+int fmd_gather_create(const uint8_t id[FMD_GATHER_ID_BYTES], int rank, int world, int device,
+                      size_t audio_floats, unsigned rds_rows, fmd_gather** out)
+{
+  if (!id || !out || world < 1 || rank < 0 || rank >= world || audio_floats == 0 || rds_rows == 0)
+    return gfail(FMD_ERR_ARG, "fmd_gather_create: bad argument");
+  *out = nullptr;
+  GHIP(hipSetDevice(device));
+  fmd_gather* g = new fmd_gather;
+  g->rank = rank;
+  g->world = world;
+  g->device = device;
+  g->audio_floats = audio_floats;
+  g->rds_rows = rds_rows;
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  ncclResult_t r = ncclCommInitRank(&g->comm, world, u, rank);
+  if (r != ncclSuccess)
+  {
+    delete g;
+    return gfail(FMD_ERR_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  }
+  if (hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&g->ready, hipEventDisableTiming) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&g->d_word), 2 * sizeof(double)) != hipSuccess)
+  {
+    fmd_gather_destroy(g);
+    return gfail(FMD_ERR_DEVICE, "fmd_gather_create: stream / event / buffer creation failed");
+  }
+  for (auto& e : g->done)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+    {
+      fmd_gather_destroy(g);
+      return gfail(FMD_ERR_DEVICE, "fmd_gather_create: event creation failed");
+    }
+  *out = g;
+  return FMD_OK;
+}
+
+void fmd_gather_destroy(fmd_gather* g)
+{
+  if (!g)
+    return;
+  (void)hipSetDevice(g->device);
+  if (g->side)
+    (void)hipStreamSynchronize(g->side);
+  if (g->comm)
+    (void)ncclCommDestroy(g->comm);
+  for (auto e : g->t0)
+    (void)hipEventDestroy(e);
+  for (auto e : g->t1)
+    (void)hipEventDestroy(e);
+  if (g->ready)
+    (void)hipEventDestroy(g->ready);
+  for (auto e : g->done)
+    if (e)
+      (void)hipEventDestroy(e);
+  if (g->side)
+    (void)hipStreamDestroy(g->side);
+  if (g->d_word)
+    (void)hipFree(g->d_word);
+  delete g;
+}
+
+int fmd_gather_step(fmd_gather* g, fmd_batch* batch, int lag, unsigned channel_offset, const float* d_audio,
+                    int32_t* d_rds, float* d_all_audio, int32_t* d_all_rds, void* stream_)
+{
+  if (!g || !d_audio || !d_rds || (g->rank == 0 && (!d_all_audio || !d_all_rds)))
+    return gfail(FMD_ERR_ARG, "fmd_gather_step: null buffer");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GHIP(hipSetDevice(g->device));
+  int warn = FMD_OK;
+  if (batch)
+  {
+    const int rc = fmd_batch_export_rds_device(batch, d_rds, g->rds_rows, channel_offset, lag, stream);
+    if (rc < 0)
+      return gfail(rc, std::string("fmd_batch_export_rds_device: ") + fmd_last_error());
+    warn = rc;
+  }
+  GHIP(hipEventRecord(g->ready, stream));
+  GHIP(hipStreamWaitEvent(g->side, g->ready, 0));
+  if (g->timed == g->t0.size())
+  {
+    hipEvent_t a, b;
+    GHIP(hipEventCreate(&a));
+    GHIP(hipEventCreate(&b));
+    g->t0.push_back(a);
+    g->t1.push_back(b);
+  }
+  GHIP(hipEventRecord(g->t0[g->timed], g->side));
+  const size_t rds_ints = size_t(g->rds_rows) * 4;
+  GNCCL(ncclGroupStart());
+  if (g->rank != 0)
+  {
+    GNCCL(ncclSend(d_audio, g->audio_floats, ncclFloat, 0, g->comm, g->side));
+    GNCCL(ncclSend(d_rds, rds_ints, ncclInt32, 0, g->comm, g->side));
+  }
+  else
+    for (int r = 1; r < g->world; r++)
+    {
+      GNCCL(ncclRecv(d_all_audio + size_t(r) * g->audio_floats, g->audio_floats, ncclFloat, r, g->comm, g->side));
+      GNCCL(ncclRecv(d_all_rds + size_t(r) * rds_ints, rds_ints, ncclInt32, r, g->comm, g->side));
+    }
+  GNCCL(ncclGroupEnd());
+  if (g->rank == 0)
+  { // rank 0's own outputs: a device copy, on the same stream
+    GHIP(hipMemcpyAsync(d_all_audio, d_audio, g->audio_floats * sizeof(float), hipMemcpyDeviceToDevice, g->side));
+    GHIP(hipMemcpyAsync(d_all_rds, d_rds, rds_ints * sizeof(int32_t), hipMemcpyDeviceToDevice, g->side));
+  }
+  GHIP(hipEventRecord(g->t1[g->timed], g->side));
+  g->timed++;
+  GHIP(hipEventRecord(g->done[g->issued % fmd_gather::kRing], g->side));
+  g->issued++;
+  return warn;
+}
+
+int fmd_gather_wait_lagged(fmd_gather* g, unsigned lag, void* stream_)
+{
+  if (!g || lag >= fmd_gather::kRing)
+    return gfail(FMD_ERR_ARG, "fmd_gather_wait: null gather or lag >= 16");
+  if (g->issued > lag) // the steps complete in order on the library's stream: the youngest one waited for covers the rest
+    GHIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream_), g->done[(g->issued - 1 - lag) % fmd_gather::kRing], 0));
+  return FMD_OK;
+}
+
+int fmd_gather_wait(fmd_gather* g, void* stream_)
+{
+  return fmd_gather_wait_lagged(g, 0, stream_);
+}
+
+int fmd_gather_barrier(fmd_gather* g, double value, double* max_value)
+{
+  if (!g)
+    return gfail(FMD_ERR_ARG, "null gather");
+  GHIP(hipSetDevice(g->device));
+  GHIP(hipMemcpyAsync(g->d_word, &value, sizeof(double), hipMemcpyHostToDevice, g->side));
+  GNCCL(ncclAllReduce(g->d_word, g->d_word + 1, 1, ncclDouble, ncclMax, g->comm, g->side));
+  double m = value;
+  GHIP(hipMemcpyAsync(&m, g->d_word + 1, sizeof(double), hipMemcpyDeviceToHost, g->side));
+  GHIP(hipStreamSynchronize(g->side));
+  if (max_value)
+    *max_value = m;
+  return FMD_OK;
+}
+
+float fmd_gather_ms_per_step(fmd_gather* g)
+{
+  if (!g || g->timed == 0)
+    return -1.0f;
+  if (hipStreamSynchronize(g->side) != hipSuccess)
+    return -1.0f;
+  double sum = 0.0;
+  for (size_t i = 0; i < g->timed; i++)
+  {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, g->t0[i], g->t1[i]) == hipSuccess)
+      sum += ms;
+  }
+  const float mean = float(sum / double(g->timed));
+  g->timed = 0;
+  return mean;
+}
+
+} // extern "C"

@@ -1,0 +1,93 @@
+"""ctypes binding of libfmd_gather.so (include/fmd_gather.h): the rank-0 gather of float audio and RDS
+records over RCCL, written in C++ (csrc/fmd_gather.hip).  bench.py uses it for the data path when the
+backend is RCCL; torch.distributed stays for the rendezvous (it carries the communicator's id)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfmd_gather.so")
+ID_BYTES = 128
+EXPORTS = ["fmd_gather_last_error", "fmd_gather_unique_id", "fmd_gather_create", "fmd_gather_destroy",
+           "fmd_gather_step", "fmd_gather_wait", "fmd_gather_wait_lagged", "fmd_gather_barrier",
+           "fmd_gather_ms_per_step"]
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libfmd_gather.so is not built (run __graft_entry__.build())")
+        import torch  # noqa: F401  (its HIP runtime and RCCL first: one of each per process)
+        L = C.CDLL(LIB_PATH)
+        vp, u, i = C.c_void_p, C.c_uint, C.c_int
+        L.fmd_gather_last_error.restype = C.c_char_p
+        L.fmd_gather_unique_id.argtypes = [vp]
+        L.fmd_gather_create.argtypes = [vp, i, i, i, C.c_size_t, u, C.POINTER(vp)]
+        L.fmd_gather_destroy.argtypes = [vp]
+        L.fmd_gather_step.argtypes = [vp, vp, i, u, vp, vp, vp, vp, vp]
+        L.fmd_gather_wait.argtypes = [vp, vp]
+        L.fmd_gather_wait_lagged.argtypes = [vp, u, vp]
+        L.fmd_gather_barrier.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
+        L.fmd_gather_ms_per_step.restype = C.c_float
+        L.fmd_gather_ms_per_step.argtypes = [vp]
+        _LIB = L
+    return _LIB
+
+
+class GatherError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc < 0:
+        raise GatherError("fmd_gather error %d: %s" % (rc, lib().fmd_gather_last_error().decode()))
+    return rc
+
+
+def unique_id():
+    """bytes(128), on rank 0 (ncclGetUniqueId)."""
+    buf = (C.c_uint8 * ID_BYTES)()
+    _check(lib().fmd_gather_unique_id(buf))
+    return bytes(buf)
+
+
+class Gather:
+    def __init__(self, uid, rank, world, device, audio_floats, rds_rows):
+        h = C.c_void_p()
+        buf = (C.c_uint8 * ID_BYTES).from_buffer_copy(uid)
+        _check(lib().fmd_gather_create(buf, rank, world, device, audio_floats, rds_rows, C.byref(h)))
+        self._h = h
+        self.issued = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().fmd_gather_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def step(self, batch, lag, channel_offset, d_audio, d_rds, d_all_audio, d_all_rds, stream):
+        """Returns the step's ticket (for wait_for)."""
+        _check(lib().fmd_gather_step(self._h, batch._h if batch is not None else None, lag, channel_offset,
+                                     d_audio, d_rds, d_all_audio, d_all_rds, stream))
+        self.issued += 1
+        return self.issued - 1
+
+    def wait_for(self, ticket, stream):
+        """Orders `stream` behind the step with this ticket (steps complete in order)."""
+        lag = self.issued - 1 - ticket
+        _check(lib().fmd_gather_wait_lagged(self._h, max(0, min(lag, 15)), stream))
+
+    def wait(self, stream):
+        _check(lib().fmd_gather_wait(self._h, stream))
+
+    def barrier(self, value=0.0):
+        m = C.c_double()
+        _check(lib().fmd_gather_barrier(self._h, value, C.byref(m)))
+        return m.value
+
+    def ms_per_step(self):
+        v = lib().fmd_gather_ms_per_step(self._h)
+        return None if v < 0 else float(v)

@@ -36,6 +36,22 @@ def test_every_declared_symbol_is_exported(pkg):
     assert set(pkg.EXPORTS) <= declared
 
 
+def test_gather_library_exports_what_its_header_declares(pkg):
+    """libfmd_gather.so (the whole-node step: rank-0 gather over RCCL, C++ above the two C ABIs) loads
+    beside torch's RCCL and exports every symbol include/fmd_gather.h declares; no call is made (no
+    communicator without a GPU)."""
+    import importlib
+    g = importlib.import_module(pkg.__name__ + ".gather")
+    hdr = open(os.path.join(ROOT, "include", "fmd_gather.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fmd_gather_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 8
+    lib = g.lib()
+    assert not [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert set(g.EXPORTS) == declared
+    assert os.path.exists(os.path.join(ROOT, "tools", "node_bench"))  # built by __graft_entry__.build()
+
+
 def test_no_gpu_fails_loudly(pkg):
     import torch
     if torch.cuda.is_available():

@@ -120,3 +120,14 @@ def test_full_size_verify_of_the_other_configs(workload, steps):
     C = 4096 if workload == "config5" else 256
     assert d["config"]["channels_per_gpu"] == C
     assert d["verify"]["channels_per_rank"] == sorted({0, 1, C // 2, C - 1})
+
+
+def test_node_bench_cpp_world_of_one():
+    """tools/node_bench: the timed loop of a rank in C++ (no Python in the process), here with a world of
+    one -- the RCCL communicator is created from the id file, every step goes through fmd_gather_step."""
+    out = subprocess.run([os.path.join(ROOT, "tools", "node_bench"), "--gpus", "1", "--steps", "12", "--warmup", "4",
+                          "--channels", "2048"], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["audio_floats_per_channel_step"] in (2620, 2622)
+    assert d["config"]["gather_ms_per_step_rank0"] > 0
