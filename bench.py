@@ -199,6 +199,73 @@ def _spawn_ranks(n):
     raise SystemExit(0)
 
 
+def config2(args):
+    """BASELINE configs[1]: 1 stereo FM channel + RDS, 2.4 MS/s, through the drop-in surface -- the call the
+    reference's demux thread makes (cFmDecoder::ProcessStream, /root/reference/src/RadioReceiver.cpp:515-538):
+    host IQ block in, float audio out, UECP frames through the callbacks, synchronous.  `value` = IQ samples
+    per second of wall time over K calls; the JSON line also says where a call's time goes (host side:
+    fmd_batch_debug_host_ms; device side: per-stage events of 24 extra calls) and what one CPU core does on
+    the same blocks.  A single channel is ONE lane of work for the two serial recurrences (FM PLL, pilot PLL):
+    the floor of a call is the serial stage's 5958 samples x ~107 issue slots x 4.1 cycles = 1.1 ms."""
+    import torch  # noqa: F401
+    from __graft_entry__ import load_package
+    from tools import fmsig_py
+    pkg = load_package()
+    K, W = max(args.steps, 220), args.warmup
+    p = fmsig_py.default_params(FS, noise_sigma=0.005)
+    nblk = 32
+    blocks = [fmsig_py.generate_f32(p, b * N, N).view(np.complex64) for b in range(nblk)]
+    dec = pkg.FmDecoder(FS, -0.15 * FS, 48000.0, 15000.0, D)
+    view = dec.batch_view()
+    for kv in args.debug_set:
+        key, _, val = kv.partition("=")
+        view.debug_set(key, int(val))
+    for i in range(W):
+        dec.ProcessStream(blocks[i % nblk])
+    view.debug_host_ms()
+    lat = []
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        t1 = time.perf_counter()
+        a = dec.ProcessStream(blocks[i % nblk])
+        lat.append(time.perf_counter() - t1)
+    dt = time.perf_counter() - t0
+    ncalls, host = view.debug_host_ms()
+    lat = np.array(lat) * 1e3
+    view.set_profiling(2)  # events between the stages (everything on one stream, which a single call is anyway)
+    for i in range(24):
+        dec.ProcessStream(blocks[i % nblk])
+    stage, calls = view.stage_ms()
+    view.set_profiling(0)
+    stereo, frames = dec.StereoDetected(), len(dec.sink.frames.get(0, []))
+    out = {
+        "metric": "IQ MS/s demodulated, one decoder through cFmDecoder::ProcessStream (host buffers)",
+        "value": round(N * K / dt / 1e6, 2), "unit": "MS/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: 1 stereo FM channel + RDS @2.4 MS/s, 65536 IQ per call, "
+                               "fmd_process_stream (host IQ in, host audio out, UECP callbacks), %d calls" % K,
+                   "stereo_detected": bool(stereo), "uecp_frames": frames,
+                   "debug_set": args.debug_set},
+        "latency_ms": {"mean": round(float(lat.mean()), 4), "p50": round(float(np.percentile(lat, 50)), 4),
+                       "p99": round(float(np.percentile(lat, 99)), 4), "max": round(float(lat.max()), 4),
+                       "host_side_mean": {k: round(v, 4) for k, v in host.items()},
+                       "host_side_note": "copy_in: IQ block to the device; submit: the call's ~25 launches; "
+                                         "wait_copy_out: waiting for them + audio back; rds_callbacks: group "
+                                         "collection + UECP group decoder",
+                       "device_stage_ms": {k: round(v, 4) for k, v in stage.items() if v >= 0},
+                       "device_stage_calls": calls,
+                       "floor": "serial stage: 5958 baseband samples x 106.5 issue slots x 4.1 cycles at 2.39 GHz "
+                                "= 1.09 ms for the FM wave alone (one channel = one lane of a strictly serial "
+                                "recurrence)"},
+    }
+    if not args.no_cpu_baseline:
+        cb = cpu_baseline(seconds=4.0)
+        out["cpu_baseline"] = cb
+        out["cpu_baseline"]["note"] = "per_core (one thread, one channel) is the figure that compares with `value`"
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,8 +276,10 @@ def main():
     ap.add_argument("--channels", type=int, default=8192, help="channels per GPU")
     ap.add_argument("--ring", type=int, default=10, help="distinct input blocks resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config5"],
+    ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config5", "config2"],
                     help="config4 (default, the metric's workload): independent channels @2.4 MS/s; "
+                         "config2: ONE stereo+RDS decoder through the cFmDecoder surface (fmd_process_stream, host "
+                         "buffers in and out, callbacks): per-call latency and where it goes; "
                          "config3: 256 channels from ONE shared capture (table_size 256); "
                          "config5: 4096-tap IF FIR @10 MS/s, D=46, 4096 channels")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"],
@@ -246,6 +315,8 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.workload == "config2":
+        return config2(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _spawn_ranks(args.gpus)  # does not return
     if os.environ.get("FMD_BENCH_TEST_HANG") == "1" and os.environ.get("FMD_BENCH_SPAWNED") == "1":

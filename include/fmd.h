@@ -129,6 +129,10 @@ int fmd_process_stream(fmd_decoder* d, const float* iq, unsigned samples, float*
  * fmd_process_stream on the converted block; the transfer and the HBM read are 4x smaller. */
 int fmd_process_stream_u8(fmd_decoder* d, const uint8_t* buf, unsigned samples, float* audio);
 int fmd_get_status(fmd_decoder* d, fmd_status* st);
+/* The one-channel batch behind a decoder: for the profiling / development calls below (fmd_batch_set_
+ * profiling, fmd_batch_get_stage_ms, fmd_batch_debug_*); not for processing (the decoder owns it). */
+struct fmd_batch;
+struct fmd_batch* fmd_decoder_batch(fmd_decoder* d);
 
 /* ---- batch of independent channels on one GPU -------------------------------------- */
 typedef struct fmd_batch fmd_batch;
@@ -321,6 +325,11 @@ int fmd_batch_debug_set_spin_limit(fmd_batch* b, unsigned limit);
  * library decides, 0 window per wave (k_resample), 1 LDS ring (k_resample_ring) wherever the
  * geometry allows it; ...). */
 int fmd_batch_debug_set(fmd_batch* b, const char* key, int value);
+/* Where the time of the host-buffer calls (fmd_batch_process_host*, fmd_process_stream*) went since the
+ * last query, mean ms per call: out[0] copy of the IQ block to the device, [1] submission of the call's
+ * kernels, [2] waiting for them + copy of the audio back, [3] collection of the RDS groups + UECP group
+ * decoder callbacks.  Returns the number of calls averaged. */
+int fmd_batch_debug_host_ms(fmd_batch* b, float out[4]);
 
 const char* fmd_last_error(void);
 const char* fmd_version(void);

@@ -113,6 +113,7 @@ EXPORTS = [
     "fmd_group_decoder_reset", "fmd_group_decoder_push", "fmd_uecp_stuff_frame",
     "fmd_batch_take_rds_lost", "fmd_batch_status_call_index",
     "fmd_batch_debug_set_spin_limit", "fmd_batch_debug_timeline", "fmd_batch_debug_set",
+    "fmd_batch_debug_host_ms", "fmd_decoder_batch",
 ]
 
 
@@ -202,6 +203,9 @@ def lib():
         L.fmd_batch_debug_set_spin_limit.argtypes = [vp, u]
         L.fmd_batch_debug_timeline.argtypes = [vp, vp, u]
         L.fmd_batch_debug_set.argtypes = [vp, C.c_char_p, i]
+        L.fmd_batch_debug_host_ms.argtypes = [vp, vp]
+        L.fmd_decoder_batch.restype = vp
+        L.fmd_decoder_batch.argtypes = [vp]
         _LIB = L
     return _LIB
 
@@ -378,6 +382,13 @@ class Batch:
         """Development switch of this batch by name (fmd_batch_debug_set)."""
         _check(lib().fmd_batch_debug_set(self._h, key.encode(), int(value)))
 
+    def debug_host_ms(self):
+        """(calls, {copy_in, submit, wait_copy_out, rds_callbacks}) mean ms of the host-buffer calls since
+        the last query (fmd_batch_debug_host_ms)."""
+        out = (C.c_float * 4)()
+        n = _check(lib().fmd_batch_debug_host_ms(self._h, out))
+        return n, dict(zip(("copy_in", "submit", "wait_copy_out", "rds_callbacks"), (float(v) for v in out)))
+
     def status(self, channel=0):
         st = FmdStatus()
         _check(lib().fmd_batch_get_status(self._h, channel, C.byref(st)))
@@ -434,6 +445,21 @@ class Batch:
         return out, calls
 
 
+class _BatchView(Batch):
+    """A batch somebody else owns (FmDecoder.batch_view)."""
+
+    def __init__(self, handle, sink):
+        self._h = handle
+        self.sink = sink
+        self.n_channels = 1
+
+    def close(self):
+        self._h = None
+
+    def __del__(self):
+        pass
+
+
 class FmDecoder:
     """The reference's cFmDecoder surface (FmDecode.h:110-165) on the GPU library."""
 
@@ -456,6 +482,11 @@ class FmDecoder:
 
     def Reset(self):
         _check(lib().fmd_reset(self._h))
+
+    def batch_view(self):
+        """The decoder's one-channel batch as a Batch object that does not own it: for the profiling and
+        development calls (set_profiling, stage_ms, debug_host_ms, debug_set), not for processing."""
+        return _BatchView(C.c_void_p(lib().fmd_decoder_batch(self._h)), self.sink)
 
     def ProcessStream(self, samples_in):
         iq = np.ascontiguousarray(samples_in)

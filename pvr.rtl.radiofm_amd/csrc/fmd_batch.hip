@@ -149,6 +149,10 @@ struct fmd_batch
   int dbg_post_delay_us = 20;  // the post chain starts this long behind the serial stage's end
   int dbg_hb4 = 1, dbg_ring4 = 1; // 0: the generic half-band / ring-FIR kernels where the unrolled ones would run
   int dbg_prof_dump = 0;
+  // where a host-buffer call's time goes (fmd_batch_debug_host_ms): copy in, submission, wait + copy
+  // out, RDS collection + group decoder callbacks; sums since the last query
+  double host_ms[4] = {0, 0, 0, 0};
+  unsigned host_calls = 0;
   DevBuf<long long> serial_probe; // FMD_SERIAL_PROBE=1: per-workgroup timing of the serial stage
   DevBuf<float> fstate; // all float state arrays, CP each
   DevBuf<int> istate;
@@ -911,7 +915,10 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     // and they run side by side on two streams (+10 % at 24 576, +12 % at 32 768 channels); below
     // that the extra concurrent kernels only stretch the latency-bound serial stage (-4 % at
     // 8192), so they share one stream ("split_post" of fmd_batch_debug_set overrides).
-    b->split_post = b->CP > 16384;
+    // A batch of one or two wavefronts (the single decoder of cFmDecoder: RadioReceiver.cpp:515-538) is
+    // pure latency: its RDS chain (0.35 ms of lane-serial kernels) and its audio chain (0.19 ms) behind the
+    // serial stage run side by side as well -- 2.17 -> 1.9 ms per call of one channel.
+    b->split_post = b->CP > 16384 || b->CP <= 128;
     // The serial stage takes whole CUs (one role wave per SIMD) while that costs at most a quarter of the chip (<= 8192
     // channels = 64 CUs; +4.4 % at 8192 channels) and the batch is big enough for the bandwidth
     // kernels to notice their neighbours at all ("serial_exclusive" of fmd_batch_debug_set overrides).
@@ -1852,6 +1859,20 @@ int fmd_batch_debug_set_spin_limit(fmd_batch* b, unsigned limit)
   return FMD_OK;
 }
 
+int fmd_batch_debug_host_ms(fmd_batch* b, float out[4])
+{
+  if (!b || !out)
+    return fail(FMD_ERR_ARG, "null argument");
+  const unsigned n = b->host_calls;
+  for (int i = 0; i < 4; i++)
+  {
+    out[i] = n ? float(b->host_ms[i] / n) : 0.0f;
+    b->host_ms[i] = 0.0;
+  }
+  b->host_calls = 0;
+  return int(n);
+}
+
 int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
 {
   if (!b || !key)
@@ -2105,11 +2126,16 @@ static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t 
       return fail(FMD_ERR_DEVICE, "staging allocation failed");
     b->h_audio_cap = a_stride * C;
   }
+  using clk = std::chrono::steady_clock;
+  auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+  clk::time_point tp = clk::now();
   if (iq_channel_stride)
     HIPCHK(hipMemcpy2D(b->h_iq.p, dev_row, iq, iq_channel_stride * esz, size_t(samples) * esz, C,
                        hipMemcpyHostToDevice));
   else
     HIPCHK(hipMemcpy(b->h_iq.p, iq, size_t(samples) * esz, hipMemcpyHostToDevice));
+  b->host_ms[0] += ms_since(tp);
+  tp = clk::now();
   unsigned nf = 0;
   int rc = process_device_impl(b, b->h_iq.p, fmt, dev_iq_stride, samples, b->h_audio.p, a_stride, &nf,
                                nullptr);
@@ -2117,6 +2143,8 @@ static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t 
     return rc;
   if (C > 1 && nf > audio_channel_stride)
     return fail(FMD_ERR_ARG, "audio_channel_stride smaller than the audio produced");
+  b->host_ms[1] += ms_since(tp);
+  tp = clk::now();
   // Synchronous entry point in every concurrency mode: in mode 2 the null stream is not ordered after
   // the call -- order it behind the whole call before copying the audio out.
   rc = wait_impl(b, 0, nullptr, false); // the groups-lost flag is this call's to report, at its end
@@ -2124,9 +2152,13 @@ static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t 
     return rc;
   HIPCHK(hipMemcpy2D(audio, (C > 1 ? audio_channel_stride : size_t(nf)) * sizeof(float), b->h_audio.p,
                      a_stride * sizeof(float), size_t(nf) * sizeof(float), C, hipMemcpyDeviceToHost));
+  b->host_ms[2] += ms_since(tp);
+  tp = clk::now();
   rc = fmd_batch_collect_rds(b, nullptr, 0, 1, nullptr);
   if (rc < 0)
     return rc;
+  b->host_ms[3] += ms_since(tp);
+  b->host_calls++;
   if (out_floats)
     *out_floats = nf;
   return take_lost_groups(b); // FMD_OK, or FMD_WARN_RDS_LOST once: audio and state are intact
@@ -2427,6 +2459,11 @@ int fmd_process_stream_u8(fmd_decoder* d, const uint8_t* buf, unsigned samples, 
   unsigned nf = 0;
   int rc = fmd_batch_process_host_u8(d->b, buf, 0, samples, audio, 0, &nf);
   return rc < 0 ? rc : int(nf); // (a groups-lost warning does not touch the audio: fmd_last_error has it)
+}
+
+fmd_batch* fmd_decoder_batch(fmd_decoder* d)
+{
+  return d ? d->b : nullptr;
 }
 
 int fmd_get_status(fmd_decoder* d, fmd_status* st)
