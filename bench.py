@@ -715,7 +715,7 @@ def main():
     if os.environ.get("FMD_BENCH_TIMELINE") and rank == 0:  # dev aid: what fill and drain are made of
         tl = batch.debug_timeline()
         sys.stderr.write("TIMELINE (ms since the first timed call's FIR start; wall %.3f ms)\n"
-                         "call  fir_start fir_end  ser_start ser_end  tail_start tail_end\n" % (dt * 1e3))
+                         "call  fir_start fir_end  ser_start ser_end  tail_start tail_end  hbchain_start hbchain_end  resample_start resample_end\n" % (dt * 1e3))
         for c, row in enumerate(tl):
             sys.stderr.write("%4d  %s\n" % (c, "  ".join("%8.3f" % v for v in row)))
     # what makes an N > 1 run explain itself: every rank's own time per step and FIR time, and what the
@@ -754,6 +754,25 @@ def main():
         stage_all, _ = batch.stage_ms()
     batch.set_profiling(0)
 
+    # What the host-buffer boundary (fmd_batch_process_host: ProcessStream's own arguments are host
+    # pointers) could sustain at best: every IQ byte crosses PCIe once.  Measured here, never `value`.
+    pcie = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        hb = torch.empty(256 << 20, dtype=torch.uint8).pin_memory()
+        db = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+        db.copy_(hb, non_blocking=True)
+        torch.cuda.synchronize()
+        tpc = time.perf_counter()
+        for _ in range(4):
+            db.copy_(hb, non_blocking=True)
+        torch.cuda.synchronize()
+        gbs = 4 * hb.numel() / (time.perf_counter() - tpc) / 1e9
+        in_b = 2.0 if u8 else 8.0
+        pcie = {"h2d_GBps_pinned": round(gbs, 1), "value": round(gbs * 1e9 / in_b / 1e6, 1), "unit": "MS/s",
+                "note": "upper bound with host-resident input: %.0f B per IQ sample over the measured pinned "
+                        "host-to-device rate, copies fully overlapped with compute; `value` above is with the "
+                        "input resident in HBM (SURVEY 8(d))" % in_b}
+        del hb, db
     if rank == 0:
         samples_per_step = C * N
         value = world * samples_per_step * K / dt / 1e6
@@ -817,6 +836,18 @@ def main():
                     and t.get("samples_per_call") == N):
                 out["roofline"]["traffic"] = t["bytes_per_launch"]
                 out["roofline"]["traffic_source"] = t["source"]
+        # what the whole path moves per call against what the algorithm needs (input once, audio once)
+        algo_call = samples_per_step * ((in_bytes / C if shared else in_bytes)) + C * nf * 4.0
+        out["algorithmic_bytes_per_call"] = int(algo_call)
+        fpath = os.path.join(ROOT, "profiles", "traffic_per_call.json")
+        out["fabric_bytes_per_call"] = None
+        if os.path.exists(fpath) and args.workload == "config4" and not u8 and not args.debug_set:
+            t = json.load(open(fpath))
+            if t.get("channels") == C and t.get("samples_per_call") == N:
+                out["fabric_bytes_per_call"] = t["bytes_per_call"]
+                out["fabric_bytes_source"] = t["source"]
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
         if args.debug_set:
             out["config"]["debug_set"] = args.debug_set
         if verify is not None:
@@ -839,6 +870,22 @@ def main():
                                                     "after the timed region; one tile per workgroup there, two "
                                                     "beside the serial stage); avg_ms / achieved / frac above "
                                                     "are inside the overlapped pipeline"}
+        if args.workload == "config5":
+            # 362 flop per input sample against 8.17 B: far on the VALU side of the ridge.  A
+            # lane owns an output and adds its 4096 taps in the reference's order, no FMA: one wave per SIMD
+            # (the 127 KB window fills the CU's LDS) issuing packed mul / add pairs
+            r = out["roofline"]
+            r["hbm"] = {"achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac"]}
+            r.update(bound="valu-issue", achieved=r["valu_tflops_nofma"], peak=78.6, unit="TFLOP/s",
+                     frac=round(r["valu_tflops_nofma"] / 78.6, 4))
+            r["peak_note"] = "packed FP32 multiply / add without FMA: 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz"
+            if "alone" in r:
+                r["alone"]["hbm_frac"] = r["alone"].pop("frac")
+                r["alone"]["hbm_achieved_GBps"] = r["alone"].pop("achieved")
+            r["issue_floor"] = ("a lone wave per SIMD issues a packed op every 8 cycles at best: 16 cycles "
+                                              "per tap and output; measured 17.8 (profiles/r3_lone_wave_issue_costs.txt, "
+                                              "r3_long_filter_layouts.txt); 78.6 TF = 256 CUs x 4 SIMDs x 32 flop/clk "
+                                              "x 2.4 GHz needs two waves per SIMD, which the window does not leave room for")
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(if_filter_order=order)
         # RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would

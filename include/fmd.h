@@ -310,10 +310,11 @@ int fmd_debug_math(int what, unsigned n, const float* a, const float* b, float* 
  * when the probe is off).  Synchronises the device. */
 int fmd_batch_debug_serial_probe(fmd_batch* b, long long* out, unsigned cap_workgroups);
 /* Dev aid (overlapped calls at profiling level 1, whole-CU serial stage): per profiled call when its
- * IF FIR, its serial stage and its audio tail started and ended on the device, in ms since the first
- * profiled call's FIR started: cap_calls rows of 6 floats (-1 = not recorded).  Returns the number of
- * rows.  Synchronises the device.  What a short run's fill and drain are made of (bench.py prints it
- * with FMD_BENCH_TIMELINE=1). */
+ * IF FIR, its serial stage, its audio tail, its half-band chain and its resampler started and ended on
+ * the device (the last two only in their large-batch forms), in ms since the first profiled call's FIR
+ * started: cap_calls rows of 10 floats (-1 = not recorded).  Returns the number of rows.  Synchronises
+ * the device.  What a short run's fill and drain are made of (bench.py prints it with
+ * FMD_BENCH_TIMELINE=1). */
 int fmd_batch_debug_timeline(fmd_batch* b, float* out, unsigned cap_calls);
 /* Test aid: bound (in polls) of the serial stage's LDS hand-off waits for the calls that follow;
  * 0 makes every wait time out at once, which exercises the device-side error path. */

@@ -369,9 +369,9 @@ class Batch:
         return ci.value
 
     def debug_timeline(self, cap=512):
-        """[calls, 6] ms since the first profiled call's FIR start: FIR, serial stage, audio tail
-        (start, end each); empty unless calls overlap at profiling level 1."""
-        buf = np.full((cap, 6), -1.0, dtype=np.float32)
+        """[calls, 10] ms since the first profiled call's FIR start: FIR, serial stage, audio tail,
+        half-band chain, resampler (start, end each); empty unless calls overlap at profiling level 1."""
+        buf = np.full((cap, 10), -1.0, dtype=np.float32)
         n = _check(lib().fmd_batch_debug_timeline(self._h, buf.ctypes.data, cap))
         return buf[:n].copy()
 

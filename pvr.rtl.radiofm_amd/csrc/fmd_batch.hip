@@ -149,6 +149,7 @@ struct fmd_batch
   int dbg_post_delay_us = 20;  // the post chain starts this long behind the serial stage's end
   int dbg_hb4 = 1, dbg_ring4 = 1; // 0: the generic half-band / ring-FIR kernels where the unrolled ones would run
   int dbg_prof_dump = 0;
+  int dbg_lpf_late = 1;        // the post chain's two low-pass filters behind EV_HEAVY (beside the next IF FIR)
   // where a host-buffer call's time goes (fmd_batch_debug_host_ms): copy in, submission, wait + copy
   // out, RDS collection + group decoder callbacks; sums since the last query
   double host_ms[4] = {0, 0, 0, 0};
@@ -212,6 +213,7 @@ struct fmd_batch
   {
     unsigned R = 0, A = 0, mf_g = 0;
     int q = 0, es = 0, sq = 0;
+    bool tail_after_alp = false; // the audio tail waits for EV_ALP (the audio low-pass behind EV_HEAVY)
     uint32_t call_index = 0;
     float* d_audio = nullptr;
     size_t audio_stride = 0;
@@ -219,7 +221,7 @@ struct fmd_batch
   };
   bool split_post = false;
   bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
-  enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_RDSH, EV_N };
+  enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_RDSH, EV_ALP, EV_N };
   hipEvent_t cev[NSLOT][EV_N] = {};
   bool cev_ready = false;
   uint32_t slot_call[NSLOT] = {}; // call index that last used the slot (0 = never)
@@ -1195,7 +1197,7 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     mark_failed(b, "hipEventRecord failed behind the RDS part of a call");
   // the RDS part above only needed the RDS half of the call's heavy part (EV_RDSH, waited for by the
   // caller); the audio tail needs the other half too
-  if (record && hipStreamWaitEvent(s, b->cev[j.es][fmd_batch::EV_HEAVY], 0) != hipSuccess)
+  if (record && hipStreamWaitEvent(s, b->cev[j.es][j.tail_after_alp ? fmd_batch::EV_ALP : fmd_batch::EV_HEAVY], 0) != hipSuccess)
     mark_failed(b, "hipStreamWaitEvent failed in front of the audio tail of a call");
   {
     fmd::AudioConsts k{};
@@ -1494,6 +1496,13 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     nrolls = 0;
     roll_hmax = 1;
   };
+  /* Default overlapped mode: the two low-pass filters of the post chain (0.1 ms each at 8192 channels, a few
+   * hundred small workgroups) go to the END of the heavy stream's work for the call, behind EV_HEAVY: the next
+   * IF FIR, which waits for EV_HEAVY, then runs beside them instead of behind them, and the half-band chain
+   * and the resampler follow each other directly.  The light part waits for its low-pass (EV_RDSH is recorded
+   * behind the RDS one, EV_ALP behind the audio one). */
+  const bool lpf_late = !serial_mode && !b->split_post && b->dbg_lpf_late != 0;
+  std::function<void()> rds_lpf_late, audio_lpf_late;
   bool hb_all_normal = d.hb.size() <= 3;
   for (size_t s = 0; s < d.hb.size(); s++)
     hb_all_normal = hb_all_normal && hb_mode[s] == HB_NORMAL && d.hb[s].len != 11;
@@ -1525,6 +1534,13 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       if (pl)
       {
         const unsigned n0 = (hb_in[0] + 1) / 2, n1 = (n0 + 1) / 2;
+        if (evset && b->profiling == 1 && !serial_mode) // its own start and stop (fmd_batch_debug_timeline)
+          hipExtLaunchKernelGGL(kern, dim3(groups, pl->S), dim3(64, 4), 0u, sR, evset[6], evset[7], 0u,
+                                (const float2*)b->mix[q].p, (const float2*)b->hbbuf[0].p, (const float2*)b->hbbuf[1].p,
+                                b->rdsraw.p, T_lpf - 1, b->hbf_tail1.p, b->hbf_tail2.p, b->hbcoef[0], b->hbcoef[1],
+                                b->hbcoef[2], (const fmd::HbStep*)pl->steps.p, (const int*)pl->seg_first.p, hb_in[0],
+                                n0, n1, C, CP);
+        else
         hipLaunchKernelGGL(kern, dim3(groups, pl->S), dim3(64, 4), 0, sR, b->mix[q].p, b->hbbuf[0].p,
                            b->hbbuf[1].p, b->rdsraw.p, T_lpf - 1, b->hbf_tail1.p, b->hbf_tail2.p, b->hbcoef[0],
                            b->hbcoef[1], b->hbcoef[2], pl->steps.p, pl->seg_first.p, hb_in[0], n0, n1, C, CP);
@@ -1585,6 +1601,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       }
     }
     mark(3);
+    auto lpf = [&]() {
     const int ring4 = b->dbg_ring4;
     if (ring4 && T_lpf >= unsigned(fmd::RG))
       hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
@@ -1601,6 +1618,14 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     }
     else
       hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, sR, b->rdsraw.p, b->rdsraw.p, T_lpf - 1, R, CP);
+    };
+    if (lpf_late)
+    { // what the decimator left to roll goes now; the low-pass later (see above)
+      roll_flush(sR);
+      rds_lpf_late = lpf;
+      return;
+    }
+    lpf();
     mark(4);
   };
   auto rds_light = [&]() {
@@ -1658,6 +1683,12 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       auto go = [&](auto plan, auto kern) {
         hipLaunchKernelGGL(plan, dim3(rs_steps * b->rsr_NW), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p, pstep,
                            A, b->rsr_rb, b->rsr_nbr, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p);
+        if (evset && b->profiling == 1 && !serial_mode)
+          hipExtLaunchKernelGGL(kern, dim3(groups, S), dim3(64, b->rsr_NW + 1), lds, sA, evset[8], evset[9], 0u,
+                                (const float2*)b->brp(q), Hbb, b->rsr_rb, d.rs_order, (const float*)b->rsr_tab.p,
+                                b->rsr_nbm, (const int*)b->rsr_head.p, (const int*)b->rsr_steps.p, rs_steps, per_seg,
+                                b->rsr_nbr, A, b->rs.p, T_alp - 1, C, CP, b->rsr_exp, b->rsr_pace);
+        else
         hipLaunchKernelGGL(kern, dim3(groups, S), dim3(64, b->rsr_NW + 1), lds, sA, b->brp(q), Hbb, b->rsr_rb,
                            d.rs_order, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p, rs_steps, per_seg,
                            b->rsr_nbr, A, b->rs.p, T_alp - 1, C, CP, b->rsr_exp, b->rsr_pace);
@@ -1679,6 +1710,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     }
     roll_later(b->brp(q), b->brp(q ^ 1), Hbb, M); // with the low-pass's own roll, at the chain's end
     mark(6);
+    auto lpf = [&]() {
     const int ring4a = b->dbg_ring4;
     if (ring4a && T_alp >= unsigned(fmd::RG))
       hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (A + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
@@ -1689,6 +1721,14 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                        int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
     roll_later(b->rs.p, b->rs.p, T_alp - 1, A);
     roll_flush(sA);
+    };
+    if (lpf_late)
+    {
+      roll_flush(sA); // the baseband rows' history now; the low-pass (and its own roll) later
+      audio_lpf_late = lpf;
+      return;
+    }
+    lpf();
     mark(7);
   };
   auto audio_light = [&]() {
@@ -1729,9 +1769,17 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       after(sA, pe2[fmd_batch::EV_AUD]);
     }
     rds_heavy();
-    signal(ce[fmd_batch::EV_RDSH], sR);
+    if (!lpf_late)
+      signal(ce[fmd_batch::EV_RDSH], sR);
     audio_heavy();
     signal(ce[fmd_batch::EV_HEAVY], sP);
+    if (lpf_late)
+    { // the two low-pass filters: beside the IF FIR that EV_HEAVY has just let go
+      rds_lpf_late();
+      signal(ce[fmd_batch::EV_RDSH], sP);
+      audio_lpf_late();
+      signal(ce[fmd_batch::EV_ALP], sP);
+    }
     fmd_batch::LightJob job;
     job.R = R;
     job.A = A;
@@ -1742,6 +1790,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     job.call_index = ci;
     job.d_audio = d_audio;
     job.audio_stride = audio_channel_stride;
+    job.tail_after_alp = lpf_late;
     if (evset && b->profiling == 1)
     {
       job.tl0 = evset[4];
@@ -1900,6 +1949,8 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
     b->dbg_hb4 = value != 0;
   else if (k == "ring4")
     b->dbg_ring4 = value != 0;
+  else if (k == "lpf_late")
+    b->dbg_lpf_late = value != 0;
   else if (k == "prof_dump")
     b->dbg_prof_dump = value != 0;
   else if (k == "serial_probe")
@@ -2527,12 +2578,12 @@ int fmd_batch_debug_timeline(fmd_batch* b, float* out, unsigned cap_calls)
   for (unsigned c = 0; c < n; c++)
   {
     hipEvent_t* es = &b->ev[size_t(c) * (ST_COUNT + 1)];
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 10; i++)
     {
       float ms = -1.0f;
       if (hipEventElapsedTime(&ms, t0, es[i]) != hipSuccess)
         ms = -1.0f; // an event that was never recorded (the call's tail was not profiled)
-      out[size_t(c) * 6 + i] = ms;
+      out[size_t(c) * 10 + i] = ms;
     }
   }
   (void)hipGetLastError();

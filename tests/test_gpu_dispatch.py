@@ -267,7 +267,7 @@ def test_device_timeline_of_overlapped_calls(fmsig):
     the FIR of call k + 1 does overlap the serial stage of call k -- the point of concurrency 2."""
     import torch
     pkg = load_package()
-    fs, D, C, nblk = 2.4e6, 11, 2048, 8
+    fs, D, C, nblk = 2.4e6, 11, 4096, 8  # (4096 channels: the large-batch forms of half-band chain and resampler)
     gen = fmsig.DeviceGenerator([fmsig.channel_params(fs, c % 16) for c in range(C)], "cuda")
     b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
     b.set_concurrency(2)
@@ -284,10 +284,11 @@ def test_device_timeline_of_overlapped_calls(fmsig):
     b.wait(stream=st)
     torch.cuda.synchronize()
     tl = b.debug_timeline()
-    assert tl.shape == (nblk, 6) and (tl >= 0).all() and tl[0, 0] == 0.0
+    assert tl.shape == (nblk, 10) and (tl >= 0).all() and tl[0, 0] == 0.0
     for k in range(nblk):
-        f0, f1, s0, s1, t0, t1 = tl[k]
+        f0, f1, s0, s1, t0, t1, h0, h1, r0, r1 = tl[k]
         assert f0 < f1 <= s0 < s1 <= t0 < t1, (k, tl[k])
+        assert s1 <= h0 < h1 <= r0 < r1 <= t0, (k, tl[k])  # half-band chain, then resampler, behind the serial stage
     assert all(tl[k, 3] <= tl[k + 1, 2] for k in range(nblk - 1))           # serial stages one after the other
     assert any(tl[k + 1, 0] < tl[k, 3] for k in range(1, nblk - 1))           # a later FIR beside an earlier serial stage
     b.set_profiling(0)
