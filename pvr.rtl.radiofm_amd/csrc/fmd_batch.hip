@@ -142,6 +142,16 @@ struct fmd_batch
   std::vector<std::unique_ptr<HbfPlan>> hbf_plans;
   DevBuf<float2> hbf_tail1, hbf_tail2;
   int hbf_mode = -1;
+  /* The RDS oscillator as one sequence per batch (k_rds_osc), for calls whose serial stage writes no mixed
+   * rows (k_demod_serial<.., MIX = false> + k_halfband_chain<.., OSC>): tables of four calls in rotation
+   * (a call's table is read by its half-band chain, two serial stages later), kOscH entries of history in
+   * front; the state behind the newest call, and behind each of the last four calls.  osc_on: the kernel
+   * runs every call (large batches from creation; "halfband_chain" = 1 before the first call). */
+  static constexpr unsigned kOscH = 64;
+  DevBuf<float2> osc_tab[4];
+  DevBuf<float> osc_uni, osc_after;
+  bool osc_on = false;
+  int dbg_nomix = 1;
   // development switches (fmd_batch_debug_set; the library reads no environment variable)
   int dbg_fir_nt = 0;          // tiles per IF FIR workgroup (0: the library decides)
   int dbg_fir_b128 = 1;        // long filters: 16-byte window reads where the layout allows
@@ -279,6 +289,10 @@ struct fmd_batch
     }
     hbf_tail1.release();
     hbf_tail2.release();
+    for (auto& t : osc_tab)
+      t.release();
+    osc_uni.release();
+    osc_after.release();
     rsr_head.release();
     rsr_steps.release();
     rpll.release();
@@ -797,6 +811,14 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   {
     bad |= b->hbf_tail1.alloc(size_t(d.hb[1].len - 1) * CP);
     bad |= b->hbf_tail2.alloc(size_t(d.hb[2].len - 1) * CP);
+    for (auto& t : b->osc_tab)
+      bad |= t.alloc(size_t(fmd_batch::kOscH) + b->Mmax + 8);
+    bad |= b->osc_uni.alloc(2);
+    bad |= b->osc_after.alloc(8);
+    const float one_zero[2] = {1.0f, 0.0f}; // CRDSDownConvert: m_Osc1 = (1, 0) (DownConvert.cpp:284)
+    if (!bad)
+      bad |= upload(b->osc_uni.p, one_zero, sizeof one_zero);
+    b->osc_on = CP / 64 >= 64 && d.hb[0].len - 1 <= int(fmd_batch::kOscH);
   }
   bad |= b->rdsraw.alloc(size_t(T_lpf - 1 + b->Rmax) * CP);
   bad |= b->rlpf[0].alloc(size_t(b->Rmax) * CP);
@@ -1363,6 +1385,37 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       note(hipEventRecord(evset[i], sF));
   };
 
+  /* ---- which form the RDS decimator takes: decided here, the serial stage's form follows from it ---- */
+  bool hb_all_normal = d.hb.size() <= 3;
+  for (size_t s = 0; s < d.hb.size(); s++)
+    hb_all_normal = hb_all_normal && hb_mode[s] == HB_NORMAL && d.hb[s].len != 11;
+  /* Large batches in the usual geometries: the three half-band stages as one stream, intermediate rows in
+   * LDS (k_halfband_chain).  Everything else -- short calls with a stage outside its normal regime, the
+   * 11-tap class, chains of another length, small batches -- keeps one launch per stage. */
+  fmd_batch::HbfPlan* hbf_pl = nullptr;
+  int hbf_kind = -1; // 0: 15 / 23 / 43 taps, 1: 15 / 19 / 35
+  if (hb_all_normal && d.hb.size() == 3 && b->hbf_mode != 0 && (b->hbf_mode == 1 || CP / 64 >= 64))
+  {
+    const int h0 = (d.hb[0].len - 1) / 2, h1 = (d.hb[1].len - 1) / 2, h2 = (d.hb[2].len - 1) / 2;
+    hbf_kind = (h0 == 7 && h1 == 11 && h2 == 21) ? 0 : (h0 == 7 && h1 == 9 && h2 == 17) ? 1 : -1;
+    if (hbf_kind >= 0)
+    {
+      const unsigned groups = CP / 64;
+      const unsigned ncu = unsigned(b->n_cus) - ((b->serial_exclusive && !serial_mode) ? (groups + 1) / 2 : 0u);
+      const unsigned S = std::max(1u, std::min({8u, (2u * ncu + groups / 2u) / groups, R / 32u}));
+      hbf_pl = hbf_plan(b, hb_in[0], S);
+    }
+  }
+  // ... and then the serial stage writes no mixed rows: the chain multiplies the baseband with the
+  // oscillator's sequence itself (k_rds_osc, one per batch and call, here on the IF stream: long before
+  // anything needs it)
+  const bool nomix = hbf_pl != nullptr && b->osc_on && b->dbg_nomix != 0;
+  const unsigned osc_slot = ci & 3u;
+  if (b->osc_on)
+    hipLaunchKernelGGL(fmd::k_rds_osc, dim3(1), dim3(64), 0, sF, b->osc_uni.p, b->osc_tab[(ci + 3u) & 3u].p, b->lastM,
+                       b->osc_tab[osc_slot].p, M, fmd_batch::kOscH, b->osc_after.p + 2 * osc_slot, d.rds_osc_cos,
+                       d.rds_osc_sin);
+
   /* ---- K1: tuner + IF decimating FIR  (stream F) ---- */
   signal(ce[fmd_batch::EV_IN], stream);
   after(sF, ce[fmd_batch::EV_IN]);
@@ -1436,24 +1489,29 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
      * boxes, never slower (stage 1.71 -> 1.83 ms, FIR 1.02 -> 0.97 ms inside the pipeline on the
      * first).  "serial_claim" = 1 of fmd_batch_debug_set brings the claim back. */
     const bool serial_claim = b->dbg_serial_claim != 0;
-    auto kser2 = serial_claim ? &fmd::k_demod_serial<2, true> : &fmd::k_demod_serial<2, false>;
+    auto kser2 = nomix ? (serial_claim ? &fmd::k_demod_serial<2, true, false> : &fmd::k_demod_serial<2, false, false>)
+                       : (serial_claim ? &fmd::k_demod_serial<2, true, true> : &fmd::k_demod_serial<2, false, true>);
+    auto kser1 = nomix ? &fmd::k_demod_serial<1, false, false> : &fmd::k_demod_serial<1, false, true>;
+    const float* osc_after = b->osc_after.p ? b->osc_after.p + 2 * osc_slot : nullptr;
     if (b->serial_exclusive && !serial_mode && evset && b->profiling == 1)
       // profiling level 1: the stage's own start and stop too (fmd_batch_debug_timeline)
       hipExtLaunchKernelGGL(kser2, dim3((groups + 1) / 2), dim3(256), 0u, sS, evset[2],
                             evset[3], 0u, (const float2*)b->demod[q].p, b->Mstride, M, C, CP, k, b->st,
                             b->brp(q), Hbb, b->mix[q].p, Hmix,
                             (const double*)(b->sctab256.p), sct, unsigned(sq),
-                            (long long*)nullptr);
+                            (long long*)nullptr, osc_after);
     else if (b->serial_exclusive && !serial_mode)
       hipLaunchKernelGGL(kser2, dim3((groups + 1) / 2), dim3(256), 0, sS,
                          (const float2*)b->demod[q].p, b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p,
                          Hmix, (const double*)b->sctab256.p, sct, unsigned(sq),
-                         b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : (long long*)nullptr);
+                         b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : (long long*)nullptr,
+                         osc_after);
     else
-      hipLaunchKernelGGL((fmd::k_demod_serial<1, false>), dim3(groups), dim3(128), 0, sS, b->demod[q].p,
+      hipLaunchKernelGGL(kser1, dim3(groups), dim3(128), 0, sS, (const float2*)b->demod[q].p,
                          b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p, Hmix,
-                         b->sctab256.p, sct, unsigned(sq),
-                         b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : nullptr);
+                         (const double*)b->sctab256.p, sct, unsigned(sq),
+                         b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : (long long*)nullptr,
+                         osc_after);
   }
   signal(ce[fmd_batch::EV_SER], sS);
   mark(2);
@@ -1503,9 +1561,6 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
    * behind the RDS one, EV_ALP behind the audio one). */
   const bool lpf_late = !serial_mode && !b->split_post && b->dbg_lpf_late != 0;
   std::function<void()> rds_lpf_late, audio_lpf_late;
-  bool hb_all_normal = d.hb.size() <= 3;
-  for (size_t s = 0; s < d.hb.size(); s++)
-    hb_all_normal = hb_all_normal && hb_mode[s] == HB_NORMAL && d.hb[s].len != 11;
   auto rds_heavy = [&]() {
     /* ---- RDS branch  (stream R): half-bands, 75-tap LPF, PLL, matched filter, bits ---- */
     after(sR, ce[fmd_batch::EV_SER]);
@@ -1514,41 +1569,39 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
      * (k_halfband_chain).  Everything else -- short calls with a stage outside its normal regime, the
      * 11-tap class, chains of another length, small batches -- keeps one launch per stage. */
     bool chain_done = false;
-    if (hb_all_normal && d.hb.size() == 3 && b->hbf_mode != 0 && (b->hbf_mode == 1 || CP / 64 >= 64))
+    if (hbf_pl)
     {
-      const int h0 = (d.hb[0].len - 1) / 2, h1 = (d.hb[1].len - 1) / 2, h2 = (d.hb[2].len - 1) / 2;
+      fmd_batch::HbfPlan* pl = hbf_pl;
       const unsigned groups = CP / 64;
-      const unsigned ncu = unsigned(b->n_cus) - ((b->serial_exclusive && !serial_mode) ? (groups + 1) / 2 : 0u);
-      const unsigned S = std::max(1u, std::min({8u, (2u * ncu + groups / 2u) / groups, R / 32u}));
-      fmd_batch::HbfPlan* pl = nullptr;
-      auto kern = &fmd::k_halfband_chain<7, 11, 21>;
-      bool known = true;
-      if (h0 == 7 && h1 == 11 && h2 == 21)
-        kern = &fmd::k_halfband_chain<7, 11, 21>;
-      else if (h0 == 7 && h1 == 9 && h2 == 17)
-        kern = &fmd::k_halfband_chain<7, 9, 17>;
+      const unsigned L0H = unsigned(d.hb[0].len - 1);
+      const unsigned n0 = (hb_in[0] + 1) / 2, n1 = (n0 + 1) / 2;
+      // stage 0's input rows and, without mixed rows, the oscillator entries that go with them: both
+      // indexed by the stage's input row (0 = the first of its L0H history rows)
+      const float2* in0 = nomix ? (const float2*)(b->brp(q) + size_t(Hbb - L0H) * CP) : (const float2*)b->mix[q].p;
+      const float2* osc = nomix ? (const float2*)(b->osc_tab[osc_slot].p + (fmd_batch::kOscH - L0H)) : nullptr;
+      auto kern = hbf_kind == 0 ? (nomix ? &fmd::k_halfband_chain<7, 11, 21, true> : &fmd::k_halfband_chain<7, 11, 21, false>)
+                                : (nomix ? &fmd::k_halfband_chain<7, 9, 17, true> : &fmd::k_halfband_chain<7, 9, 17, false>);
+      if (evset && b->profiling == 1 && !serial_mode) // its own start and stop (fmd_batch_debug_timeline)
+        hipExtLaunchKernelGGL(kern, dim3(groups, pl->S), dim3(64, 4), 0u, sR, evset[6], evset[7], 0u, in0,
+                              (const float2*)b->hbbuf[0].p, (const float2*)b->hbbuf[1].p, b->rdsraw.p, T_lpf - 1,
+                              b->hbf_tail1.p, b->hbf_tail2.p, b->hbcoef[0], b->hbcoef[1], b->hbcoef[2],
+                              (const fmd::HbStep*)pl->steps.p, (const int*)pl->seg_first.p, hb_in[0], n0, n1, C, CP,
+                              osc);
       else
-        known = false;
-      if (known)
-        pl = hbf_plan(b, hb_in[0], S);
-      if (pl)
-      {
-        const unsigned n0 = (hb_in[0] + 1) / 2, n1 = (n0 + 1) / 2;
-        if (evset && b->profiling == 1 && !serial_mode) // its own start and stop (fmd_batch_debug_timeline)
-          hipExtLaunchKernelGGL(kern, dim3(groups, pl->S), dim3(64, 4), 0u, sR, evset[6], evset[7], 0u,
-                                (const float2*)b->mix[q].p, (const float2*)b->hbbuf[0].p, (const float2*)b->hbbuf[1].p,
-                                b->rdsraw.p, T_lpf - 1, b->hbf_tail1.p, b->hbf_tail2.p, b->hbcoef[0], b->hbcoef[1],
-                                b->hbcoef[2], (const fmd::HbStep*)pl->steps.p, (const int*)pl->seg_first.p, hb_in[0],
-                                n0, n1, C, CP);
-        else
-        hipLaunchKernelGGL(kern, dim3(groups, pl->S), dim3(64, 4), 0, sR, b->mix[q].p, b->hbbuf[0].p,
-                           b->hbbuf[1].p, b->rdsraw.p, T_lpf - 1, b->hbf_tail1.p, b->hbf_tail2.p, b->hbcoef[0],
-                           b->hbcoef[1], b->hbcoef[2], pl->steps.p, pl->seg_first.p, hb_in[0], n0, n1, C, CP);
-        roll_later(b->mix[q].p, b->mix[q ^ 1].p, unsigned(d.hb[0].len - 1), hb_in[0]);
-        roll_later(b->hbf_tail1.p, b->hbbuf[0].p, unsigned(d.hb[1].len - 1), 0u);
-        roll_later(b->hbf_tail2.p, b->hbbuf[1].p, unsigned(d.hb[2].len - 1), 0u);
-        chain_done = true;
-      }
+        hipLaunchKernelGGL(kern, dim3(groups, pl->S), dim3(64, 4), 0, sR, in0, (const float2*)b->hbbuf[0].p,
+                           (const float2*)b->hbbuf[1].p, b->rdsraw.p, T_lpf - 1, b->hbf_tail1.p, b->hbf_tail2.p,
+                           b->hbcoef[0], b->hbcoef[1], b->hbcoef[2], (const fmd::HbStep*)pl->steps.p,
+                           (const int*)pl->seg_first.p, hb_in[0], n0, n1, C, CP, osc);
+      if (nomix) // the next call's stage-0 history, should it take a launch per stage (it reads mixed rows)
+        hipLaunchKernelGGL(fmd::k_mix_tail, rgrid(L0H), rt, 0, sR,
+                           (const float2*)(b->brp(q) + size_t(Hbb + hb_in[0] - L0H) * CP),
+                           (const float2*)(b->osc_tab[osc_slot].p + fmd_batch::kOscH + hb_in[0] - L0H),
+                           b->mix[q ^ 1].p, L0H, CP);
+      else
+        roll_later(b->mix[q].p, b->mix[q ^ 1].p, L0H, hb_in[0]);
+      roll_later(b->hbf_tail1.p, b->hbbuf[0].p, unsigned(d.hb[1].len - 1), 0u);
+      roll_later(b->hbf_tail2.p, b->hbbuf[1].p, unsigned(d.hb[2].len - 1), 0u);
+      chain_done = true;
     }
     if (!chain_done)
     {
@@ -1962,7 +2015,16 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
       return fail(FMD_ERR_DEVICE, "serial probe allocation failed");
   }
   else if (k == "halfband_chain") // -1 the library decides, 0 a launch per stage, 1 k_halfband_chain wherever it applies
+  {
     b->hbf_mode = value < 0 ? -1 : (value ? 1 : 0);
+    // before the first call a small batch can still start the batch-wide oscillator sequence (and with it
+    // the form of the serial stage that writes no mixed rows); later its chain reads mixed rows
+    if (value > 0 && b->call_index == 0 && b->osc_uni.p && b->des.hb.size() == 3 &&
+        b->des.hb[0].len - 1 <= int(fmd_batch::kOscH))
+      b->osc_on = true;
+  }
+  else if (k == "nomix") // 0: the serial stage writes the mixed rows also where k_halfband_chain follows
+    b->dbg_nomix = value != 0;
   else if (k == "rsr_form") // 0: 2 outputs x 8 waves, 1: 4 x 4, 2: 2 x 4 (falls through to the next that fits)
   {
     bool ok = false;

@@ -1609,12 +1609,19 @@ typedef float fmd_v4f __attribute__((ext_vector_type(4)));
 constexpr int STAGE_RS = 65; // row stride of the staged input in LDS (float2 units)
 constexpr unsigned FM_UNROLL = 4; // samples per trip of the FM wave's loop over a full chunk (1, 2, 4: 651 / 599 / 596 cycles per sample)
 
-template <int NG, bool EXCL>
+/* MIX = false (large batches, where k_halfband_chain follows): the stage neither runs the RDS oscillator nor
+ * writes the mixed rows.  The oscillator (DownConvert.cpp:436-442) is a recurrence on its own state only
+ * -- the same numbers for every channel of a batch (k_rds_osc computes them once per call) -- and the
+ * product with the baseband is made where it is consumed (k_halfband_chain<.., true>): one store per
+ * sample instead of two, ~20 instructions per sample less in the second role wave, 0.39 GB per call less
+ * (8192 channels).  `osc_after` = the oscillator state behind this call (from k_rds_osc): the per-channel
+ * copy that the MIX = true form keeps in registers is brought up to date from it. */
+template <int NG, bool EXCL, bool MIX = true>
 __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     const float2* __restrict__ demod, unsigned Mstride, unsigned M, unsigned C, unsigned CP,
     DemodConsts k, ChannelState st, float2* __restrict__ br, unsigned Hbb,
     float2* __restrict__ mix, unsigned Hmix, const double* __restrict__ sctab_g, FmdSincosTab sct,
-    unsigned stereo_q, long long* __restrict__ wg_probe)
+    unsigned stereo_q, long long* __restrict__ wg_probe, const float* __restrict__ osc_after)
 {
   // sctab_g: (sin, cos)(k / 256), 2048 entries (fmd_sincos_p256)
   // dev aid ("serial_probe" of fmd_batch_debug_set): when each workgroup started and ended on the
@@ -1934,6 +1941,8 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
              * below (the barrier keeps the compiler from moving those in front of the read) */
             p_sc = fmd_sincos_p256_lookup_lds(p_phase, sctab);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MIX)
+            {
             /* ---- RDS oscillator mix (DownConvert.cpp:436-442, :464-465), imag(input) == 0 ---- */
             float2 osc;
             osc.x = o_re * k.osc_cos - o_im * k.osc_sin;
@@ -1949,6 +1958,9 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
             *reinterpret_cast<float2*>(mix_rows + row_off) =
                 make_float2((v * osc.x) - (zero * osc.y), (v * osc.y) + (zero * osc.x));
 #endif
+            }
+            else
+              *reinterpret_cast<float2*>(br_rows + row_off) = make_float2(v, tone * (2 * v)); // FmDecode.cpp:456
             row_off += row_step;
         };
 #ifdef FMD_DBG_NO_2ND /* dev aid (tools/ubench/serial_stage): the FM wave's loop alone */
@@ -1972,16 +1984,18 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
           for (unsigned u = 0; u < cnt; u++)
             second_sample(u);
         }
-        stores_behind = 2 * cnt;
+        stores_behind = (MIX ? 2 : 1) * cnt;
       }
       if (staging)
       {
-        if (stores_behind >= 2 * DS)
-        {
-          if (DS == 32)
+        if (stores_behind >= (MIX ? 2 : 1) * DS)
+        { // all but the chunk's stores, which are younger than the staging loads
+          if ((MIX ? 2 : 1) * DS == 64)
             asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-          else
+          else if ((MIX ? 2 : 1) * DS == 32)
             asm volatile("s_waitcnt vmcnt(31)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
         }
         else
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2007,8 +2021,8 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
       st.F(F_P_FREQ)[c] = p_freq;
       st.F(F_P_PHASE)[c] = p_phase;
       st.F(F_P_LEVEL)[c] = p_level;
-      st.F(F_OSC_RE)[c] = o_re;
-      st.F(F_OSC_IM)[c] = o_im;
+      st.F(F_OSC_RE)[c] = MIX ? o_re : osc_after[0];
+      st.F(F_OSC_IM)[c] = MIX ? o_im : osc_after[1];
       st.F(F_DC_OFF)[c] = dc;
       { // lock status (FmDecode.cpp:219-228)
         int cnt = st.I(I_P_LOCK_CNT)[c];
@@ -2287,6 +2301,55 @@ __global__ __launch_bounds__(256) void k_halfband4(const float2* __restrict__ in
 /* from where the chain's roll moves them into those history rows.  Stage 0's rows are fetched    */
 /* a step ahead (15 rows per wave and step in registers).                                         */
 /* ------------------------------------------------------------------------------------------ */
+/* The RDS quadrature oscillator of a call (CRDSDownConvert::ProcessData, DownConvert.cpp:436-442): a
+ * recurrence on its own state with an amplitude servo, independent of the signal, started at (1, 0) in
+ * every decoder and advanced by every baseband sample -- so ONE sequence per batch.  One wave computes it
+ * (every lane the same numbers; lane t mod 64 stores entry t), M entries behind H entries of history
+ * (the previous call's last H), and leaves the state behind the call in `uni` and in `after`. */
+__global__ __launch_bounds__(64) void k_rds_osc(float* __restrict__ uni, const float2* __restrict__ prev,
+                                                unsigned prev_M, float2* __restrict__ tab, unsigned M, unsigned H,
+                                                float* __restrict__ after, float osc_cos, float osc_sin)
+{
+  const unsigned lane = threadIdx.x;
+  for (unsigned h = lane; h < H; h += 64)
+    tab[h] = prev[prev_M + h];
+  float o_re = uni[0], o_im = uni[1];
+  for (unsigned t = 0; t < M; t++)
+  {
+    float2 osc;
+    osc.x = o_re * osc_cos - o_im * osc_sin;
+    osc.y = o_im * osc_cos + o_re * osc_sin;
+    const float gn = (float)(1.95 - (double)(o_re * o_re + o_im * o_im));
+    o_re = gn * osc.x;
+    o_im = gn * osc.y;
+    if ((t & 63u) == lane)
+      tab[H + t] = osc;
+  }
+  if (lane == 0)
+  {
+    uni[0] = after[0] = o_re;
+    uni[1] = after[1] = o_im;
+  }
+}
+
+/* Behind a call that wrote no mixed rows: the H rows of history the NEXT call's first half-band stage
+ * finds in front of its input, should that call take a launch per stage (rows M - H .. M - 1 of
+ * baseband x oscillator, as the serial stage's MIX form writes them). */
+__global__ void k_mix_tail(const float2* __restrict__ br_last, const float2* __restrict__ osc_last,
+                           float2* __restrict__ dst, unsigned H, unsigned CP)
+{
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= CP)
+    return;
+  for (unsigned r = blockIdx.y; r < H; r += gridDim.y)
+  {
+    const float v = br_last[(size_t)r * CP + c].x;
+    const float2 o = osc_last[r];
+    const float zero = 0.0f;
+    dst[(size_t)r * CP + c] = make_float2((v * o.x) - (zero * o.y), (v * o.y) + (zero * o.x));
+  }
+}
+
 struct HbStep
 {
   int a_lo, a_n, b_lo, b_n, c_lo, c_n; // outputs of stage 0 / 1 / 2 this step computes (first, count)
@@ -2323,12 +2386,15 @@ __device__ __forceinline__ void hb_rows(LD ld, const HbCoef& hc, float2 (&acc)[R
     rf_acc(acc[r], hc.c[HALF], ld(2 * r + HALF));
 }
 
-template <int H0, int H1, int H2>
+/* OSC: stage 0's input rows are not the mixed rows but (baseband, -) rows, and row r meets the RDS
+ * oscillator's value osc[r] on its way into the sum -- (v osc.x - 0 osc.y, v osc.y + 0 osc.x) like
+ * CRDSDownConvert::ProcessData writes it (DownConvert.cpp:464-465; the input's imaginary part is zero). */
+template <int H0, int H1, int H2, bool OSC = false>
 __global__ __launch_bounds__(256) void k_halfband_chain(
     const float2* __restrict__ mix, const float2* __restrict__ hist1, const float2* __restrict__ hist2,
     float2* __restrict__ out, unsigned Hout, float2* __restrict__ tail1, float2* __restrict__ tail2,
     HbCoef hc0, HbCoef hc1, HbCoef hc2, const HbStep* __restrict__ steps, const int* __restrict__ seg_first,
-    unsigned n_in, unsigned n0, unsigned n1, unsigned C, unsigned CP)
+    unsigned n_in, unsigned n0, unsigned n1, unsigned C, unsigned CP, const float2* __restrict__ osc)
 {
   __shared__ float2 ring1[HBF_RING][64]; // stage 0's outputs, row i0 (>= -2 H1: history) at slot i0 & 63
   __shared__ float2 ring2[HBF_RING][64]; // stage 1's outputs
@@ -2388,7 +2454,19 @@ __global__ __launch_bounds__(256) void k_halfband_chain(
       if (nr > 0)
       {
         float2 acc[4];
-        hb_rows<4, H0>([&](int row) { return (row & 1) ? x[4 + H0 + (row - H0) / 2] : x[row / 2]; }, hc0, acc);
+        hb_rows<4, H0>(
+            [&](int row) {
+              const float2 v = (row & 1) ? x[4 + H0 + (row - H0) / 2] : x[row / 2];
+              if constexpr (!OSC)
+                return v;
+              else
+              {
+                const float2 o = osc[min(2 * k0 + row, 2 * H0 + (int)n_in - 1)]; // wave-uniform: a scalar load
+                const float zero = 0.0f;
+                return make_float2((v.x * o.x) - (zero * o.y), (v.x * o.y) + (zero * o.x));
+              }
+            },
+            hc0, acc);
 #pragma unroll
         for (int r = 0; r < 4; r++)
           if (r < nr)

@@ -18,17 +18,24 @@ def _bits_equal(a, b):
     return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-@pytest.mark.parametrize("fs,D,sizes,alternate", [
-    (2.4e6, 11, [N] * 6 + [40000, 3000, 65535, 2000, 50001, N], False),  # 15 / 23 / 43 taps
-    (2.4e6, 11, [N, 30000, N, N, 1500, N, 65533, N], True),              # fused and per-stage calls in turn
-    (1.0e6, 4, [N] * 4 + [30000, 1200, 65535, N], False),                # 15 / 19 / 35 taps
-    (10e6, 46, [N] * 4, False),
+@pytest.mark.parametrize("fs,D,sizes,alternate,nomix", [
+    (2.4e6, 11, [N] * 6 + [40000, 3000, 65535, 2000, 50001, N], False, 1),  # 15 / 23 / 43 taps
+    (2.4e6, 11, [N, 30000, N, N, 1500, N, 65533, N], True, 1),              # fused and per-stage calls in turn
+    (2.4e6, 11, [N, 30000, N, N, 1500, N, 65533, N], True, 0),              # ... with the serial stage writing the mixed rows
+    (1.0e6, 4, [N] * 4 + [30000, 1200, 65535, N], False, 1),                # 15 / 19 / 35 taps
+    (10e6, 46, [N] * 4, False, 1),
 ])
-def test_fused_chain_rds_taps_bit_exact(oracle, fmsig, fs, D, sizes, alternate):
+def test_fused_chain_rds_taps_bit_exact(oracle, fmsig, fs, D, sizes, alternate, nomix):
+    """nomix = 1 (what large batches run): the serial stage writes no mixed rows, the chain multiplies the
+    baseband with the batch-wide oscillator sequence (k_rds_osc) itself; calls that take a launch per stage
+    in between (the alternating case, the 1500- and 3000-sample calls) read mixed rows again and must find
+    the rows of history and the per-channel oscillator state the other form left for them."""
     pkg = load_package()
     p = fmsig.default_params(fs, noise_sigma=0.01, seed=41)
     o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
     b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 1)
+    b.debug_set("halfband_chain", 1)  # before the first call: starts the oscillator sequence too
+    b.debug_set("nomix", nomix)
     b.enable_taps()
     pos = 0
     for blk, n in enumerate(sizes):

@@ -3,7 +3,8 @@
 and random call sizes through the HIP path and the CPU oracle, bit for bit.  Exercises the launch
 code's choices (tile size, window layout E = 0 / 1 / 2, load depth, power-of-two and '%' tuner
 paths, hand-scheduled loops, short-block regimes) on shapes no fixed test names.
-usage: fuzz_geometries.py [trials] [seed]"""
+usage: fuzz_geometries.py [trials] [seed] [force]     (force = 1: the large-batch forms of resampler and
+half-band chain -- k_resample_ring, k_halfband_chain -- wherever the geometry allows them)"""
 import os
 import sys
 
@@ -17,6 +18,8 @@ from tools import fmsig_py  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+FORCE = len(sys.argv) > 3 and sys.argv[3] == "1"
+forced = 0
 rng = np.random.default_rng(SEED)
 pkg = load_package()
 bad = 0
@@ -39,6 +42,13 @@ for trial in range(T):
     except pkg.FmdError as e:
         print("trial %d fs %.0f D %d order %d table %d: rejected at create (%s)" % (trial, fs, D, order, table, e))
         continue
+    if FORCE:
+        b.debug_set("halfband_chain", 1)
+        try:
+            b.debug_set("resampler", 1)
+            forced += 1
+        except pkg.FmdError:
+            pass  # no form of the ring resampler fits this geometry's window
     o = oracle_py.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D, **kw)
     p = fmsig_py.default_params(fs, noise_sigma=0.01, seed=100 + trial)
     nmin = b.min_samples()
@@ -59,5 +69,5 @@ for trial in range(T):
     bad += 0 if ok else 1
     done += 1
     b.close()
-print("fuzz: %d geometries, %d with a mismatch" % (done, bad))
+print("fuzz: %d geometries (%d with the ring resampler forced), %d with a mismatch" % (done, forced, bad))
 sys.exit(1 if bad else 0)

@@ -2,7 +2,8 @@
 """Soak: many differently impaired stations (detuned, weak, noisy, over-deviated, silent, DC, clipping)
 through the HIP batch path and through the CPU oracle, block by block, bit for bit.  Looks for
 rare-path divergences (literal arctangent / phase-wrap fallbacks, PLL slips, RDS sync loss and
-FEC) that the fixed test signals may never reach.  usage: soak.py [channels] [blocks] [seed]"""
+FEC) that the fixed test signals may never reach.  usage: soak.py [channels] [blocks] [seed] [force]
+(force = 1: the large-batch forms of resampler and half-band chain, k_resample_ring / k_halfband_chain)"""
 import os
 import sys
 
@@ -41,6 +42,9 @@ for c in range(C):
     params.append(fmsig_py.default_params(fs, **kw))
 pkg = load_package()
 b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C)
+if len(sys.argv) > 4 and sys.argv[4] == "1":
+    b.debug_set("resampler", 1)
+    b.debug_set("halfband_chain", 1)
 refs = [oracle_py.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for _ in range(C)]
 bad = 0
 sizes = [N] * NBLK
