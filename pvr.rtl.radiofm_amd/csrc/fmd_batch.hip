@@ -112,7 +112,7 @@ struct fmd_batch
   unsigned lastM = 0, lastA = 0, lastR = 0;
 
   // device memory
-  DevBuf<float2> lut, hist[2], demod[2], br[2], mix[2], rdsraw, rlpf[2], rs, alp[2];
+  DevBuf<float2> lut, hist[2], demod[2], br[2], mix[2], rdsraw[2], rlpf[2], rs[2], alp[2];
   std::vector<DevBuf<float2>> hbbuf; // input buffers of stages 1..n-1 (stage 0 reads mix)
   DevBuf<float> if_coeff, rs_coeff, rds_lpf_taps, mf_taps2, audio_taps, ktab;
   DevBuf<float> rpll, rmf, tap_sync;
@@ -216,7 +216,7 @@ struct fmd_batch
   //   concurrency 2: as 1, but the caller's stream is only ordered after a call by fmd_batch_wait /
   //                  fmd_batch_collect_rds; lets call k+1's FIR overlap call k's serial stages
   int concurrency = 1;
-  hipStream_t s_fir = nullptr, s_ser = nullptr, s_post = nullptr, s_rds = nullptr;
+  hipStream_t s_fir = nullptr, s_ser = nullptr, s_post = nullptr, s_rds = nullptr, s_lpf = nullptr;
   // What the light part of a call's post chain (RDS PLL, matched filter, bit recovery, audio tail)
   // needs to know about its call: see launch_light.
   struct LightJob
@@ -231,7 +231,7 @@ struct fmd_batch
   };
   bool split_post = false;
   bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
-  enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_RDSH, EV_ALP, EV_N };
+  enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_RDSH, EV_ALP, EV_DEC, EV_N };
   hipEvent_t cev[NSLOT][EV_N] = {};
   bool cev_ready = false;
   uint32_t slot_call[NSLOT] = {}; // call index that last used the slot (0 = never)
@@ -265,10 +265,12 @@ struct fmd_batch
     demod[1].release();
     mix[0].release();
     mix[1].release();
-    rdsraw.release();
+    rdsraw[0].release();
+    rdsraw[1].release();
     rlpf[0].release();
     rlpf[1].release();
-    rs.release();
+    rs[0].release();
+    rs[1].release();
     alp[0].release();
     alp[1].release();
     for (auto& b : hbbuf)
@@ -327,6 +329,8 @@ struct fmd_batch
       (void)hipStreamDestroy(s_post);
       if (s_rds)
         (void)hipStreamDestroy(s_rds);
+      if (s_lpf)
+        (void)hipStreamDestroy(s_lpf);
     }
     h_iq.release();
     h_audio.release();
@@ -490,7 +494,8 @@ int do_reset(fmd_batch* b)
     if (hipMemset(s.I(slot), 0, CP * sizeof(int)) != hipSuccess)
       return -1;
   // RDS LPF ring (history rows of rdsraw), matched filter ring, positions
-  if (zero_rows(b->rdsraw.p, b->des.rds_lpf_taps.size() - 1, CP))
+  if (zero_rows(b->rdsraw[0].p, b->des.rds_lpf_taps.size() - 1, CP) ||
+      zero_rows(b->rdsraw[1].p, b->des.rds_lpf_taps.size() - 1, CP))
     return -1;
   if (zero_rows(b->rpll.p, b->des.rds_mf_taps.size() - 1, CP))
     return -1;
@@ -820,13 +825,17 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
       bad |= upload(b->osc_uni.p, one_zero, sizeof one_zero);
     b->osc_on = CP / 64 >= 64 && d.hb[0].len - 1 <= int(fmd_batch::kOscH);
   }
-  bad |= b->rdsraw.alloc(size_t(T_lpf - 1 + b->Rmax) * CP);
+  // (the inputs of the two low-pass filters by call parity too, history rows in front: the decimator /
+  // resampler of the next call does not wait for this call's low-pass)
+  bad |= b->rdsraw[0].alloc(size_t(T_lpf - 1 + b->Rmax) * CP);
+  bad |= b->rdsraw[1].alloc(size_t(T_lpf - 1 + b->Rmax) * CP);
   bad |= b->rlpf[0].alloc(size_t(b->Rmax) * CP);
   bad |= b->rlpf[1].alloc(size_t(b->Rmax) * CP);
   bad |= b->rpll.alloc(size_t(T_mf - 1 + b->Rmax) * CP);
   bad |= b->rmf.alloc(size_t(b->Rmax) * CP);
   bad |= b->tap_sync.alloc(size_t(b->Rmax) * CP);
-  bad |= b->rs.alloc(size_t(T_alp - 1 + b->Amax) * CP);
+  bad |= b->rs[0].alloc(size_t(T_alp - 1 + b->Amax) * CP);
+  bad |= b->rs[1].alloc(size_t(T_alp - 1 + b->Amax) * CP);
   bad |= b->alp[0].alloc(size_t(b->Amax) * CP);
   bad |= b->alp[1].alloc(size_t(b->Amax) * CP);
   bad |= b->rds_lpf_taps.alloc(T_lpf);
@@ -922,9 +931,9 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     // post chain has slack every call and goes last
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi)); // lo = least, hi = greatest priority
-    // (the two heavy chains side by side on a fifth stream: measured slower in rounds 1-3, removed; every
-    // extra stream competes for the few hardware queues, GPU_MAX_HW_QUEUES)
-    const int nstreams = 4;
+    // (the two heavy chains side by side on a fifth stream: measured slower in rounds 1-3, removed.)  The
+    // fifth stream carries the post chain's two low-pass filters: see lpf_late in process_device_impl
+    const int nstreams = 5;
     // (the light chain's stream at the high priority too: measured twice, no difference)
     const int prio[5] = {hi, hi, lo, lo, lo};
     hipStream_t st4[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -934,6 +943,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     b->s_ser = st4[1];
     b->s_post = st4[2];
     b->s_rds = st4[3];
+    b->s_lpf = st4[4];
     // RDS chain and audio chain behind the serial stage are independent.  With more channels than
     // the chip holds serial-stage workgroups (256 CUs x 64 channels) the batch is throughput-bound
     // and they run side by side on two streams (+10 % at 24 576, +12 % at 32 768 channels); below
@@ -1555,12 +1565,17 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     roll_hmax = 1;
   };
   /* Default overlapped mode: the two low-pass filters of the post chain (0.1 ms each at 8192 channels, a few
-   * hundred small workgroups) go to the END of the heavy stream's work for the call, behind EV_HEAVY: the next
-   * IF FIR, which waits for EV_HEAVY, then runs beside them instead of behind them, and the half-band chain
-   * and the resampler follow each other directly.  The light part waits for its low-pass (EV_RDSH is recorded
-   * behind the RDS one, EV_ALP behind the audio one). */
-  const bool lpf_late = !serial_mode && !b->split_post && b->dbg_lpf_late != 0;
+   * hundred small workgroups) run on a stream of their own, each behind the kernel that feeds it (EV_DEC: the
+   * decimator; EV_HEAVY: the resampler).  On the heavy stream they stood between the half-band chain and the
+   * resampler and in front of the next IF FIR -- 0.2 ms of every period with most of the 192 CUs idle; and
+   * behind EV_HEAVY on that stream they were in the next call's way (the IF FIR, at the high priority, kept
+   * them from running beside it: they ran when it had ended, in front of the half-band chain).  Their
+   * inputs (rdsraw, rs) are buffered by call parity so that the next call's decimator / resampler need not
+   * wait for them.  The light part waits for its low-pass (EV_RDSH behind the RDS one, EV_ALP behind the
+   * audio one). */
+  const bool lpf_late = !serial_mode && !b->split_post && b->dbg_lpf_late != 0 && b->s_lpf;
   std::function<void()> rds_lpf_late, audio_lpf_late;
+  hipStream_t sLPr = lpf_late ? b->s_lpf : sR, sLPa = lpf_late ? b->s_lpf : sA;
   auto rds_heavy = [&]() {
     /* ---- RDS branch  (stream R): half-bands, 75-tap LPF, PLL, matched filter, bits ---- */
     after(sR, ce[fmd_batch::EV_SER]);
@@ -1583,13 +1598,13 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                                 : (nomix ? &fmd::k_halfband_chain<7, 9, 17, true> : &fmd::k_halfband_chain<7, 9, 17, false>);
       if (evset && b->profiling == 1 && !serial_mode) // its own start and stop (fmd_batch_debug_timeline)
         hipExtLaunchKernelGGL(kern, dim3(groups, pl->S), dim3(64, 4), 0u, sR, evset[6], evset[7], 0u, in0,
-                              (const float2*)b->hbbuf[0].p, (const float2*)b->hbbuf[1].p, b->rdsraw.p, T_lpf - 1,
+                              (const float2*)b->hbbuf[0].p, (const float2*)b->hbbuf[1].p, b->rdsraw[q].p, T_lpf - 1,
                               b->hbf_tail1.p, b->hbf_tail2.p, b->hbcoef[0], b->hbcoef[1], b->hbcoef[2],
                               (const fmd::HbStep*)pl->steps.p, (const int*)pl->seg_first.p, hb_in[0], n0, n1, C, CP,
                               osc);
       else
         hipLaunchKernelGGL(kern, dim3(groups, pl->S), dim3(64, 4), 0, sR, in0, (const float2*)b->hbbuf[0].p,
-                           (const float2*)b->hbbuf[1].p, b->rdsraw.p, T_lpf - 1, b->hbf_tail1.p, b->hbf_tail2.p,
+                           (const float2*)b->hbbuf[1].p, b->rdsraw[q].p, T_lpf - 1, b->hbf_tail1.p, b->hbf_tail2.p,
                            b->hbcoef[0], b->hbcoef[1], b->hbcoef[2], (const fmd::HbStep*)pl->steps.p,
                            (const int*)pl->seg_first.p, hb_in[0], n0, n1, C, CP, osc);
       if (nomix) // the next call's stage-0 history, should it take a launch per stage (it reads mixed rows)
@@ -1611,7 +1626,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
         const unsigned n_out =
             (d.hb[s].len == 11 || hb_mode[s] == HB_PASS) ? hb_in[s] / 2 : (hb_in[s] + 1) / 2;
         const bool last = (s + 1 == d.hb.size());
-        float2* outp = last ? b->rdsraw.p : b->hbbuf[s].p;
+        float2* outp = last ? b->rdsraw[q].p : b->hbbuf[s].p;
         const unsigned Hout = last ? (T_lpf - 1) : unsigned(d.hb[s + 1].len - 1);
         const int hb4 = b->dbg_hb4;
         const unsigned Hs = unsigned(d.hb[s].len - 1);
@@ -1658,19 +1673,19 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     const int ring4 = b->dbg_ring4;
     if (ring4 && T_lpf >= unsigned(fmd::RG))
       hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
-                         sR, b->rdsraw.p, b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C,
+                         sLPr, b->rdsraw[q].p, b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C,
                          CP, 0u);
     else
     hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
-                       size_t(T_lpf - 1 + fmd::RF_TI) * 64 * sizeof(float2), sR, b->rdsraw.p,
+                       size_t(T_lpf - 1 + fmd::RF_TI) * 64 * sizeof(float2), sLPr, b->rdsraw[q].p,
                        b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C, CP, 0u);
     if (hb_all_normal)
     {
-      roll_later(b->rdsraw.p, b->rdsraw.p, T_lpf - 1, R);
-      roll_flush(sR);
+      roll_later(b->rdsraw[q].p, b->rdsraw[q ^ 1].p, T_lpf - 1, R);
+      roll_flush(sLPr);
     }
     else
-      hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, sR, b->rdsraw.p, b->rdsraw.p, T_lpf - 1, R, CP);
+      hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, sLPr, b->rdsraw[q].p, b->rdsraw[q ^ 1].p, T_lpf - 1, R, CP);
     };
     if (lpf_late)
     { // what the decimator left to roll goes now; the low-pass later (see above)
@@ -1740,11 +1755,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
           hipExtLaunchKernelGGL(kern, dim3(groups, S), dim3(64, b->rsr_NW + 1), lds, sA, evset[8], evset[9], 0u,
                                 (const float2*)b->brp(q), Hbb, b->rsr_rb, d.rs_order, (const float*)b->rsr_tab.p,
                                 b->rsr_nbm, (const int*)b->rsr_head.p, (const int*)b->rsr_steps.p, rs_steps, per_seg,
-                                b->rsr_nbr, A, b->rs.p, T_alp - 1, C, CP, b->rsr_exp, b->rsr_pace);
+                                b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, b->rsr_exp, b->rsr_pace);
         else
         hipLaunchKernelGGL(kern, dim3(groups, S), dim3(64, b->rsr_NW + 1), lds, sA, b->brp(q), Hbb, b->rsr_rb,
                            d.rs_order, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p, rs_steps, per_seg,
-                           b->rsr_nbr, A, b->rs.p, T_alp - 1, C, CP, b->rsr_exp, b->rsr_pace);
+                           b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, b->rsr_exp, b->rsr_pace);
       };
       if (b->rsr_R == 4)
         go(&fmd::k_rs_plan<4, 4>, &fmd::k_resample_ring<4, 4>);
@@ -1759,7 +1774,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                          pstep, A, b->ktab.p, b->rs_row, b->rs_margin, b->pidx.p);
       hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
                          dim3(64, 4), 0, sA, b->brp(q), Hbb, d.rs_order, b->ktab.p, b->rs_row,
-                         b->rs_margin, b->pidx.p, A, b->rs.p, T_alp - 1, C, CP);
+                         b->rs_margin, b->pidx.p, A, b->rs[q].p, T_alp - 1, C, CP);
     }
     roll_later(b->brp(q), b->brp(q ^ 1), Hbb, M); // with the low-pass's own roll, at the chain's end
     mark(6);
@@ -1767,13 +1782,13 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     const int ring4a = b->dbg_ring4;
     if (ring4a && T_alp >= unsigned(fmd::RG))
       hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (A + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
-                         sA, b->rs.p, b->alp[q].p, A, int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
+                         sLPa, b->rs[q].p, b->alp[q].p, A, int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
     else
     hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (A + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
-                       size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), sA, b->rs.p, b->alp[q].p, A,
+                       size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), sLPa, b->rs[q].p, b->alp[q].p, A,
                        int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
-    roll_later(b->rs.p, b->rs.p, T_alp - 1, A);
-    roll_flush(sA);
+    roll_later(b->rs[q].p, b->rs[q ^ 1].p, T_alp - 1, A);
+    roll_flush(sLPa);
     };
     if (lpf_late)
     {
@@ -1821,17 +1836,29 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       after(sP, pe2[fmd_batch::EV_RDS]);
       after(sA, pe2[fmd_batch::EV_AUD]);
     }
+    if (lpf_late && have_prev2)
+    { // rdsraw[q] / rs[q] are written again: their low-pass filters of two calls ago have read them
+      after(sP, pe2[fmd_batch::EV_RDSH]);
+      after(sP, pe2[fmd_batch::EV_ALP]);
+    }
     rds_heavy();
-    if (!lpf_late)
-      signal(ce[fmd_batch::EV_RDSH], sR);
+    signal(ce[lpf_late ? fmd_batch::EV_DEC : fmd_batch::EV_RDSH], sR);
     audio_heavy();
     signal(ce[fmd_batch::EV_HEAVY], sP);
     if (lpf_late)
-    { // the two low-pass filters: beside the IF FIR that EV_HEAVY has just let go
+    { // the two low-pass filters on their own stream
+      hipStream_t sl = b->s_lpf;
+      if (have_prev2)
+      { // rlpf[q] / alp[q] were last read by the light part of two calls ago
+        after(sl, pe2[fmd_batch::EV_RDS]);
+        after(sl, pe2[fmd_batch::EV_AUD]);
+      }
+      after(sl, ce[fmd_batch::EV_DEC]);
       rds_lpf_late();
-      signal(ce[fmd_batch::EV_RDSH], sP);
+      signal(ce[fmd_batch::EV_RDSH], sl);
+      after(sl, ce[fmd_batch::EV_HEAVY]);
       audio_lpf_late();
-      signal(ce[fmd_batch::EV_ALP], sP);
+      signal(ce[fmd_batch::EV_ALP], sl);
     }
     fmd_batch::LightJob job;
     job.R = R;
@@ -2376,7 +2403,7 @@ int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsig
     }
     case FMD_TAP_MONO_RS:
     case FMD_TAP_STEREO_RS:
-      src = reinterpret_cast<const float*>(b->rs.p) + (tap == FMD_TAP_MONO_RS ? 1 : 0);
+      src = reinterpret_cast<const float*>(b->rs[b->call_index & 1u].p) + (tap == FMD_TAP_MONO_RS ? 1 : 0);
       esize = 4;
       first_row = T_alp - 1;
       rows = b->lastA;
