@@ -142,14 +142,22 @@ struct fmd_batch
   std::vector<std::unique_ptr<HbfPlan>> hbf_plans;
   DevBuf<float2> hbf_tail1, hbf_tail2;
   int hbf_mode = -1;
-  /* The RDS oscillator as one sequence per batch (k_rds_osc), for calls whose serial stage writes no mixed
-   * rows (k_demod_serial<.., MIX = false> + k_halfband_chain<.., OSC>): tables of four calls in rotation
-   * (a call's table is read by its half-band chain, two serial stages later), kOscH entries of history in
-   * front; the state behind the newest call, and behind each of the last four calls.  osc_on: the kernel
-   * runs every call (large batches from creation; "halfband_chain" = 1 before the first call). */
+  /* The RDS oscillator (CRDSDownConvert::ProcessData, DownConvert.cpp:436-442) as one sequence per batch,
+   * for calls whose serial stage writes no mixed rows (k_demod_serial<.., MIX = false> +
+   * k_halfband_chain<.., OSC>): a recurrence on its own state with an amplitude servo, independent of the
+   * signal, started at (1, 0) in every decoder and advanced by every baseband sample.  The HOST computes a
+   * call's M values while it submits the call (~60 us of one core; a lone GPU wave takes 0.37 ms for the
+   * same dependent chain, on a stream the IF FIR needs), in page-locked staging (8 slots) that an
+   * asynchronous copy takes to the device tables (4 in rotation: a call's table is read by its half-band
+   * chain, two serial stages later), kOscH entries of history in front.  osc_on: every call (large batches
+   * from creation; "halfband_chain" = 1 before the first call). */
   static constexpr unsigned kOscH = 64;
   DevBuf<float2> osc_tab[4];
-  DevBuf<float> osc_uni, osc_after;
+  float2* h_osc = nullptr;       // [NSLOT][kOscH + Mmax + 8], page-locked
+  hipEvent_t osc_ev[8] = {}; // [NSLOT] behind the copy out of a staging slot
+  bool osc_ev_used[8] = {};
+  size_t h_osc_stride = 0;
+  float osc_re = 1.0f, osc_im = 0.0f; // CRDSDownConvert: m_Osc1 = (1, 0) (DownConvert.cpp:284)
   bool osc_on = false;
   int dbg_nomix = 1;
   // development switches (fmd_batch_debug_set; the library reads no environment variable)
@@ -159,7 +167,7 @@ struct fmd_batch
   int dbg_post_delay_us = 20;  // the post chain starts this long behind the serial stage's end
   int dbg_hb4 = 1, dbg_ring4 = 1; // 0: the generic half-band / ring-FIR kernels where the unrolled ones would run
   int dbg_prof_dump = 0;
-  int dbg_lpf_late = 1;        // the post chain's two low-pass filters behind EV_HEAVY (beside the next IF FIR)
+  int dbg_lpf_late = -1;       // the post chain's two low-pass filters on their own stream: -1 the library decides
   // where a host-buffer call's time goes (fmd_batch_debug_host_ms): copy in, submission, wait + copy
   // out, RDS collection + group decoder callbacks; sums since the last query
   double host_ms[4] = {0, 0, 0, 0};
@@ -169,6 +177,7 @@ struct fmd_batch
   DevBuf<int> istate;
   DevBuf<uint16_t> r_data;
   static constexpr int NSLOT = 8; // event sets / RDS queues in rotation (call_index % NSLOT)
+  static_assert(NSLOT == 8, "osc_ev / osc_ev_used above");
   DevBuf<fmd::RdsGroupRec> queue[NSLOT]; // never drained while a call that appends to it is in flight
   DevBuf<unsigned> queue_counts; // [NSLOT], contiguous: one copy reads them all
   unsigned* qcount(int q) const { return queue_counts.p + q; }
@@ -293,8 +302,11 @@ struct fmd_batch
     hbf_tail2.release();
     for (auto& t : osc_tab)
       t.release();
-    osc_uni.release();
-    osc_after.release();
+    if (h_osc)
+      (void)hipHostFree(h_osc);
+    for (auto e : osc_ev)
+      if (e)
+        (void)hipEventDestroy(e);
     rsr_head.release();
     rsr_steps.release();
     rpll.release();
@@ -818,11 +830,13 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     bad |= b->hbf_tail2.alloc(size_t(d.hb[2].len - 1) * CP);
     for (auto& t : b->osc_tab)
       bad |= t.alloc(size_t(fmd_batch::kOscH) + b->Mmax + 8);
-    bad |= b->osc_uni.alloc(2);
-    bad |= b->osc_after.alloc(8);
-    const float one_zero[2] = {1.0f, 0.0f}; // CRDSDownConvert: m_Osc1 = (1, 0) (DownConvert.cpp:284)
+    b->h_osc_stride = size_t(fmd_batch::kOscH) + b->Mmax + 8;
+    bad |= hipHostMalloc(reinterpret_cast<void**>(&b->h_osc), fmd_batch::NSLOT * b->h_osc_stride * sizeof(float2),
+                         hipHostMallocDefault) != hipSuccess;
     if (!bad)
-      bad |= upload(b->osc_uni.p, one_zero, sizeof one_zero);
+      std::memset(b->h_osc, 0, fmd_batch::NSLOT * b->h_osc_stride * sizeof(float2));
+    for (auto& e : b->osc_ev)
+      bad |= hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess;
     b->osc_on = CP / 64 >= 64 && d.hb[0].len - 1 <= int(fmd_batch::kOscH);
   }
   // (the inputs of the two low-pass filters by call parity too, history rows in front: the decimator /
@@ -1417,14 +1431,35 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     }
   }
   // ... and then the serial stage writes no mixed rows: the chain multiplies the baseband with the
-  // oscillator's sequence itself (k_rds_osc, one per batch and call, here on the IF stream: long before
-  // anything needs it)
+  // oscillator's sequence itself (computed here, once per batch and call, and copied over on the IF stream:
+  // long before anything needs it)
   const bool nomix = hbf_pl != nullptr && b->osc_on && b->dbg_nomix != 0;
   const unsigned osc_slot = ci & 3u;
+  float osc_re = b->osc_re, osc_im = b->osc_im; // committed with the positions, at the end
   if (b->osc_on)
-    hipLaunchKernelGGL(fmd::k_rds_osc, dim3(1), dim3(64), 0, sF, b->osc_uni.p, b->osc_tab[(ci + 3u) & 3u].p, b->lastM,
-                       b->osc_tab[osc_slot].p, M, fmd_batch::kOscH, b->osc_after.p + 2 * osc_slot, d.rds_osc_cos,
-                       d.rds_osc_sin);
+  {
+    // the staging slot was last read by the copy of the call 8 calls ago: complete unless the caller has
+    // submitted eight calls without ever waiting
+    if (b->osc_ev_used[es])
+      note(hipEventSynchronize(b->osc_ev[es]));
+    float2* h = b->h_osc + size_t(es) * b->h_osc_stride;
+    const float2* hp = b->h_osc + size_t((ci + fmd_batch::NSLOT - 1) % fmd_batch::NSLOT) * b->h_osc_stride;
+    std::memcpy(h, hp + b->lastM, fmd_batch::kOscH * sizeof(float2)); // the previous call's last entries
+    const float oc = d.rds_osc_cos, os = d.rds_osc_sin;
+    float2* o = h + fmd_batch::kOscH;
+    for (unsigned t = 0; t < M; t++)
+    { // the statements of k_demod_serial's MIX form (this file is compiled with -ffp-contract=off too)
+      const float x = osc_re * oc - osc_im * os;
+      const float y = osc_im * oc + osc_re * os;
+      const float gn = float(1.95 - double(osc_re * osc_re + osc_im * osc_im));
+      osc_re = gn * x;
+      osc_im = gn * y;
+      o[t] = make_float2(x, y);
+    }
+    note(hipMemcpyAsync(b->osc_tab[osc_slot].p, h, (fmd_batch::kOscH + M) * sizeof(float2), hipMemcpyHostToDevice, sF));
+    note(hipEventRecord(b->osc_ev[es], sF));
+    b->osc_ev_used[es] = true;
+  }
 
   /* ---- K1: tuner + IF decimating FIR  (stream F) ---- */
   signal(ce[fmd_batch::EV_IN], stream);
@@ -1502,26 +1537,26 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     auto kser2 = nomix ? (serial_claim ? &fmd::k_demod_serial<2, true, false> : &fmd::k_demod_serial<2, false, false>)
                        : (serial_claim ? &fmd::k_demod_serial<2, true, true> : &fmd::k_demod_serial<2, false, true>);
     auto kser1 = nomix ? &fmd::k_demod_serial<1, false, false> : &fmd::k_demod_serial<1, false, true>;
-    const float* osc_after = b->osc_after.p ? b->osc_after.p + 2 * osc_slot : nullptr;
+
     if (b->serial_exclusive && !serial_mode && evset && b->profiling == 1)
       // profiling level 1: the stage's own start and stop too (fmd_batch_debug_timeline)
       hipExtLaunchKernelGGL(kser2, dim3((groups + 1) / 2), dim3(256), 0u, sS, evset[2],
                             evset[3], 0u, (const float2*)b->demod[q].p, b->Mstride, M, C, CP, k, b->st,
                             b->brp(q), Hbb, b->mix[q].p, Hmix,
                             (const double*)(b->sctab256.p), sct, unsigned(sq),
-                            (long long*)nullptr, osc_after);
+                            (long long*)nullptr, osc_re, osc_im);
     else if (b->serial_exclusive && !serial_mode)
       hipLaunchKernelGGL(kser2, dim3((groups + 1) / 2), dim3(256), 0, sS,
                          (const float2*)b->demod[q].p, b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p,
                          Hmix, (const double*)b->sctab256.p, sct, unsigned(sq),
                          b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : (long long*)nullptr,
-                         osc_after);
+                         osc_re, osc_im);
     else
       hipLaunchKernelGGL(kser1, dim3(groups), dim3(128), 0, sS, (const float2*)b->demod[q].p,
                          b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p, Hmix,
                          (const double*)b->sctab256.p, sct, unsigned(sq),
                          b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : (long long*)nullptr,
-                         osc_after);
+                         osc_re, osc_im);
   }
   signal(ce[fmd_batch::EV_SER], sS);
   mark(2);
@@ -1573,7 +1608,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
    * inputs (rdsraw, rs) are buffered by call parity so that the next call's decimator / resampler need not
    * wait for them.  The light part waits for its low-pass (EV_RDSH behind the RDS one, EV_ALP behind the
    * audio one). */
-  const bool lpf_late = !serial_mode && !b->split_post && b->dbg_lpf_late != 0 && b->s_lpf;
+  /* Only where the two loops of the pipeline are balanced (short IF filters): with a long IF filter the FIR
+   * alone sets the period and the fifth stream only gets in its way (config 5: 3.41 ms per call with it,
+   * 3.16 without -- its head waits for events in a hardware queue the FIR's stream shares). */
+  const bool lpf_late = !serial_mode && !b->split_post && b->s_lpf &&
+                        (b->dbg_lpf_late > 0 || (b->dbg_lpf_late < 0 && d.if_order <= 512));
   std::function<void()> rds_lpf_late, audio_lpf_late;
   hipStream_t sLPr = lpf_late ? b->s_lpf : sR, sLPa = lpf_late ? b->s_lpf : sA;
   auto rds_heavy = [&]() {
@@ -1909,6 +1948,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   b->if_pos = pos + M * D - N;                      // DownConvert.cpp:132
   b->lut_idx = (b->lut_idx + N) % d.table_size;     // FmDecode.cpp:81
   b->rs_pos = new_rs_pos;                           // DownConvert.cpp:230-232
+  b->osc_re = osc_re;                               // DownConvert.cpp:440-441 (batch-wide, see osc_on)
+  b->osc_im = osc_im;
   b->rds_lpf_g = (b->rds_lpf_g + R) % T_lpf;
   b->mf_g = (b->mf_g + R) % T_mf;
   b->alpf_g = (b->alpf_g + A) % T_alp;
@@ -2030,7 +2071,7 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
   else if (k == "ring4")
     b->dbg_ring4 = value != 0;
   else if (k == "lpf_late")
-    b->dbg_lpf_late = value != 0;
+    b->dbg_lpf_late = value < 0 ? -1 : (value ? 1 : 0);
   else if (k == "prof_dump")
     b->dbg_prof_dump = value != 0;
   else if (k == "serial_probe")
@@ -2046,7 +2087,7 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
     b->hbf_mode = value < 0 ? -1 : (value ? 1 : 0);
     // before the first call a small batch can still start the batch-wide oscillator sequence (and with it
     // the form of the serial stage that writes no mixed rows); later its chain reads mixed rows
-    if (value > 0 && b->call_index == 0 && b->osc_uni.p && b->des.hb.size() == 3 &&
+    if (value > 0 && b->call_index == 0 && b->h_osc && b->des.hb.size() == 3 &&
         b->des.hb[0].len - 1 <= int(fmd_batch::kOscH))
       b->osc_on = true;
   }

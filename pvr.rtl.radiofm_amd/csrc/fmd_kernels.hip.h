@@ -1611,17 +1611,18 @@ constexpr unsigned FM_UNROLL = 4; // samples per trip of the FM wave's loop over
 
 /* MIX = false (large batches, where k_halfband_chain follows): the stage neither runs the RDS oscillator nor
  * writes the mixed rows.  The oscillator (DownConvert.cpp:436-442) is a recurrence on its own state only
- * -- the same numbers for every channel of a batch (k_rds_osc computes them once per call) -- and the
+ * -- the same numbers for every channel of a batch (the host computes them once per call, rds_osc_table
+ * in fmd_batch.hip) -- and the
  * product with the baseband is made where it is consumed (k_halfband_chain<.., true>): one store per
  * sample instead of two, ~20 instructions per sample less in the second role wave, 0.39 GB per call less
- * (8192 channels).  `osc_after` = the oscillator state behind this call (from k_rds_osc): the per-channel
- * copy that the MIX = true form keeps in registers is brought up to date from it. */
+ * (8192 channels).  `osc_after_*` = the oscillator state behind this call: the per-channel copy that the
+ * MIX = true form keeps in registers is brought up to date from it. */
 template <int NG, bool EXCL, bool MIX = true>
 __global__ __launch_bounds__(128 * NG) void k_demod_serial(
     const float2* __restrict__ demod, unsigned Mstride, unsigned M, unsigned C, unsigned CP,
     DemodConsts k, ChannelState st, float2* __restrict__ br, unsigned Hbb,
     float2* __restrict__ mix, unsigned Hmix, const double* __restrict__ sctab_g, FmdSincosTab sct,
-    unsigned stereo_q, long long* __restrict__ wg_probe, const float* __restrict__ osc_after)
+    unsigned stereo_q, long long* __restrict__ wg_probe, float osc_after_re, float osc_after_im)
 {
   // sctab_g: (sin, cos)(k / 256), 2048 entries (fmd_sincos_p256)
   // dev aid ("serial_probe" of fmd_batch_debug_set): when each workgroup started and ended on the
@@ -2021,8 +2022,8 @@ __global__ __launch_bounds__(128 * NG) void k_demod_serial(
       st.F(F_P_FREQ)[c] = p_freq;
       st.F(F_P_PHASE)[c] = p_phase;
       st.F(F_P_LEVEL)[c] = p_level;
-      st.F(F_OSC_RE)[c] = MIX ? o_re : osc_after[0];
-      st.F(F_OSC_IM)[c] = MIX ? o_im : osc_after[1];
+      st.F(F_OSC_RE)[c] = MIX ? o_re : osc_after_re;
+      st.F(F_OSC_IM)[c] = MIX ? o_im : osc_after_im;
       st.F(F_DC_OFF)[c] = dc;
       { // lock status (FmDecode.cpp:219-228)
         int cnt = st.I(I_P_LOCK_CNT)[c];
@@ -2301,37 +2302,6 @@ __global__ __launch_bounds__(256) void k_halfband4(const float2* __restrict__ in
 /* from where the chain's roll moves them into those history rows.  Stage 0's rows are fetched    */
 /* a step ahead (15 rows per wave and step in registers).                                         */
 /* ------------------------------------------------------------------------------------------ */
-/* The RDS quadrature oscillator of a call (CRDSDownConvert::ProcessData, DownConvert.cpp:436-442): a
- * recurrence on its own state with an amplitude servo, independent of the signal, started at (1, 0) in
- * every decoder and advanced by every baseband sample -- so ONE sequence per batch.  One wave computes it
- * (every lane the same numbers; lane t mod 64 stores entry t), M entries behind H entries of history
- * (the previous call's last H), and leaves the state behind the call in `uni` and in `after`. */
-__global__ __launch_bounds__(64) void k_rds_osc(float* __restrict__ uni, const float2* __restrict__ prev,
-                                                unsigned prev_M, float2* __restrict__ tab, unsigned M, unsigned H,
-                                                float* __restrict__ after, float osc_cos, float osc_sin)
-{
-  const unsigned lane = threadIdx.x;
-  for (unsigned h = lane; h < H; h += 64)
-    tab[h] = prev[prev_M + h];
-  float o_re = uni[0], o_im = uni[1];
-  for (unsigned t = 0; t < M; t++)
-  {
-    float2 osc;
-    osc.x = o_re * osc_cos - o_im * osc_sin;
-    osc.y = o_im * osc_cos + o_re * osc_sin;
-    const float gn = (float)(1.95 - (double)(o_re * o_re + o_im * o_im));
-    o_re = gn * osc.x;
-    o_im = gn * osc.y;
-    if ((t & 63u) == lane)
-      tab[H + t] = osc;
-  }
-  if (lane == 0)
-  {
-    uni[0] = after[0] = o_re;
-    uni[1] = after[1] = o_im;
-  }
-}
-
 /* Behind a call that wrote no mixed rows: the H rows of history the NEXT call's first half-band stage
  * finds in front of its input, should that call take a launch per stage (rows M - H .. M - 1 of
  * baseband x oscillator, as the serial stage's MIX form writes them). */

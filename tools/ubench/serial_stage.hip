@@ -174,16 +174,16 @@ int main(int argc, char** argv)
       CK(hipEventRecord(e0, nullptr));
       if (form == 0)
         hipLaunchKernelGGL((fmd::k_demod_serial<2, true>), dim3((groups + 1) / 2), dim3(256), 0, nullptr, d_demod,
-                           Mstride, M, C, CP, k, st, brp, Hbb, d_mix, Hmix, d_tab, sct, unsigned(l & 3), d_probe, (const float*)nullptr);
+                           Mstride, M, C, CP, k, st, brp, Hbb, d_mix, Hmix, d_tab, sct, unsigned(l & 3), d_probe, 0.0f, 0.0f);
       else if (form == 1)
         hipLaunchKernelGGL((fmd::k_demod_serial<1, false>), dim3(groups), dim3(128), 0, nullptr, d_demod, Mstride,
-                           M, C, CP, k, st, brp, Hbb, d_mix, Hmix, d_tab, sct, unsigned(l & 3), d_probe, (const float*)nullptr);
+                           M, C, CP, k, st, brp, Hbb, d_mix, Hmix, d_tab, sct, unsigned(l & 3), d_probe, 0.0f, 0.0f);
       else if (form == 2)
         hipLaunchKernelGGL((fmd::k_demod_serial<2, false>), dim3((groups + 1) / 2), dim3(256), 0, nullptr, d_demod,
-                           Mstride, M, C, CP, k, st, brp, Hbb, d_mix, Hmix, d_tab, sct, unsigned(l & 3), d_probe, (const float*)nullptr);
+                           Mstride, M, C, CP, k, st, brp, Hbb, d_mix, Hmix, d_tab, sct, unsigned(l & 3), d_probe, 0.0f, 0.0f);
       else
         hipLaunchKernelGGL((fmd::k_demod_serial<1, true>), dim3(groups), dim3(128), 0, nullptr, d_demod, Mstride,
-                           M, C, CP, k, st, brp, Hbb, d_mix, Hmix, d_tab, sct, unsigned(l & 3), d_probe, (const float*)nullptr);
+                           M, C, CP, k, st, brp, Hbb, d_mix, Hmix, d_tab, sct, unsigned(l & 3), d_probe, 0.0f, 0.0f);
       CK(hipEventRecord(e1, nullptr));
       CK(hipDeviceSynchronize());
       float ms = 0;
