@@ -27,7 +27,7 @@ def _bits_equal(a, b):
 ])
 def test_fused_chain_rds_taps_bit_exact(oracle, fmsig, fs, D, sizes, alternate, nomix):
     """nomix = 1 (what large batches run): the serial stage writes no mixed rows, the chain multiplies the
-    baseband with the batch-wide oscillator sequence (k_rds_osc) itself; calls that take a launch per stage
+    baseband with the batch-wide oscillator sequence (computed by the host, once per call) itself; calls that take a launch per stage
     in between (the alternating case, the 1500- and 3000-sample calls) read mixed rows again and must find
     the rows of history and the per-channel oscillator state the other form left for them."""
     pkg = load_package()
