@@ -167,6 +167,7 @@ struct fmd_batch
   int dbg_post_delay_us = 20;  // the post chain starts this long behind the serial stage's end
   int dbg_hb4 = 1, dbg_ring4 = 1; // 0: the generic half-band / ring-FIR kernels where the unrolled ones would run
   int dbg_prof_dump = 0;
+  int dbg_rsr_wgs = 0;         // workgroups of k_resample_ring (0: the library decides)
   int dbg_lpf_late = -1;       // the post chain's two low-pass filters on their own stream: -1 the library decides
   // where a host-buffer call's time goes (fmd_batch_debug_host_ms): copy in, submission, wait + copy
   // out, RDS collection + group decoder callbacks; sums since the last query
@@ -1769,7 +1770,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   auto audio_heavy = [&]() {
 
     /* ---- audio branch  (stream A): resamplers, 15 kHz LPF, de-emphasis / notch / matrix ---- */
-    after(sA, ce[fmd_batch::EV_SER]);
+    if (sA != sR) // (one stream: the RDS branch in front has waited)
+      after(sA, ce[fmd_batch::EV_SER]);
     /* Large batches stream the rows through an LDS ring (k_resample_ring: every row crosses the fabric
      * once per segment instead of ~6 times); small ones, short calls and geometries whose window does
      * not fit a CU's LDS keep the window-per-wave form, which has more workgroups to offer. */
@@ -1779,25 +1781,28 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                       (b->rsr_mode == 1 || (CP / 64 >= 64 && rs_steps >= 24 && per_step >= 16));
     if (ring)
     {
-      // segments: about two workgroups for every CU the serial stage leaves free, >= 8 steps each
+      // one workgroup (a whole CU's LDS) for every CU the serial stage leaves free: one round, with an equal
+      // run of (group, step) units each, >= 8 steps ("rsr_wgs" of fmd_batch_debug_set overrides the count;
+      // 160 / 176 / 184 / 192 of 192: 267 800 / 278 700 / 280 000 / 282 300 MS/s whole path on one box)
       const unsigned groups = CP / 64;
       const unsigned ncu = unsigned(b->n_cus) - ((b->serial_exclusive && !serial_mode) ? (groups + 1) / 2 : 0u);
-      unsigned S = std::max(1u, std::min(8u, (2u * ncu + groups / 2u) / groups));
-      S = std::max(1u, std::min(S, rs_steps / 8u));
-      const unsigned per_seg = (rs_steps + S - 1) / S;
-      S = (rs_steps + per_seg - 1) / per_seg;
+      const unsigned units = groups * rs_steps;
+      unsigned W = b->dbg_rsr_wgs > 0 ? unsigned(b->dbg_rsr_wgs) : std::max(1u, ncu);
+      W = std::max(1u, std::min(W, units / 8u));
+      const unsigned per_wg = (units + W - 1) / W;
+      W = (units + per_wg - 1) / per_wg;
       const unsigned lds = b->rsr_nbr * 4096u;
       auto go = [&](auto plan, auto kern) {
         hipLaunchKernelGGL(plan, dim3(rs_steps * b->rsr_NW), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p, pstep,
                            A, b->rsr_rb, b->rsr_nbr, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p);
         if (evset && b->profiling == 1 && !serial_mode)
-          hipExtLaunchKernelGGL(kern, dim3(groups, S), dim3(64, b->rsr_NW + 1), lds, sA, evset[8], evset[9], 0u,
+          hipExtLaunchKernelGGL(kern, dim3(W), dim3(64, b->rsr_NW + 1), lds, sA, evset[8], evset[9], 0u,
                                 (const float2*)b->brp(q), Hbb, b->rsr_rb, d.rs_order, (const float*)b->rsr_tab.p,
-                                b->rsr_nbm, (const int*)b->rsr_head.p, (const int*)b->rsr_steps.p, rs_steps, per_seg,
+                                b->rsr_nbm, (const int*)b->rsr_head.p, (const int*)b->rsr_steps.p, rs_steps, per_wg,
                                 b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, b->rsr_exp, b->rsr_pace);
         else
-        hipLaunchKernelGGL(kern, dim3(groups, S), dim3(64, b->rsr_NW + 1), lds, sA, b->brp(q), Hbb, b->rsr_rb,
-                           d.rs_order, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p, rs_steps, per_seg,
+        hipLaunchKernelGGL(kern, dim3(W), dim3(64, b->rsr_NW + 1), lds, sA, b->brp(q), Hbb, b->rsr_rb,
+                           d.rs_order, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p, rs_steps, per_wg,
                            b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, b->rsr_exp, b->rsr_pace);
       };
       if (b->rsr_R == 4)
@@ -2074,6 +2079,8 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
     b->dbg_lpf_late = value < 0 ? -1 : (value ? 1 : 0);
   else if (k == "prof_dump")
     b->dbg_prof_dump = value != 0;
+  else if (k == "rsr_wgs")
+    b->dbg_rsr_wgs = std::max(0, value);
   else if (k == "serial_probe")
   { // per-workgroup timing of the serial stage's last 8 launches (fmd_batch_debug_serial_probe)
     HIPCHK(hipSetDevice(b->device));

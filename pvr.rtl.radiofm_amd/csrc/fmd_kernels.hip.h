@@ -3265,7 +3265,7 @@ template <int R, int RSR_NW>
 __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
     const float2* __restrict__ br, unsigned Hbb, int RB, unsigned order, const float* __restrict__ tab,
     unsigned nbm, const int* __restrict__ head, const int* __restrict__ steptab, unsigned nsteps,
-    unsigned steps_per_seg, unsigned NBR, unsigned A, float2* __restrict__ out, unsigned Hout, unsigned C,
+    unsigned steps_per_wg, unsigned NBR, unsigned A, float2* __restrict__ out, unsigned Hout, unsigned C,
     unsigned CP, unsigned exp, unsigned pace)
 {
   constexpr int RSR_PRE = RSR_ROWS / RSR_NW; // rows a wave can hold for the next step
@@ -3274,15 +3274,21 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
   __shared__ unsigned nonfinite_s;
   const unsigned lane = threadIdx.x;
   const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
-  const unsigned c = blockIdx.x * 64 + lane;
-  const unsigned s0 = blockIdx.y * steps_per_seg;
-  if (s0 >= nsteps)
+  /* The steps of all channel groups in one sequence (group-major), an equal run of it per workgroup: the
+   * grid is as many workgroups as CUs are free, whatever the number of groups -- a workgroup takes a whole
+   * CU's LDS, so a grid of groups x segments ran in rounds, and one CU that was not free at the start cost
+   * a whole round more (0.53 instead of 0.36 ms inside the pipeline with 384 workgroups for 192 CUs).  A
+   * run that crosses into the next group starts that group's ring afresh, like a segment. */
+  const unsigned units = (CP / 64u) * nsteps;
+  unsigned u0 = min(units, blockIdx.x * steps_per_wg);
+  const unsigned u1 = min(units, u0 + steps_per_wg);
+  if (u0 >= u1)
     return;
-  const unsigned s1 = min(s0 + steps_per_seg, nsteps);
+  unsigned c = 0, s0 = 0, s1 = 0, lane_off = 0;
+  bool live = false;
   const unsigned ring_pairs = NBR * 4;
   // absolute row rr in memory: wave-uniform row pointer + 32-bit lane offset; and in the ring
   const char* const gbase = reinterpret_cast<const char*>(br + ((ptrdiff_t)Hbb - (ptrdiff_t)RB) * (ptrdiff_t)CP);
-  const unsigned lane_off = c * (unsigned)sizeof(float2);
   const size_t row_bytes = (size_t)CP * sizeof(float2);
   // a value is finite iff its exponent field is not all ones: the largest magnitude word seen decides
   unsigned emax = 0u;
@@ -3292,7 +3298,7 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
   auto ring_addr = [&](unsigned pair_slot, unsigned odd) {
     return reinterpret_cast<float2*>(rsr_smem + (size_t)pair_slot * 1024 + lane * 16 + odd * 8);
   };
-  const bool live = c < C; // padding lanes hold whatever: they must not trip the non-finite flag
+  // (live: padding lanes hold whatever: they must not trip the non-finite flag)
   // this wave's share of the rows r0, r0 + 1, ... r0 + n_rows - 1 (r0 a multiple of 8): rows r0 + w + NW n,
   // fetched into registers with all loads in flight, and put into the ring later
   float2 pre[RSR_PRE];
@@ -3339,18 +3345,14 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
     const uint64_t ta = reinterpret_cast<uint64_t>(tab) + ((uint64_t)step * RSR_NW * nbm + (uint64_t)b0) * (32 * R);
     rs_warm_asm<R, RSR_NW>((unsigned)ta, (unsigned)(ta >> 32), nbm * (32u * R), (unsigned)rounds, pace);
   };
-  if (threadIdx.x == 0 && threadIdx.y == 0)
-    nonfinite_s = 0u;
-  __syncthreads();
-  int topb = steptab[2 * s0];
   if (!(exp & 64u))
   { /* The taps arrive by scalar loads one batch ahead; a load that misses the L2 (the plan kernel wrote the
      * table on some other XCD) takes longer than that.  So the workgroups of an XCD (equal blockIdx.x % 8
-     * under round-robin placement: speed only) first read their segment's part of the table through
-     * the vector path, a sixteenth each, which leaves it in their L2. */
+     * under round-robin placement: speed only) first read the table (1.7 MB for 82 steps) through the
+     * vector path, an equal part each, which leaves it in their L2. */
     const size_t gsz = (size_t)nbm * (8 * R) * sizeof(float);
-    const char* t0 = reinterpret_cast<const char*>(tab) + (size_t)s0 * RSR_NW * gsz;
-    const size_t bytes = (size_t)(s1 - s0) * RSR_NW * gsz;
+    const char* t0 = reinterpret_cast<const char*>(tab);
+    const size_t bytes = (size_t)nsteps * RSR_NW * gsz;
     const unsigned nx = (gridDim.x + 7u) / 8u, part = blockIdx.x / 8u;
     const size_t per = ((bytes + nx - 1) / nx + 15) & ~(size_t)15;
     const size_t lo = min(bytes, part * per), hi = min(bytes, lo + per);
@@ -3363,6 +3365,20 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
     if (sink == 0x7fc12345u) // never (keeps the loads)
       nonfinite_s = sink;
   }
+  for (; u0 < u1; u0 += s1 - s0)
+  {
+  const unsigned grp = u0 / nsteps;
+  s0 = u0 - grp * nsteps;
+  s1 = min(nsteps, s0 + (u1 - u0));
+  c = grp * 64 + lane;
+  lane_off = c * (unsigned)sizeof(float2);
+  live = c < C;
+  emax = 0u;
+  __syncthreads(); // the previous run's last step is through with the ring and the flag
+  if (threadIdx.x == 0 && threadIdx.y == 0)
+    nonfinite_s = 0u;
+  __syncthreads();
+  int topb = steptab[2 * s0];
   { // the first step's whole window
     const int r_hi = topb * 8 + 7;
     for (int r0 = steptab[2 * s0 + 1] * 8; r0 <= r_hi && !(exp & 16u); r0 += RSR_NW * RSR_PRE)
@@ -3450,6 +3466,7 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
     stash(r_new0, mine);
     topb = ntop;
     lds_barrier();
+  }
   }
 }
 
