@@ -126,8 +126,6 @@ struct fmd_batch
   int rsr_R = 0, rsr_NW = 0;
   unsigned rsr_nbr = 0, rsr_nbm = 0, rsr_exp = 0, rsr_pace = 0;
   int rsr_rb = 0;
-  DevBuf<float> fa_tab; // k_if_fir_acc's taps by (sample of the period, place): [8 D + 1][fa_JA]
-  int fa_JA = 0;        // 12 / 24 sums per lane; 0: the geometry does not fit (k_if_fir runs)
   DevBuf<float> rsr_tab;
   DevBuf<int> rsr_head, rsr_steps;
   int rsr_mode = -1;
@@ -169,9 +167,6 @@ struct fmd_batch
   int dbg_post_delay_us = 20;  // the post chain starts this long behind the serial stage's end
   int dbg_hb4 = 1, dbg_ring4 = 1; // 0: the generic half-band / ring-FIR kernels where the unrolled ones would run
   int dbg_prof_dump = 0;
-  int dbg_fir_acc = -1;        // long IF filters: -1 the library decides, 0 k_if_fir, 1 k_if_fir_acc wherever it fits
-  int dbg_fir_acc_exp = 0;     // experiments (results invalid): 1 one tap row, 2 no staging, 4 no barrier
-  int dbg_fir_acc_waves = 0;   // its waves per CU the segments are cut for (0: 16)
   int dbg_rsr_wgs = 0;         // workgroups of k_resample_ring (0: the library decides)
   int dbg_lpf_late = -1;       // the post chain's two low-pass filters on their own stream: -1 the library decides
   // where a host-buffer call's time goes (fmd_batch_debug_host_ms): copy in, submission, wait + copy
@@ -291,7 +286,6 @@ struct fmd_batch
     for (auto& b : hbbuf)
       b.release();
     if_coeff.release();
-    fa_tab.release();
     rs_coeff.release();
     br[0].release();
     br[1].release();
@@ -911,26 +905,6 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
 
   bad |= upload(b->lut.p, lut.data(), lut.size() * sizeof(float));
   bad |= upload(b->if_coeff.p, d.if_coeff.data(), d.if_coeff.size() * sizeof(float));
-  if (d.if_order >= 512)
-  { // k_if_fir_acc: eight waves split the outputs, JA = ceil(order / (8 D)) sums per lane
-    const unsigned Dp = 8u * d.D;
-    const unsigned need = (d.if_order - 1) / Dp + 1;
-    const int JA = need <= 12 ? 12 : need <= 24 ? 24 : 0;
-    if (JA)
-    {
-      std::vector<float> tab(size_t(Dp + 1) * JA, 0.0f);
-      for (unsigned r = 0; r < Dp; r++)
-        for (int i = 0; i < JA; i++)
-        {
-          const size_t j = size_t(i) * Dp + 1 + r;
-          if (j <= d.if_order)
-            tab[size_t(r) * JA + i] = d.if_coeff[j];
-        }
-      bad |= b->fa_tab.alloc(tab.size());
-      bad |= upload(b->fa_tab.p, tab.data(), tab.size() * sizeof(float));
-      b->fa_JA = JA;
-    }
-  }
   bad |= upload(b->rs_coeff.p, d.rs_coeff.data(), d.rs_coeff.size() * sizeof(float));
   bad |= upload(b->rds_lpf_taps.p, d.rds_lpf_taps.data(), T_lpf * sizeof(float));
   bad |= upload(b->audio_taps.p, d.lpf_taps.data(), T_alp * sizeof(float));
@@ -1203,42 +1177,6 @@ int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, un
 {
   const fmd::Design& d = b->des;
   const unsigned T = d.table_size;
-  /* Long filters in wide batches: lane = channel, running sums in registers (k_if_fir_acc): sixteen waves
-   * per CU at the full instruction rate where the window form has four that issue at half of it. */
-  if (b->fa_JA && !b->if_dry_run && b->params.fir_reduction == 0 &&
-      (b->dbg_fir_acc > 0 || (b->dbg_fir_acc < 0 && b->C >= 512)))
-  {
-    constexpr unsigned RES = 8;
-    const unsigned C = b->C, groups = (C + 63) / 64;
-    const unsigned waves = unsigned(b->dbg_fir_acc_waves > 0 ? b->dbg_fir_acc_waves : 16) * unsigned(b->n_cus);
-    const unsigned S0 = std::max(1u, waves / (groups * RES));
-    unsigned seg = (M + S0 - 1) / S0;
-    seg = std::max(4u * RES, (seg + RES - 1) / RES * RES);
-    const unsigned S = (M + seg - 1) / seg;
-    const size_t lds = fmd::FA_LDS_BYTES;
-    auto kfn = b->fa_JA == 12 ? &fmd::k_if_fir_acc<IN, RES, 12> : &fmd::k_if_fir_acc<IN, RES, 24>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              int(lds));
-    const typename IN::elem* x = static_cast<const typename IN::elem*>(d_iq);
-    mark(0);
-    if (ev_start)
-      hipExtLaunchKernelGGL(kfn, dim3(groups, S), dim3(64 * RES), unsigned(lds), sF, ev_start, ev_stop, 0u, x,
-                            iq_channel_stride, N, (const float2*)b->hist[b->hist_sel].p, (const float2*)b->lut.p, T,
-                            b->lut_idx, (const float*)b->fa_tab.p, d.if_order, d.D, pos, M, (float2*)b->demod[q].p,
-                            b->Mstride, C, seg, unsigned(b->dbg_fir_acc_exp));
-    else
-      hipLaunchKernelGGL(kfn, dim3(groups, S), dim3(64 * RES), lds, sF, x, iq_channel_stride, N,
-                         (const float2*)b->hist[b->hist_sel].p, (const float2*)b->lut.p, T, b->lut_idx,
-                         (const float*)b->fa_tab.p, d.if_order, d.D, pos, M, b->demod[q].p, b->Mstride, C, seg,
-                         unsigned(b->dbg_fir_acc_exp));
-    mark(1);
-    hipLaunchKernelGGL(fmd::k_if_hist<IN>, dim3(C, 4), dim3(256), 0, sF, x, iq_channel_stride, N,
-                       (const float2*)b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, (const float2*)b->lut.p, T,
-                       b->lut_idx, d.if_order);
-    hipLaunchKernelGGL(fmd::k_if_level<IN>, dim3(C), dim3(64), 0, sF, x, iq_channel_stride, N, b->lut.p, T,
-                       b->lut_idx, b->st);
-    return FMD_OK;
-  }
   auto fits = [&](unsigned tile) {
     const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * tile && (size_t(tile) * d.D) % T == 0;
     const size_t lds = (size_t(tile - 1) * d.D + d.if_order + 4) * sizeof(float2);
@@ -2141,12 +2079,6 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
     b->dbg_lpf_late = value < 0 ? -1 : (value ? 1 : 0);
   else if (k == "prof_dump")
     b->dbg_prof_dump = value != 0;
-  else if (k == "fir_acc")
-    b->dbg_fir_acc = value < 0 ? -1 : (value ? 1 : 0);
-  else if (k == "fir_acc_exp")
-    b->dbg_fir_acc_exp = std::max(0, value);
-  else if (k == "fir_acc_waves")
-    b->dbg_fir_acc_waves = std::max(0, value);
   else if (k == "rsr_wgs")
     b->dbg_rsr_wgs = std::max(0, value);
   else if (k == "serial_probe")

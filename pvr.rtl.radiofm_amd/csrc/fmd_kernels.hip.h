@@ -1548,225 +1548,6 @@ __global__ __launch_bounds__(64) void k_if_fir_mt(const typename IN::elem* __res
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* K1 for LONG filters and wide batches: lane = channel, the running sums in registers.          */
-/*                                                                                              */
-/* k_if_fir gives a lane one output and walks its `order` window slots in LDS: the window of     */
-/* 256 outputs (127 KB at D = 46, order 4096) is all a CU holds, one wave per SIMD, and a lone    */
-/* wave issues a packed instruction every 8 cycles where four waves get one every 4.75           */
-/* (profiles/r2_pk_rate.txt): 17.8 cycles per tap.  Here a wave owns 64 CHANNELS and streams     */
-/* their tuned samples newest first (the order of the reference's sum, DownConvert.cpp:112-128:  */
-/* j = 1 .. order over x[p - j]); every sample it reads -- once, 8 bytes per lane, from a tile    */
-/* the workgroup's waves staged transposed in LDS -- goes into the sums of ALL outputs of the     */
-/* wave whose window holds it, each with its own tap (wave-uniform: scalar loads, SGPR operands  */
-/* of plain v_mul_f32 / v_add_f32, 2.1 cycles each at four waves per SIMD).  The RES waves of a   */
-/* workgroup share the tile and split the outputs by m mod RES: a wave's outputs are D' = RES D   */
-/* samples apart, so JA = ceil(order / D') sums are live per lane (12 for 4096 taps at D = 46),   */
-/* a[i] being the output that started i periods ago with tap j = i D' + 1 + r at the period's     */
-/* sample r; after D' samples the oldest one is done and the sums move up one place.  LDS per      */
-/* workgroup is the two tiles (66 KB): two workgroups, sixteen waves per CU.  An output is        */
-/* captured behind the sample that carries its tap `order` -- what is added to its register       */
-/* afterwards (padding taps, a neighbour segment's samples) is never stored, so nothing depends   */
-/* on zero taps being exact.  A segment of outputs streams (outputs + order / D) D samples: the   */
-/* ramps at its ends are skipped in blocks of four sums.                                          */
-/* Table: tapt[r][i] = coeff[i D' + 1 + r] (0 beyond `order`), r < D', rows of JA floats.         */
-/* hist_out is k_if_hist's (the tile loop has no tile that knows it is the call's last).          */
-/* ------------------------------------------------------------------------------------------ */
-constexpr int FA_TS = 64;    // samples per tile
-constexpr int FA_PITCH = 65; // float2 per tile row: the transposing writes of a half-wave reach all banks
-// LDS: a row in front (the sample loop's dummy last read), then the two tiles
-constexpr size_t FA_LDS_BYTES = size_t(2 * FA_TS + 1) * FA_PITCH * sizeof(float2);
-
-/* n samples of a wave's stream, newest first, from the LDS row at xaddr downwards, with the tap rows from
- * (klo, khi) upwards, into the running sums of the blocks in `mask` (tools/gen_fir_acc_asm.py). */
-template <int JA>
-__device__ __forceinline__ void fir_acc_run_asm(fmd_f2v (&a)[JA], unsigned& xaddr, unsigned& n, unsigned klo,
-                                                unsigned khi, unsigned mask);
-template <>
-__device__ __forceinline__ void fir_acc_run_asm<12>(fmd_f2v (&a)[12], unsigned& xaddr, unsigned& n, unsigned klo,
-                                                    unsigned khi, unsigned mask)
-{
-#include "fmd_fir_acc_run_12.inc"
-}
-template <>
-__device__ __forceinline__ void fir_acc_run_asm<24>(fmd_f2v (&a)[24], unsigned& xaddr, unsigned& n, unsigned klo,
-                                                    unsigned khi, unsigned mask)
-{
-#include "fmd_fir_acc_run_24.inc"
-}
-
-template <class IN, int RES, int JA>
-__global__ __launch_bounds__(64 * RES) void k_if_fir_acc(
-    const typename IN::elem* __restrict__ iq, size_t chan_stride, unsigned N,
-    const float2* __restrict__ hist_in, const float2* __restrict__ lut, unsigned T, unsigned lut_idx0,
-    const float* __restrict__ tapt, unsigned order, unsigned D, unsigned pos, unsigned M,
-    float2* __restrict__ out, unsigned Mstride, unsigned C, unsigned seg_outputs, unsigned exp)
-{
-  static_assert(JA % 4 == 0 && 64 % RES == 0, "blocks of two / four sums; channels of a tile dealt to the waves");
-  constexpr int CPW = 64 / RES; // channels a wave stages per tile
-  extern __shared__ __attribute__((aligned(16))) float2 fa_tile[]; // [1 + 2 FA_TS][FA_PITCH]
-  __builtin_amdgcn_s_setprio(1);
-  const unsigned lane = threadIdx.x & 63u;
-  const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned m_lo = blockIdx.y * seg_outputs;
-  if (m_lo >= M)
-    return;
-  const unsigned m_hi = min(M, m_lo + seg_outputs);
-  const unsigned c = blockIdx.x * 64 + lane;
-  const int k_top = (int)(pos + (m_hi - 1) * D) - 1;   // newest sample any output of the segment takes
-  const int k_bot = (int)(pos + m_lo * D) - (int)order; // oldest
-  const unsigned Dp = D * RES;
-  const unsigned i_last = (order - 1) / Dp, r_last = (order - 1) % Dp; // where tap `order` sits
-  // this wave's outputs: m = m_hi - 1 - w - RES u, u = 0 .. U - 1
-  const int U = (m_hi - m_lo > w) ? (int)((m_hi - m_lo - 1 - w) / RES) + 1 : 0;
-  const int ntiles = (k_top - k_bot + FA_TS) / FA_TS;
-  const bool tpow2 = (T & (T - 1)) == 0;
-
-  // staging: the wave's CPW channels of a tile, lane = sample.  The loads of the next tile are issued in
-  // front of a tile's sample loop and only touched behind it (tuning included: history is tuned already)
-  float2 sv[CPW], lv[CPW];
-  auto fetch = [&](int t) {
-    const int k0 = k_top - FA_TS * (t + 1) + 1; // the tile's oldest sample: wave-uniform
-    const int k = k0 + (int)lane;
-    const int kc = min(max(k, 0), (int)N - 1);
-    const int kh = min(max((int)order + k, 0), (int)order - 1);
-    const unsigned li = tpow2 ? ((lut_idx0 + (unsigned)kc) & (T - 1)) : ((lut_idx0 + (unsigned)kc) % T);
-    if (k0 >= 0)
-    {
-#pragma unroll
-      for (int cc = 0; cc < CPW; cc++)
-      {
-        const unsigned ch = min(blockIdx.x * 64 + w * CPW + cc, C - 1);
-        sv[cc] = IN::one(iq + (size_t)ch * chan_stride, (size_t)kc);
-        lv[cc] = lut[(size_t)ch * T + li];
-      }
-    }
-    else
-    { // the tile reaches into the previous call: per lane one or the other
-#pragma unroll
-      for (int cc = 0; cc < CPW; cc++)
-      {
-        const unsigned ch = min(blockIdx.x * 64 + w * CPW + cc, C - 1);
-        const float2 xr = IN::one(iq + (size_t)ch * chan_stride, (size_t)kc);
-        const float2 xl = lut[(size_t)ch * T + li];
-        const float2 xh = hist_in[(size_t)ch * order + kh];
-        sv[cc] = k >= 0 ? xr : xh;
-        lv[cc] = k >= 0 ? xl : make_float2(1.0f, 0.0f); // marks a tuned sample: see stash
-      }
-    }
-  };
-  auto stash = [&](int t) {
-    const int k = k_top - FA_TS * (t + 1) + 1 + (int)lane;
-    float2* tb = fa_tile + (size_t)((t & 1) * FA_TS + 1) * FA_PITCH + lane * FA_PITCH + w * CPW;
-#pragma unroll
-    for (int cc = 0; cc < CPW; cc++)
-      tb[cc] = k >= 0 ? cmul(sv[cc], lv[cc]) : sv[cc];
-  };
-
-  fmd_f2v a[JA];
-#pragma unroll
-  for (int i = 0; i < JA; i++)
-    a[i] = fmd_f2v{0.0f, 0.0f};
-  fmd_f2v done = fmd_f2v{0.0f, 0.0f};
-  int skip = (int)(w * D); // samples in front of this wave's first output's first tap
-  unsigned r = 0;
-  int per = 0;             // a[0] is output u = per
-  // blocks of sums that hold an output of this wave in period `per`: u = per - i in [0, U)
-  constexpr int BW = JA == 12 ? 2 : 4; // sums per mask bit (tools/gen_fir_acc_asm.py)
-  unsigned on = 0u;
-  auto blocks = [&]() {
-    on = 0u;
-#pragma unroll
-    for (int bq = 0; bq < JA / BW; bq++)
-      on |= (per - BW * bq >= 0 && per - (BW * bq + BW - 1) < U) ? 1u << bq : 0u;
-  };
-  blocks();
-
-  fetch(0);
-  stash(0);
-  __syncthreads();
-  for (int t = 0; t < ntiles; t++)
-  {
-    if (t + 1 < ntiles && !(exp & 2u))
-      fetch(t + 1);
-    const float2* tb = fa_tile + (size_t)((t & 1) * FA_TS + 1) * FA_PITCH + lane;
-    int s = FA_TS - 1;
-    if (skip > 0)
-    {
-      const int n = min(skip, FA_TS);
-      skip -= n;
-      s -= n;
-    }
-    while (s >= 0)
-    { // a run: up to the tile's end, the sample with tap `order`, or the period's end
-      const unsigned stop = r <= r_last ? r_last + 1 : Dp;
-      const int n = min(s + 1, (int)(stop - r));
-      {
-        const uint64_t ta = reinterpret_cast<uint64_t>(tapt + (size_t)((exp & 1u) ? 0u : r) * JA);
-        // (the low half of a generic LDS pointer is the LDS byte address)
-        unsigned xaddr = (unsigned)(size_t)(tb + (size_t)s * FA_PITCH);
-        unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane(n);
-        fir_acc_run_asm<JA>(a, xaddr, cnt, (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta),
-                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ta >> 32)),
-                            (unsigned)__builtin_amdgcn_readfirstlane((int)on));
-      }
-      s -= n;
-      r += (unsigned)n;
-      if (r == r_last + 1)
-      { // the output at place i_last has had its last tap
-#pragma unroll
-        for (int i = 0; i < JA; i++)
-          if ((unsigned)i == i_last)
-            done = a[i];
-        const int u = per - (int)i_last;
-        if (u >= 0 && u < U && c < C)
-          out[(size_t)c * Mstride + (m_hi - 1 - w - RES * (unsigned)u)] = make_float2(done.x, done.y);
-      }
-      if (r == Dp)
-      {
-        r = 0;
-        per++;
-#pragma unroll
-        for (int i = JA - 1; i > 0; i--)
-          a[i] = a[i - 1];
-        a[0] = fmd_f2v{0.0f, 0.0f};
-        blocks();
-      }
-    }
-    if (t + 1 < ntiles && !(exp & 2u))
-      stash(t + 1);
-    if (!(exp & 4u))
-      __syncthreads();
-  }
-}
-
-/* The last `order` tuned samples of a call, for the next one (DownConvert.cpp:135-151; a block shorter
- * than the filter keeps the newest part of the old history in front of it, :137-145): what k_if_fir's
- * last tile does, as a kernel of its own behind k_if_fir_acc. */
-template <class IN>
-__global__ __launch_bounds__(256) void k_if_hist(const typename IN::elem* __restrict__ iq, size_t chan_stride,
-                                                 unsigned N, const float2* __restrict__ hist_in,
-                                                 float2* __restrict__ hist_out, const float2* __restrict__ lut,
-                                                 unsigned T, unsigned lut_idx0, unsigned order)
-{
-  const unsigned c = blockIdx.x;
-  const typename IN::elem* __restrict__ x = iq + (size_t)c * chan_stride;
-  const float2* __restrict__ l = lut + (size_t)c * T;
-  float2* __restrict__ ho = hist_out + (size_t)c * order;
-  const float2* __restrict__ hi = hist_in + (size_t)c * order;
-  const unsigned keep = N < order ? order - N : 0u;
-  for (unsigned i = blockIdx.y * 256 + threadIdx.x; i < order; i += gridDim.y * 256)
-  {
-    if (i < keep)
-      ho[i] = hi[i + N];
-    else
-    {
-      const unsigned k = N + i - order;
-      ho[i] = cmul(IN::one(x, k), l[(lut_idx0 + k) % T]);
-    }
-  }
-}
-
-/* ------------------------------------------------------------------------------------------ */
 /* K2a: RMSLevelApprox (FmDecode.cpp:505-519) + EMA (:427).  One wave per channel: the lanes    */
 /*      form the |tuned sample|^2 terms (coalesced), lane 0 adds them in index order.           */
 /* ------------------------------------------------------------------------------------------ */
