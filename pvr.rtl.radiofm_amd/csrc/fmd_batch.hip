@@ -167,6 +167,7 @@ struct fmd_batch
   int dbg_post_delay_us = 20;  // the post chain starts this long behind the serial stage's end
   int dbg_hb4 = 1, dbg_ring4 = 1; // 0: the generic half-band / ring-FIR kernels where the unrolled ones would run
   int dbg_prof_dump = 0;
+  int dbg_heavy_prio = 2;      // s_setprio of k_halfband_chain's (tens) and k_resample_ring's (units) waves
   int dbg_rsr_wgs = 0;         // workgroups of k_resample_ring (0: the library decides)
   int dbg_lpf_late = -1;       // the post chain's two low-pass filters on their own stream: -1 the library decides
   // where a host-buffer call's time goes (fmd_batch_debug_host_ms): copy in, submission, wait + copy
@@ -1574,6 +1575,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
    * the serial stage is dispatched first (30-50 us after its predecessor, period 2.50 -> 2.42 ms).
    * "post_delay_us" of fmd_batch_debug_set overrides (0 = off). */
   const int post_delay_us = b->dbg_post_delay_us;
+  // wave priorities of half-band chain (tens) and ring resampler (units) in the overlapped pipeline
+  const unsigned heavy_prio = (!serial_mode && b->concurrency == 2) ? unsigned(b->dbg_heavy_prio) : 0u;
   auto post_delay = [&](hipStream_t s) {
     if (post_delay_us > 0 && b->serial_exclusive && !serial_mode && b->concurrency == 2)
       hipLaunchKernelGGL(fmd::k_delay, dim3(1), dim3(64), 0, s, unsigned(post_delay_us) * 100u);
@@ -1641,12 +1644,12 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                               (const float2*)b->hbbuf[0].p, (const float2*)b->hbbuf[1].p, b->rdsraw[q].p, T_lpf - 1,
                               b->hbf_tail1.p, b->hbf_tail2.p, b->hbcoef[0], b->hbcoef[1], b->hbcoef[2],
                               (const fmd::HbStep*)pl->steps.p, (const int*)pl->seg_first.p, hb_in[0], n0, n1, C, CP,
-                              osc);
+                              osc, (heavy_prio / 10u) % 10u);
       else
         hipLaunchKernelGGL(kern, dim3(groups, pl->S), dim3(64, 4), 0, sR, in0, (const float2*)b->hbbuf[0].p,
                            (const float2*)b->hbbuf[1].p, b->rdsraw[q].p, T_lpf - 1, b->hbf_tail1.p, b->hbf_tail2.p,
                            b->hbcoef[0], b->hbcoef[1], b->hbcoef[2], (const fmd::HbStep*)pl->steps.p,
-                           (const int*)pl->seg_first.p, hb_in[0], n0, n1, C, CP, osc);
+                           (const int*)pl->seg_first.p, hb_in[0], n0, n1, C, CP, osc, (heavy_prio / 10u) % 10u);
       if (nomix) // the next call's stage-0 history, should it take a launch per stage (it reads mixed rows)
         hipLaunchKernelGGL(fmd::k_mix_tail, rgrid(L0H), rt, 0, sR,
                            (const float2*)(b->brp(q) + size_t(Hbb + hb_in[0] - L0H) * CP),
@@ -1799,11 +1802,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
           hipExtLaunchKernelGGL(kern, dim3(W), dim3(64, b->rsr_NW + 1), lds, sA, evset[8], evset[9], 0u,
                                 (const float2*)b->brp(q), Hbb, b->rsr_rb, d.rs_order, (const float*)b->rsr_tab.p,
                                 b->rsr_nbm, (const int*)b->rsr_head.p, (const int*)b->rsr_steps.p, rs_steps, per_wg,
-                                b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, b->rsr_exp, b->rsr_pace);
+                                b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, b->rsr_exp | ((heavy_prio % 10u) << 8), b->rsr_pace);
         else
         hipLaunchKernelGGL(kern, dim3(W), dim3(64, b->rsr_NW + 1), lds, sA, b->brp(q), Hbb, b->rsr_rb,
                            d.rs_order, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p, rs_steps, per_wg,
-                           b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, b->rsr_exp, b->rsr_pace);
+                           b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, b->rsr_exp | ((heavy_prio % 10u) << 8), b->rsr_pace);
       };
       if (b->rsr_R == 4)
         go(&fmd::k_rs_plan<4, 4>, &fmd::k_resample_ring<4, 4>);
@@ -2079,6 +2082,8 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
     b->dbg_lpf_late = value < 0 ? -1 : (value ? 1 : 0);
   else if (k == "prof_dump")
     b->dbg_prof_dump = value != 0;
+  else if (k == "heavy_prio")
+    b->dbg_heavy_prio = std::max(0, std::min(33, value));
   else if (k == "rsr_wgs")
     b->dbg_rsr_wgs = std::max(0, value);
   else if (k == "serial_probe")

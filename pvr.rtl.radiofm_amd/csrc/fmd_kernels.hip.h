@@ -117,6 +117,16 @@ struct RdsGroupRec
 /* Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits
  * for this wave's outstanding global STORES (1-2 us each time); the role-waves and tile loops
  * below only exchange data through LDS. */
+/* s_setprio takes an immediate */
+__device__ __forceinline__ void wave_prio(unsigned p)
+{
+  if (p == 1u)
+    __builtin_amdgcn_s_setprio(1);
+  else if (p == 2u)
+    __builtin_amdgcn_s_setprio(2);
+  else if (p == 3u)
+    __builtin_amdgcn_s_setprio(3);
+}
 __device__ __forceinline__ void lds_barrier()
 {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -2364,8 +2374,10 @@ __global__ __launch_bounds__(256) void k_halfband_chain(
     const float2* __restrict__ mix, const float2* __restrict__ hist1, const float2* __restrict__ hist2,
     float2* __restrict__ out, unsigned Hout, float2* __restrict__ tail1, float2* __restrict__ tail2,
     HbCoef hc0, HbCoef hc1, HbCoef hc2, const HbStep* __restrict__ steps, const int* __restrict__ seg_first,
-    unsigned n_in, unsigned n0, unsigned n1, unsigned C, unsigned CP, const float2* __restrict__ osc)
+    unsigned n_in, unsigned n0, unsigned n1, unsigned C, unsigned CP, const float2* __restrict__ osc,
+    unsigned prio)
 {
+  wave_prio(prio);
   __shared__ float2 ring1[HBF_RING][64]; // stage 0's outputs, row i0 (>= -2 H1: history) at slot i0 & 63
   __shared__ float2 ring2[HBF_RING][64]; // stage 1's outputs
   constexpr int L1H = 2 * H1, L2H = 2 * H2; // history rows of stages 1 and 2
@@ -3279,6 +3291,7 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
    * CU's LDS, so a grid of groups x segments ran in rounds, and one CU that was not free at the start cost
    * a whole round more (0.53 instead of 0.36 ms inside the pipeline with 384 workgroups for 192 CUs).  A
    * run that crosses into the next group starts that group's ring afresh, like a segment. */
+  wave_prio((exp >> 8) & 3u);
   const unsigned units = (CP / 64u) * nsteps;
   unsigned u0 = min(units, blockIdx.x * steps_per_wg);
   const unsigned u1 = min(units, u0 + steps_per_wg);
