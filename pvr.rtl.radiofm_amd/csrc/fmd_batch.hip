@@ -950,7 +950,9 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     // (the two heavy chains side by side on a fifth stream: measured slower in rounds 1-3, removed.)  The
     // fifth stream carries the post chain's two low-pass filters: see lpf_late in process_device_impl
     const int nstreams = 5;
-    // (the light chain's stream at the high priority too: measured twice, no difference)
+    // (the light chain's stream at the high priority too: measured twice, no difference; the heavy part's,
+    // which since round 4 is on the loop that closes the period: 279 100 against 279 200 MS/s; with the
+    // low-pass filters' as well: -1.6 %)
     const int prio[5] = {hi, hi, lo, lo, lo};
     hipStream_t st4[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (pick_independent_streams(nstreams, prio, st4) != 0)
