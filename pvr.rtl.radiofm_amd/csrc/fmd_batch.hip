@@ -167,6 +167,7 @@ struct fmd_batch
   int dbg_post_delay_us = 20;  // the post chain starts this long behind the serial stage's end
   int dbg_hb4 = 1, dbg_ring4 = 1; // 0: the generic half-band / ring-FIR kernels where the unrolled ones would run
   int dbg_prof_dump = 0;
+  int dbg_fir_ro = 3;          // outputs per lane of the headline IF FIR form: 1 k_if_fir_mt, 2 / 3 k_if_fir_mt3
   int dbg_heavy_prio = 2;      // s_setprio of k_halfband_chain's (tens) and k_resample_ring's (units) waves
   int dbg_rsr_wgs = 0;         // workgroups of k_resample_ring (0: the library decides)
   int dbg_lpf_late = -1;       // the post chain's two low-pass filters on their own stream: -1 the library decides
@@ -1092,7 +1093,8 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   // takes from the kernels beside it (32 768 channels: 228 against 236 GS/s): two tiles only beside
   // the whole-CU serial stage.
   const int fir_nt = b->dbg_fir_nt ? b->dbg_fir_nt : (b->concurrency == 2 && b->serial_exclusive ? 2 : 1);
-  unsigned nblocks = C * ntiles;
+  unsigned nblocks = C * ntiles, ntiles_l = ntiles;
+  size_t lds_l = lds;
   if (TILE == 64 && E == 0 && pow2 && rounds == 7 && fir_nt > 1 && !shfl)
   {
     const unsigned nt = fir_nt >= 8 ? 8u : fir_nt >= 4 ? 4u : fir_nt == 3 ? 3u : 2u;
@@ -1101,6 +1103,17 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
         : nt == 3 ? &fmd::k_if_fir_mt<IN, 7, 3>
                   : &fmd::k_if_fir_mt<IN, 7, 2>;
     nblocks = C * ((ntiles + nt - 1) / nt);
+    // three outputs per lane (k_if_fir_mt3): every sample is read from LDS once for up to three taps
+    const unsigned RO = unsigned(b->dbg_fir_ro), T3 = 64 * RO;
+    const unsigned rounds3 = unsigned(((size_t(T3 - 1) * D + d.if_order + 2) / 2 + 63) / 64);
+    if (RO > 1 && nt == 2 && d.if_order == 88 && D == 11 && (size_t(T3) * D) % T == 0 &&
+        rounds3 <= (RO == 3 ? 18u : 12u))
+    {
+      kfn = RO == 3 ? &fmd::k_if_fir_mt3<IN, 18, 2, 3> : &fmd::k_if_fir_mt3<IN, 12, 2, 2>;
+      ntiles_l = (M + T3 - 1) / T3;
+      lds_l = (size_t(T3 - 1) * D + d.if_order + 4) * sizeof(float2);
+      nblocks = C * ((ntiles_l + 1) / 2);
+    }
   }
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -1110,15 +1123,15 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   // profiled calls: the two events take the kernel's own start and stop (hipExtLaunchKernelGGL),
   // not the stream's state around it (a recorded event also counts the dispatch gap behind it)
   if (ev_start)
-    hipExtLaunchKernelGGL(kfn, dim3(nblocks), dim3(TILE), unsigned(lds), sF, ev_start, ev_stop, 0u, x,
+    hipExtLaunchKernelGGL(kfn, dim3(nblocks), dim3(TILE), unsigned(lds_l), sF, ev_start, ev_stop, 0u, x,
                           iq_channel_stride, N, (const float2*)b->hist[b->hist_sel].p,
                           (float2*)b->hist[b->hist_sel ^ 1].p, (const float2*)b->lut.p, T, b->lut_idx,
                           (const float*)b->if_coeff.p, d.if_order, D, pos, M, (float2*)b->demod[q].p,
-                          b->Mstride, ntiles, (C % 8 == 0) ? 1u : 0u);
+                          b->Mstride, ntiles_l, (C % 8 == 0) ? 1u : 0u);
   else
-    hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(TILE), lds, sF, x, iq_channel_stride, N,
+    hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(TILE), lds_l, sF, x, iq_channel_stride, N,
                        b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, T, b->lut_idx,
-                       b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles,
+                       b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles_l,
                        (C % 8 == 0) ? 1u : 0u);
   mark(1);
   hipLaunchKernelGGL(fmd::k_if_level<IN>, dim3(C), dim3(64), 0, sF, x, iq_channel_stride, N, b->lut.p, T,
@@ -2084,6 +2097,8 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
     b->dbg_lpf_late = value < 0 ? -1 : (value ? 1 : 0);
   else if (k == "prof_dump")
     b->dbg_prof_dump = value != 0;
+  else if (k == "fir_ro")
+    b->dbg_fir_ro = value == 3 ? 3 : value == 2 ? 2 : 1;
   else if (k == "heavy_prio")
     b->dbg_heavy_prio = std::max(0, std::min(33, value));
   else if (k == "rsr_wgs")

@@ -1557,6 +1557,213 @@ __global__ __launch_bounds__(64) void k_if_fir_mt(const typename IN::elem* __res
   }
 }
 
+/* k_if_fir_mt with THREE adjacent outputs per lane (a wave = 192 outputs).  The pipeline runs the package at
+ * its power limit, and what the IF FIR's tap loop burns sets the clock of everything else (with half the
+ * taps -- an experiment -- the serial stage beside it takes 1.55 instead of 1.76 ms): the outputs m, m + 1,
+ * m + 2 of a lane share all but 2 D of their window, so every tuned sample is read from LDS once for up to
+ * three taps (110 reads instead of 264 for 88 taps at D = 11; lane stride 3 D samples = 66 words:
+ * conflict-free where 2 D would be 2-way and 4 D 4-way).  Each output still adds its taps j = 1 .. order in
+ * the reference's order; a sample at distance o below the newest one is tap o of output 2, o - D of
+ * output 1, o - 2 D of output 0: five stretches of o with one, two, three, two, one running sums. */
+template <class IN, int UNROLL, int NT, int RO = 3, int ORD = 88, int DEC = 11>
+__global__ __launch_bounds__(64) void k_if_fir_mt3(const typename IN::elem* __restrict__ iq,
+                                                   size_t chan_stride, unsigned N,
+                                                   const float2* __restrict__ hist_in,
+                                                   float2* __restrict__ hist_out,
+                                                   const float2* __restrict__ lut, unsigned T,
+                                                   unsigned lut_idx0, const float* __restrict__ coeff,
+                                                   unsigned order, unsigned D, unsigned pos, unsigned M,
+                                                   float2* __restrict__ out, unsigned Mstride,
+                                                   unsigned ntiles, unsigned xcd_map)
+{
+  typedef typename IN::pair pair_t;
+  static_assert(RO == 2 || RO == 3, "outputs per lane");
+  constexpr int LANES = 64, TILE = LANES * RO;
+  extern __shared__ __attribute__((aligned(16))) float2 win[];
+  __builtin_amdgcn_s_setprio(1);
+  const unsigned ngroups = (ntiles + NT - 1) / NT;
+  unsigned c, tg;
+  if (xcd_map)
+  {
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    c = (slot / ngroups) * 8u + xcd;
+    tg = slot % ngroups;
+  }
+  else
+  {
+    c = blockIdx.x / ngroups;
+    tg = blockIdx.x % ngroups;
+  }
+  const unsigned tid = threadIdx.x;
+  const typename IN::elem* __restrict__ x = iq + (size_t)c * chan_stride;
+  const float2* __restrict__ l = lut + (size_t)c * T;
+  const unsigned mask = T - 1;
+  const int kfull_all = (int)(N & ~1u);
+  // the two table entries of a lane are the same for every load and tile (T | 128 and T | TILE * D, host-checked)
+  float2 l0, l1;
+  {
+    const int k_al0 = ((int)(pos + tg * NT * TILE * D) - (int)order) & ~1;
+    const unsigned li = (lut_idx0 + (unsigned)k_al0 + 2u * tid) & mask;
+    l0 = l[li];
+    l1 = l[(li + 1) & mask];
+  }
+  pair_t v[UNROLL];
+  auto issue = [&](unsigned tile) { // the tile's window, two samples per lane and load
+    const unsigned m0 = tile * TILE;
+    const unsigned nout = min((unsigned)TILE, M - m0);
+    const int p_first = (int)(pos + m0 * D);
+    const int k_lo = p_first - (int)order;
+    const int k_hi = p_first + (int)((nout - 1) * D);
+    const int k_al = k_lo & ~1;
+    const int kfull = min(k_hi, kfull_all);
+    const int ifirst = k_al < 0 ? (-k_al) >> 1 : 0;
+    const int npairs = (kfull - k_al + 1) >> 1;
+    const pair_t* __restrict__ src = reinterpret_cast<const pair_t*>(x) + (k_al >> 1);
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++)
+      v[u] = src[max(min(u * LANES + (int)tid, npairs - 1), ifirst)];
+  };
+  const unsigned t_first = tg * NT;
+  issue(t_first);
+  for (unsigned i = 0; i < (unsigned)NT; i++)
+  {
+    const unsigned tile = t_first + i;
+    if (tile >= ntiles)
+      break;
+    const unsigned m0 = tile * TILE;
+    const unsigned nout = min((unsigned)TILE, M - m0);
+    const int p_first = (int)(pos + m0 * D);
+    const int k_lo = p_first - (int)order;
+    const int k_hi = p_first + (int)((nout - 1) * D);
+    const int k_al = k_lo & ~1;
+    if (k_lo < 0)
+    { // tail of the previous call (already tuned), only for the first tile(s)
+      const float2* __restrict__ h = hist_in + (size_t)c * order;
+      const int nh = min(-k_lo, k_hi - k_lo);
+      for (int q = (int)tid; q < nh; q += LANES)
+        win[q + (k_lo - k_al)] = h[(int)order + k_lo + q];
+    }
+    {
+      const int kfull = min(k_hi, kfull_all);
+      const int ifirst = k_al < 0 ? (-k_al) >> 1 : 0;
+      const int npairs = (kfull - k_al + 1) >> 1;
+      float4* dst = reinterpret_cast<float4*>(win);
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++)
+      {
+        const int q = u * LANES + (int)tid;
+        if (q >= ifirst && q < npairs)
+        {
+          float2 a, b;
+          IN::unpack(v[u], a, b);
+          a = cmul(a, l0);
+          b = cmul(b, l1);
+          dst[q] = make_float4(a.x, a.y, b.x, b.y);
+        }
+      }
+      // pairs beyond one round of loads (never with the UNROLL the host picks) and a ragged last sample
+      const pair_t* __restrict__ src = reinterpret_cast<const pair_t*>(x) + (k_al >> 1);
+      for (int q = UNROLL * LANES + (int)tid; q < npairs; q += LANES)
+      {
+        float2 a, b;
+        IN::unpack(src[max(q, ifirst)], a, b);
+        a = cmul(a, l0);
+        b = cmul(b, l1);
+        if (q >= ifirst)
+          dst[q] = make_float4(a.x, a.y, b.x, b.y);
+      }
+      for (int k = max(kfull, 0) + (int)tid; k < k_hi; k += LANES)
+        win[k - k_al] = cmul(IN::one(x, k), l[(lut_idx0 + (unsigned)k) & mask]);
+    }
+    lds_wave_sync();
+    if (i + 1 < (unsigned)NT && tile + 1 < ntiles)
+      issue(tile + 1); // in flight during the tap loop below
+    if (tid * RO < nout)
+    {
+      // (order == ORD and D == DEC, host-checked, ORD a multiple of DEC: the window goes in stretches of DEC
+      // samples, each unrolled; with run-time bounds the compiler's remainder loops wait for a scalar load
+      // and an LDS read per sample, unrolled as a whole it holds all 110 samples in registers)
+      static_assert(ORD % DEC == 0 && ORD >= RO * DEC, "stretches of DEC samples");
+      constexpr int NS = ORD / DEC + (RO - 1); // stretches
+      float2 a0 = make_float2(0.0f, 0.0f), a1 = a0, a2 = a0;
+      // w[-o] = the sample o below the newest output's position: tap o of the newest output, o - D of the
+      // one before, o - 2 D of the one before that
+      const float2* w = win + (k_lo - k_al) + (tid * RO + (RO - 1)) * DEC + ORD;
+      auto stretch = [&](int st, bool newest, bool middle, bool oldest) {
+        const float2* ws = w - st * DEC;
+        const float* __restrict__ kn = coeff + st * DEC;             // newest output: taps st DEC + 1 ...
+        const float* __restrict__ km = coeff + (st - 1) * DEC;       // the one before
+        const float* __restrict__ ko = coeff + (st - (RO - 1)) * DEC; // the oldest
+#pragma unroll
+        for (int i = 1; i <= DEC; i++)
+        {
+          const float2 sm = ws[-i];
+          if (newest)
+          {
+            const float cj = kn[i];
+            float2& an = RO == 3 ? a2 : a1;
+            an.x += sm.x * cj;
+            an.y += sm.y * cj;
+          }
+          if (RO == 3 && middle)
+          {
+            const float cj = km[i];
+            a1.x += sm.x * cj;
+            a1.y += sm.y * cj;
+          }
+          if (oldest)
+          {
+            const float cj = ko[i];
+            a0.x += sm.x * cj;
+            a0.y += sm.y * cj;
+          }
+        }
+      };
+      if constexpr (RO == 3)
+      {
+        stretch(0, true, false, false);
+        stretch(1, true, true, false);
+#pragma unroll 1
+        for (int st = 2; st < ORD / DEC; st++)
+          stretch(st, true, true, true);
+        stretch(NS - 2, false, true, true);
+        stretch(NS - 1, false, false, true);
+      }
+      else
+      {
+        stretch(0, true, false, false);
+#pragma unroll 1
+        for (int st = 1; st < ORD / DEC; st++)
+          stretch(st, true, false, true);
+        stretch(NS - 1, false, false, true);
+      }
+      float2* __restrict__ op = out + (size_t)c * Mstride + m0 + tid * RO;
+      op[0] = a0;
+      if (tid * RO + 1 < nout)
+        op[1] = a1;
+      if (RO == 3 && tid * RO + 2 < nout)
+        op[2] = a2;
+    }
+    if (tile == ntiles - 1)
+    {
+      float2* __restrict__ ho = hist_out + (size_t)c * order;
+      const float2* __restrict__ hi = hist_in + (size_t)c * order;
+      const unsigned keep = N < order ? order - N : 0u;
+      for (unsigned q = tid; q < order; q += LANES)
+      {
+        if (q < keep)
+          ho[q] = hi[q + N];
+        else
+        {
+          const unsigned k = N + q - order;
+          ho[q] = cmul(IN::one(x, k), l[(lut_idx0 + k) % T]);
+        }
+      }
+    }
+    lds_wave_sync(); // this tile's window reads are done before the next tile's staging
+  }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* K2a: RMSLevelApprox (FmDecode.cpp:505-519) + EMA (:427).  One wave per channel: the lanes    */
 /*      form the |tuned sample|^2 terms (coalesced), lane 0 adds them in index order.           */
