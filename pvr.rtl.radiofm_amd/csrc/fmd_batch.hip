@@ -243,7 +243,7 @@ struct fmd_batch
   };
   bool split_post = false;
   bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
-  enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_RDSH, EV_ALP, EV_DEC, EV_N };
+  enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_RDSH, EV_ALP, EV_DEC, EV_ROLL, EV_N };
   hipEvent_t cev[NSLOT][EV_N] = {};
   bool cev_ready = false;
   uint32_t slot_call[NSLOT] = {}; // call index that last used the slot (0 = never)
@@ -1518,6 +1518,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   // br[q] / mix[q] were last read by the resampler / first half-band two calls ago: this call's FIR
   // already waited for that call's whole heavy part (EV_HEAVY above), so EV_FIR covers them and the
   // serial stream carries one wait instead of three between two serial stages
+  // (EV_HEAVY, which that FIR waited for, is recorded in FRONT of the history rolls behind the heavy part,
+  // so that the FIR starts earlier; the rolls read the tails of br[q] / mix[q]: one more wait here, met long
+  // before the FIR's)
+  if (have_prev2)
+    after(sS, pe2[fmd_batch::EV_ROLL]);
   after(sS, ce[fmd_batch::EV_FIR]);
   {
     fmd::DemodConsts k{};
@@ -1632,8 +1637,29 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
    * 3.16 without -- its head waits for events in a hardware queue the FIR's stream shares). */
   const bool lpf_late = !serial_mode && !b->split_post && b->s_lpf &&
                         (b->dbg_lpf_late > 0 || (b->dbg_lpf_late < 0 && d.if_order <= 512));
-  std::function<void()> rds_lpf_late, audio_lpf_late;
+  std::function<void()> rds_lpf_late, audio_lpf_late, mix_tail;
   hipStream_t sLPr = lpf_late ? b->s_lpf : sR, sLPa = lpf_late ? b->s_lpf : sA;
+  // the resampler's form and its plan kernel (tap tables of this call's phases: no input but the positions)
+  const unsigned per_step = unsigned(std::max(b->rsr_NW * b->rsr_R, 1));
+  const unsigned rs_steps = (A + per_step - 1) / per_step;
+  const bool ring = b->rsr_R != 0 && b->rsr_mode != 0 &&
+                    (b->rsr_mode == 1 || (CP / 64 >= 64 && rs_steps >= 24 && per_step >= 16));
+  bool rs_planned = false;
+  auto rs_plan = [&](hipStream_t s) {
+    if (!ring || rs_planned)
+      return;
+    rs_planned = true;
+    auto go = [&](auto plan) {
+      hipLaunchKernelGGL(plan, dim3(rs_steps * b->rsr_NW), dim3(64), 0, s, b->rs_coeff.p, d.rs_order, p, pstep, A,
+                         b->rsr_rb, b->rsr_nbr, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p);
+    };
+    if (b->rsr_R == 4)
+      go(&fmd::k_rs_plan<4, 4>);
+    else if (b->rsr_NW == 8)
+      go(&fmd::k_rs_plan<2, 8>);
+    else
+      go(&fmd::k_rs_plan<2, 4>);
+  };
   auto rds_heavy = [&]() {
     /* ---- RDS branch  (stream R): half-bands, 75-tap LPF, PLL, matched filter, bits ---- */
     after(sR, ce[fmd_batch::EV_SER]);
@@ -1666,10 +1692,12 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                            b->hbcoef[0], b->hbcoef[1], b->hbcoef[2], (const fmd::HbStep*)pl->steps.p,
                            (const int*)pl->seg_first.p, hb_in[0], n0, n1, C, CP, osc, (heavy_prio / 10u) % 10u);
       if (nomix) // the next call's stage-0 history, should it take a launch per stage (it reads mixed rows)
-        hipLaunchKernelGGL(fmd::k_mix_tail, rgrid(L0H), rt, 0, sR,
-                           (const float2*)(b->brp(q) + size_t(Hbb + hb_in[0] - L0H) * CP),
-                           (const float2*)(b->osc_tab[osc_slot].p + fmd_batch::kOscH + hb_in[0] - L0H),
-                           b->mix[q ^ 1].p, L0H, CP);
+        mix_tail = [&, L0H]() {
+          hipLaunchKernelGGL(fmd::k_mix_tail, rgrid(L0H), rt, 0, sR,
+                             (const float2*)(b->brp(q) + size_t(Hbb + hb_in[0] - L0H) * CP),
+                             (const float2*)(b->osc_tab[osc_slot].p + fmd_batch::kOscH + hb_in[0] - L0H),
+                             b->mix[q ^ 1].p, L0H, CP);
+        };
       else
         roll_later(b->mix[q].p, b->mix[q ^ 1].p, L0H, hb_in[0]);
       roll_later(b->hbf_tail1.p, b->hbbuf[0].p, unsigned(d.hb[1].len - 1), 0u);
@@ -1746,10 +1774,17 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, sLPr, b->rdsraw[q].p, b->rdsraw[q ^ 1].p, T_lpf - 1, R, CP);
     };
     if (lpf_late)
-    { // what the decimator left to roll goes now; the low-pass later (see above)
-      roll_flush(sR);
+    { // the low-pass later (see above); what the decimator left to roll waits for the resampler's roll: one
+      // launch behind EV_HEAVY (k_roll_set takes four)
+      if (nrolls > 3)
+        roll_flush(sR);
       rds_lpf_late = lpf;
       return;
+    }
+    if (mix_tail)
+    {
+      mix_tail();
+      mix_tail = nullptr;
     }
     lpf();
     mark(4);
@@ -1793,10 +1828,6 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     /* Large batches stream the rows through an LDS ring (k_resample_ring: every row crosses the fabric
      * once per segment instead of ~6 times); small ones, short calls and geometries whose window does
      * not fit a CU's LDS keep the window-per-wave form, which has more workgroups to offer. */
-    const unsigned per_step = unsigned(std::max(b->rsr_NW * b->rsr_R, 1));
-    const unsigned rs_steps = (A + per_step - 1) / per_step;
-    const bool ring = b->rsr_R != 0 && b->rsr_mode != 0 &&
-                      (b->rsr_mode == 1 || (CP / 64 >= 64 && rs_steps >= 24 && per_step >= 16));
     if (ring)
     {
       // one workgroup (a whole CU's LDS) for every CU the serial stage leaves free: one round, with an equal
@@ -1810,9 +1841,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       const unsigned per_wg = (units + W - 1) / W;
       W = (units + per_wg - 1) / per_wg;
       const unsigned lds = b->rsr_nbr * 4096u;
-      auto go = [&](auto plan, auto kern) {
-        hipLaunchKernelGGL(plan, dim3(rs_steps * b->rsr_NW), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p, pstep,
-                           A, b->rsr_rb, b->rsr_nbr, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p);
+      rs_plan(sA); // (already done in front of the half-band chain where the two share a stream)
+      auto go = [&](auto kern) {
         if (evset && b->profiling == 1 && !serial_mode)
           hipExtLaunchKernelGGL(kern, dim3(W), dim3(64, b->rsr_NW + 1), lds, sA, evset[8], evset[9], 0u,
                                 (const float2*)b->brp(q), Hbb, b->rsr_rb, d.rs_order, (const float*)b->rsr_tab.p,
@@ -1824,11 +1854,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                            b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, b->rsr_exp | ((heavy_prio % 10u) << 8), b->rsr_pace);
       };
       if (b->rsr_R == 4)
-        go(&fmd::k_rs_plan<4, 4>, &fmd::k_resample_ring<4, 4>);
+        go(&fmd::k_resample_ring<4, 4>);
       else if (b->rsr_NW == 8)
-        go(&fmd::k_rs_plan<2, 8>, &fmd::k_resample_ring<2, 8>);
+        go(&fmd::k_resample_ring<2, 8>);
       else
-        go(&fmd::k_rs_plan<2, 4>, &fmd::k_resample_ring<2, 4>);
+        go(&fmd::k_resample_ring<2, 4>);
     }
     else
     {
@@ -1853,8 +1883,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     roll_flush(sLPa);
     };
     if (lpf_late)
-    {
-      roll_flush(sA); // the baseband rows' history now; the low-pass (and its own roll) later
+    { // the low-pass (and its own roll) later; the baseband rows' history behind EV_HEAVY (below)
       audio_lpf_late = lpf;
       return;
     }
@@ -1887,6 +1916,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     hipLaunchKernelGGL(fmd::k_status_publish, dim3((C + 255) / 256), dim3(256), 0, sA, b->st, C, ci);
     signal(ce[fmd_batch::EV_AUD], sA);
     signal(ce[fmd_batch::EV_HEAVY], sA);
+    signal(ce[fmd_batch::EV_ROLL], sA);
   }
   else
   { // Both heavy parts first on the post stream, the light parts behind them on a stream of their
@@ -1903,10 +1933,19 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       after(sP, pe2[fmd_batch::EV_RDSH]);
       after(sP, pe2[fmd_batch::EV_ALP]);
     }
+    if (lpf_late)
+      rs_plan(sP); // off the path between the half-band chain and the resampler
     rds_heavy();
     signal(ce[lpf_late ? fmd_batch::EV_DEC : fmd_batch::EV_RDSH], sR);
     audio_heavy();
-    signal(ce[fmd_batch::EV_HEAVY], sP);
+    signal(ce[fmd_batch::EV_HEAVY], sP); // the next-but-one call's IF FIR may go
+    if (mix_tail)
+    {
+      mix_tail();
+      mix_tail = nullptr;
+    }
+    roll_flush(sP); // (lpf_late: the history rolls of both heavy parts in one launch)
+    signal(ce[fmd_batch::EV_ROLL], sP);
     if (lpf_late)
     { // the two low-pass filters on their own stream
       hipStream_t sl = b->s_lpf;
