@@ -3,7 +3,7 @@
 The launch code picks different kernels by batch size: from 1024 channels on the serial stage owns
 whole CUs (k_demod_serial<2, true>), with a channel count that is a multiple of 8 the IF FIR uses
 the XCD-aware block mapping, overlapped calls (concurrency 2) use two-tile FIR workgroups
-(k_if_fir_mt) in the headline geometry and the hand-scheduled tap loops for long filters, and the
+(k_if_fir_mt3 / k_if_fir_mt) in the headline geometry and the hand-scheduled tap loops for long filters, and the
 post chain runs as a heavy and a light part on two streams.  Small-batch tests never reach those forms,
 so these run them at >= 1024 channels with overlapped calls: a handful of channels against the CPU
 oracle bit for bit on the very bytes the device generator produced, and the whole batch through a
@@ -28,7 +28,7 @@ def _bits_equal(a, b):
     return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-def _run_overlapped(pkg, fmsig, oracle, fs, D, C, sizes, check, u8, order=0, table=0, lag=2):
+def _run_overlapped(pkg, fmsig, oracle, fs, D, C, sizes, check, u8, order=0, table=0, lag=2, debug=()):
     """C channels (c and c + C/2 the same station), calls of the given sizes submitted back to back
     in concurrency 2 and consumed `lag` calls late, like bench.py.  Returns nothing; asserts."""
     import torch
@@ -38,6 +38,8 @@ def _run_overlapped(pkg, fmsig, oracle, fs, D, C, sizes, check, u8, order=0, tab
     b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D, table_size=table,
                                   if_filter_order=order), C, record_callbacks=False)
     b.set_concurrency(2)
+    for key, value in debug:
+        b.debug_set(key, value)
     a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
     dt = torch.uint8 if u8 else torch.float32
     iq, audio, start = [], [], 0
@@ -116,18 +118,20 @@ def test_long_filter_tap_loops_overlapped(oracle, fmsig, fs, D, order):
                     check=[0, 1, 8, 515, 1024, 1031], u8=False, order=order)
 
 
+@pytest.mark.parametrize("ro", [3, 2, 1], ids=["3-per-lane", "2-per-lane", "1-per-lane"])
 @pytest.mark.parametrize("u8", [False, True], ids=["f32", "u8"])
-def test_config4_geometry_overlapped_ragged_two_tile_fir(oracle, fmsig, u8):
-    """The headline geometry (2.4 MS/s, D = 11, 88 taps) at >= 1024 channels with overlapped calls:
-    k_if_fir_mt<., 7, 2> and the whole-CU serial stage, on ragged call sizes -- odd lengths, a
-    partial last tile as the second tile of a workgroup, an odd tile count (the early
-    `tile >= ntiles` exit), a short first-tile history -- and on full blocks."""
+def test_config4_geometry_overlapped_ragged_two_tile_fir(oracle, fmsig, u8, ro):
+    """The headline geometry (2.4 MS/s, D = 11, 88 taps) at >= 1024 channels with overlapped calls: the
+    two-tile IF FIR forms -- k_if_fir_mt3 with three (what ships) and two outputs per lane, k_if_fir_mt
+    with one -- and the whole-CU serial stage, on ragged call sizes: odd lengths, a partial last tile as
+    the second tile of a workgroup, an odd tile count (the early `tile >= ntiles` exit), lanes whose last
+    outputs lie beyond the call, a short first-tile history -- and on full blocks."""
     pkg = load_package()
     C = 1024
-    # outputs per call ~ n / 11, tiles of 64 outputs, two tiles per workgroup
+    # outputs per call ~ n / 11, tiles of 64 x ro outputs, two tiles per workgroup
     sizes = [N, 10007, 8192, 65535, 150, 33001, 1001, 45057, N, 8193, 330, 21120]  # incl. short calls
     _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, C, sizes,
-                    check=[0, 63, 64, 511, 512, 1023], u8=u8)
+                    check=[0, 63, 64, 511, 512, 1023], u8=u8, debug=(("fir_ro", ro),))
 
 
 def test_config3_shared_capture_overlapped(oracle, fmsig):
