@@ -89,5 +89,8 @@ if os.path.exists(pmc) and os.path.exists(stats):
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 traffic["k_if_fir_mt"].update(bytes_per_launch=int(2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024),
                                               read_bytes=int(2 * c["FETCH_SIZE"] * 1024), write_bytes=int(c["WRITE_SIZE"] * 1024),
-                                              source="profiles/%s_pmc_k_if_fir_mt.txt" % tag)
+                                              source="profiles/%s_pmc_k_if_fir_mt.txt" % tag,
+                                              kernel=n.strip() + " (two tiles per workgroup: overlapped calls beside the "
+                                                     "whole-CU serial stage, the default bench.py run; k_if_fir_mt3 = "
+                                                     "three outputs per lane, tiles of 192 outputs)")
     json.dump(traffic, open(tpath, "w"), indent=1)
