@@ -2137,7 +2137,7 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
   else if (k == "prof_dump")
     b->dbg_prof_dump = value != 0;
   else if (k == "fir_ro")
-    b->dbg_fir_ro = value == 3 ? 3 : value == 2 ? 2 : 1;
+    b->dbg_fir_ro = (value == 2 || value == 3) ? value : 1;
   else if (k == "heavy_prio")
     b->dbg_heavy_prio = std::max(0, std::min(33, value));
   else if (k == "rsr_wgs")

@@ -1577,7 +1577,9 @@ __global__ __launch_bounds__(64) void k_if_fir_mt3(const typename IN::elem* __re
                                                    unsigned ntiles, unsigned xcd_map)
 {
   typedef typename IN::pair pair_t;
-  static_assert(RO == 2 || RO == 3, "outputs per lane");
+  // (RO = 5, conflict-free too, 132 reads for five outputs: 267 VGPRs and 29 KB of window, one wave per
+  // SIMD -- the FIR takes 1.40 ms inside the pipeline, the serial stage beside it its 1.42 alone)
+  static_assert(RO == 2 || RO == 3, "outputs per lane (lane stride RO D samples: conflict-free for 3)");
   constexpr int LANES = 64, TILE = LANES * RO;
   extern __shared__ __attribute__((aligned(16))) float2 win[];
   __builtin_amdgcn_s_setprio(1);
@@ -1684,65 +1686,47 @@ __global__ __launch_bounds__(64) void k_if_fir_mt3(const typename IN::elem* __re
       // samples, each unrolled; with run-time bounds the compiler's remainder loops wait for a scalar load
       // and an LDS read per sample, unrolled as a whole it holds all 110 samples in registers)
       static_assert(ORD % DEC == 0 && ORD >= RO * DEC, "stretches of DEC samples");
-      constexpr int NS = ORD / DEC + (RO - 1); // stretches
-      float2 a0 = make_float2(0.0f, 0.0f), a1 = a0, a2 = a0;
-      // w[-o] = the sample o below the newest output's position: tap o of the newest output, o - D of the
-      // one before, o - 2 D of the one before that
+      constexpr int NB = ORD / DEC, NS = NB + (RO - 1); // stretches of an output's taps / of the lane's window
+      float2 acc[RO]; // acc[r]: output r of the lane, RO - 1 the newest
+#pragma unroll
+      for (int r = 0; r < RO; r++)
+        acc[r] = make_float2(0.0f, 0.0f);
+      // w[-o] = the sample o below the newest output's position: tap o - (RO - 1 - r) D of output r
       const float2* w = win + (k_lo - k_al) + (tid * RO + (RO - 1)) * DEC + ORD;
-      auto stretch = [&](int st, bool newest, bool middle, bool oldest) {
+      // stretch st: output r takes its taps (st - (RO - 1 - r)) D + 1 ... + D, if that is one of its NB stretches
+      auto stretch = [&](int st, auto all) {
         const float2* ws = w - st * DEC;
-        const float* __restrict__ kn = coeff + st * DEC;             // newest output: taps st DEC + 1 ...
-        const float* __restrict__ km = coeff + (st - 1) * DEC;       // the one before
-        const float* __restrict__ ko = coeff + (st - (RO - 1)) * DEC; // the oldest
 #pragma unroll
         for (int i = 1; i <= DEC; i++)
         {
           const float2 sm = ws[-i];
-          if (newest)
+#pragma unroll
+          for (int r = 0; r < RO; r++)
           {
-            const float cj = kn[i];
-            float2& an = RO == 3 ? a2 : a1;
-            an.x += sm.x * cj;
-            an.y += sm.y * cj;
-          }
-          if (RO == 3 && middle)
-          {
-            const float cj = km[i];
-            a1.x += sm.x * cj;
-            a1.y += sm.y * cj;
-          }
-          if (oldest)
-          {
-            const float cj = ko[i];
-            a0.x += sm.x * cj;
-            a0.y += sm.y * cj;
+            const int sb = st - (RO - 1 - r);
+            if (decltype(all)::value || (sb >= 0 && sb < NB))
+            {
+              const float cj = coeff[sb * DEC + i];
+              acc[r].x += sm.x * cj;
+              acc[r].y += sm.y * cj;
+            }
           }
         }
       };
-      if constexpr (RO == 3)
-      {
-        stretch(0, true, false, false);
-        stretch(1, true, true, false);
+#pragma unroll
+      for (int st = 0; st < RO - 1; st++) // the newest outputs only
+        stretch(st, std::false_type{});
 #pragma unroll 1
-        for (int st = 2; st < ORD / DEC; st++)
-          stretch(st, true, true, true);
-        stretch(NS - 2, false, true, true);
-        stretch(NS - 1, false, false, true);
-      }
-      else
-      {
-        stretch(0, true, false, false);
-#pragma unroll 1
-        for (int st = 1; st < ORD / DEC; st++)
-          stretch(st, true, false, true);
-        stretch(NS - 1, false, false, true);
-      }
+      for (int st = RO - 1; st < NB; st++)
+        stretch(st, std::true_type{});
+#pragma unroll
+      for (int st = NB; st < NS; st++) // the oldest outputs only
+        stretch(st, std::false_type{});
       float2* __restrict__ op = out + (size_t)c * Mstride + m0 + tid * RO;
-      op[0] = a0;
-      if (tid * RO + 1 < nout)
-        op[1] = a1;
-      if (RO == 3 && tid * RO + 2 < nout)
-        op[2] = a2;
+#pragma unroll
+      for (int r = 0; r < RO; r++)
+        if (tid * RO + r < nout)
+          op[r] = acc[r];
     }
     if (tile == ntiles - 1)
     {
