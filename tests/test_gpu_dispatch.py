@@ -134,6 +134,15 @@ def test_config4_geometry_overlapped_ragged_two_tile_fir(oracle, fmsig, u8, ro):
                     check=[0, 63, 64, 511, 512, 1023], u8=u8, debug=(("fir_ro", ro),))
 
 
+def test_config4_geometry_channel_count_not_a_multiple_of_8(oracle, fmsig):
+    """The same dispatch with 1030 channels: no XCD-aware block map (blocks channel-major), a ragged last
+    group of 6 channels in every lane-per-channel kernel."""
+    pkg = load_package()
+    C = 1030
+    _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, C, [N, 10007, 2113, 65535, 33001, N],
+                    check=[0, 1, 514, 515, 1028, 1029], u8=False)
+
+
 def test_config3_shared_capture_overlapped(oracle, fmsig):
     """BASELINE config 3 (256 channels from ONE capture, table_size 256) with overlapped calls and
     late consumption, as `bench.py --workload config3` runs it."""
