@@ -827,7 +827,7 @@ def main():
         # calls overlap beside the whole-CU serial stage, one tile (k_if_fir) otherwise
         form = "k_if_fir_mt" if (args.concurrency == 2 and 1024 <= (C + 63) // 64 * 64 <= 8192
                                  and args.workload == "config4" and args.fir_reduction == 0) else "k_if_fir"
-        # (three outputs per lane, k_if_fir_mt3, unless a --debug-set fir_ro says otherwise; the traffic file
+        # (two outputs per lane, k_if_fir_mt3, unless a --debug-set fir_ro says otherwise; the traffic file
         # keeps the older key)
         label = "k_if_fir_mt3" if form == "k_if_fir_mt" and not any("fir_ro" in kv for kv in (args.debug_set or [])) \
             else form

@@ -167,7 +167,8 @@ struct fmd_batch
   int dbg_post_delay_us = 20;  // the post chain starts this long behind the serial stage's end
   int dbg_hb4 = 1, dbg_ring4 = 1; // 0: the generic half-band / ring-FIR kernels where the unrolled ones would run
   int dbg_prof_dump = 0;
-  int dbg_fir_ro = 3;          // outputs per lane of the headline IF FIR form: 1 k_if_fir_mt, 2 / 3 k_if_fir_mt3
+  int dbg_fir_ro = 2;          // outputs per lane of the headline IF FIR form: 1 k_if_fir_mt, 2 / 3 k_if_fir_mt3
+                               // (2: 288 600 MS/s and the FIR 0.975 ms inside the pipeline; 3: 287 500 and 1.00)
   int dbg_heavy_prio = 2;      // s_setprio of k_halfband_chain's (tens) and k_resample_ring's (units) waves
   int dbg_rsr_wgs = 0;         // workgroups of k_resample_ring (0: the library decides)
   int dbg_lpf_late = -1;       // the post chain's two low-pass filters on their own stream: -1 the library decides
@@ -1103,7 +1104,7 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
         : nt == 3 ? &fmd::k_if_fir_mt<IN, 7, 3>
                   : &fmd::k_if_fir_mt<IN, 7, 2>;
     nblocks = C * ((ntiles + nt - 1) / nt);
-    // three outputs per lane (k_if_fir_mt3): every sample is read from LDS once for up to three taps
+    // two (three) outputs per lane (k_if_fir_mt3): every sample is read from LDS once for up to two (three) taps
     const unsigned RO = unsigned(b->dbg_fir_ro), T3 = 64 * RO;
     const unsigned rounds3 = unsigned(((size_t(T3 - 1) * D + d.if_order + 2) / 2 + 63) / 64);
     if (RO > 1 && nt == 2 && d.if_order == 88 && D == 11 && (size_t(T3) * D) % T == 0 &&

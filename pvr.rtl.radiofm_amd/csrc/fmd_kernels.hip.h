@@ -1557,14 +1557,15 @@ __global__ __launch_bounds__(64) void k_if_fir_mt(const typename IN::elem* __res
   }
 }
 
-/* k_if_fir_mt with THREE adjacent outputs per lane (a wave = 192 outputs).  The pipeline runs the package at
- * its power limit, and what the IF FIR's tap loop burns sets the clock of everything else (with half the
- * taps -- an experiment -- the serial stage beside it takes 1.55 instead of 1.76 ms): the outputs m, m + 1,
- * m + 2 of a lane share all but 2 D of their window, so every tuned sample is read from LDS once for up to
- * three taps (110 reads instead of 264 for 88 taps at D = 11; lane stride 3 D samples = 66 words:
- * conflict-free where 2 D would be 2-way and 4 D 4-way).  Each output still adds its taps j = 1 .. order in
- * the reference's order; a sample at distance o below the newest one is tap o of output 2, o - D of
- * output 1, o - 2 D of output 0: five stretches of o with one, two, three, two, one running sums. */
+/* k_if_fir_mt with RO = 2 or 3 adjacent outputs per lane (a wave = 128 / 192 outputs).  The pipeline runs the
+ * package at its power limit, and what the IF FIR's tap loop burns sets the clock of everything else (with half
+ * the taps -- an experiment -- the serial stage beside it takes 1.55 instead of 1.76 ms): the outputs m, m + 1
+ * (, m + 2) of a lane share all but D (2 D) of their window, so every tuned sample is read from LDS once for up
+ * to RO taps (99 reads for two outputs, 110 for three, instead of 88 each at D = 11; lane stride RO D samples:
+ * 66 words for three, conflict-free; 44 for two, two-way conflicts on half as many reads).  Each output still
+ * adds its taps j = 1 .. order in the reference's order; a sample at distance o below the newest output's
+ * position is tap o - (RO - 1 - r) D of output r.  Two per lane is what runs: 13 waves per CU instead of 9,
+ * the FIR 0.975 instead of 1.00 ms inside the pipeline, the whole path the same or better (fmd_batch.hip). */
 template <class IN, int UNROLL, int NT, int RO = 3, int ORD = 88, int DEC = 11>
 __global__ __launch_bounds__(64) void k_if_fir_mt3(const typename IN::elem* __restrict__ iq,
                                                    size_t chan_stride, unsigned N,

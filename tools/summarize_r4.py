@@ -92,5 +92,5 @@ if os.path.exists(pmc) and os.path.exists(stats):
                                               source="profiles/%s_pmc_k_if_fir_mt.txt" % tag,
                                               kernel=n.strip() + " (two tiles per workgroup: overlapped calls beside the "
                                                      "whole-CU serial stage, the default bench.py run; k_if_fir_mt3 = "
-                                                     "three outputs per lane, tiles of 192 outputs)")
+                                                     "two outputs per lane, tiles of 128 outputs)")
     json.dump(traffic, open(tpath, "w"), indent=1)
