@@ -829,8 +829,11 @@ def main():
                                  and args.workload == "config4" and args.fir_reduction == 0) else "k_if_fir"
         # (two outputs per lane, k_if_fir_mt3, unless a --debug-set fir_ro says otherwise; the traffic file
         # keeps the older key)
-        label = "k_if_fir_mt3" if form == "k_if_fir_mt" and not any("fir_ro" in kv for kv in (args.debug_set or [])) \
-            else form
+        fir_ro = 2  # the library's default (fmd_batch.hip: dbg_fir_ro)
+        for kv in (args.debug_set or []):
+            if kv.split("=")[0].strip() == "fir_ro":
+                fir_ro = int(kv.split("=")[1])
+        label = "k_if_fir_mt3" if form == "k_if_fir_mt" and fir_ro in (2, 3) else form
         out["roofline"]["kernel"] = ("%s (cFineTuner + cDownsampleFilter complex%s)"
                                      % (label, ", ReadAsyncCB byte conversion" if u8 else ""))
         tpath = os.path.join(ROOT, "profiles", "traffic_k_if_fir.json")

@@ -841,7 +841,10 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
       std::memset(b->h_osc, 0, fmd_batch::NSLOT * b->h_osc_stride * sizeof(float2));
     for (auto& e : b->osc_ev)
       bad |= hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess;
-    b->osc_on = CP / 64 >= 64 && d.hb[0].len - 1 <= int(fmd_batch::kOscH);
+    // the batch-wide oscillator sequence is only read by k_halfband_chain, which exists for two chains
+    const int h0 = (d.hb[0].len - 1) / 2, h1 = (d.hb[1].len - 1) / 2, h2 = (d.hb[2].len - 1) / 2;
+    const bool chain_kind = h0 == 7 && ((h1 == 11 && h2 == 21) || (h1 == 9 && h2 == 17));
+    b->osc_on = chain_kind && CP / 64 >= 64 && d.hb[0].len - 1 <= int(fmd_batch::kOscH);
   }
   // (the inputs of the two low-pass filters by call parity too, history rows in front: the decimator /
   // resampler of the next call does not wait for this call's low-pass)
@@ -1664,6 +1667,10 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   auto rds_heavy = [&]() {
     /* ---- RDS branch  (stream R): half-bands, 75-tap LPF, PLL, matched filter, bits ---- */
     after(sR, ce[fmd_batch::EV_SER]);
+    // Without mixed rows stage 0 reads the last L0H history rows of br[q]: the PREVIOUS call's roll wrote
+    // them, on the audio stream.  One stream (default): stream order.  Two (split_post): its EV_ROLL.
+    if (nomix && sR != sA && ci > 1)
+      after(sR, b->cev[(ci + fmd_batch::NSLOT - 1) % fmd_batch::NSLOT][fmd_batch::EV_ROLL]);
     post_delay(sR);
     /* Large batches in the usual geometries: the three stages as one stream, intermediate rows in LDS
      * (k_halfband_chain).  Everything else -- short calls with a stage outside its normal regime, the
@@ -1993,6 +2000,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     note(hipStreamWaitEvent(stream, ce[fmd_batch::EV_AUD], 0));
     note(hipStreamWaitEvent(stream, ce[fmd_batch::EV_RDS], 0));
     note(hipStreamWaitEvent(stream, ce[fmd_batch::EV_INDONE], 0));
+    note(hipStreamWaitEvent(stream, ce[fmd_batch::EV_ROLL], 0));
   }
   note(hipGetLastError());
   if (herr != hipSuccess)
@@ -2064,6 +2072,8 @@ static int wait_impl(fmd_batch* b, int lag, void* stream_, bool take_lost)
       HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_AUD], 0));
       HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_RDS], 0));
       HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_INDONE], 0));
+      // the history rolls behind the heavy part (br, mix, half-band tails) belong to the call too
+      HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_ROLL], 0));
     }
   // asynchronous: reports what the device has flagged so far (calls that have finished)
   if (int rc = check_device_errors(b))
@@ -2111,6 +2121,10 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
   if (!b || !key)
     return fail(FMD_ERR_ARG, "null argument");
   const std::string k(key);
+  // Keys move work between streams and change kernel forms: nothing of an earlier call may still be
+  // running when the next call takes the new route -- drain the device first.
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
   if (k == "resampler")
   {
     if (value > 0 && b->rsr_R == 0)

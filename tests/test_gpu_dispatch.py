@@ -122,7 +122,7 @@ def test_long_filter_tap_loops_overlapped(oracle, fmsig, fs, D, order):
 @pytest.mark.parametrize("u8", [False, True], ids=["f32", "u8"])
 def test_config4_geometry_overlapped_ragged_two_tile_fir(oracle, fmsig, u8, ro):
     """The headline geometry (2.4 MS/s, D = 11, 88 taps) at >= 1024 channels with overlapped calls: the
-    two-tile IF FIR forms -- k_if_fir_mt3 with three (what ships) and two outputs per lane, k_if_fir_mt
+    two-tile IF FIR forms -- k_if_fir_mt3 with three and two (what ships) outputs per lane, k_if_fir_mt
     with one -- and the whole-CU serial stage, on ragged call sizes: odd lengths, a partial last tile as
     the second tile of a workgroup, an odd tile count (the early `tile >= ntiles` exit), lanes whose last
     outputs lie beyond the call, a short first-tile history -- and on full blocks."""
@@ -306,3 +306,15 @@ def test_device_timeline_of_overlapped_calls(fmsig):
     assert any(tl[k + 1, 0] < tl[k, 3] for k in range(1, nblk - 1))           # a later FIR beside an earlier serial stage
     b.set_profiling(0)
     b.close()
+
+
+@pytest.mark.parametrize("debug", [(("split_post", 1),), (("split_post", 1), ("halfband_chain", 1), ("lpf_late", 0))],
+                         ids=["split_post", "split_post+chain"])
+def test_two_post_streams_overlapped_at_4096_channels(oracle, fmsig, debug):
+    """The post chain on two streams (what batches of more than 16384 channels take, here forced at 4096)
+    with overlapped calls: without mixed rows the half-band chain's first stage reads history rows of the
+    baseband buffer that the PREVIOUS call's roll wrote on the other stream -- the chain has to wait for
+    that call's EV_ROLL.  Audio, status and RDS groups bit for bit, eight back-to-back calls."""
+    pkg = load_package()
+    _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, 4096, [N, N, 30001, N, N, 12345, N, N],
+                    check=[0, 63, 2047, 2048, 4095], u8=False, debug=debug)
