@@ -1,6 +1,7 @@
 """What the REFERENCE BINARY returned (tests/golden/ref_streams.npz, written by
 `python tools/ref_crosscheck.py --emit ...` in the build container: the reference's own DSP sources,
-compiled there, driven over 13 generator streams / 503 calls) against
+compiled there, driven over 16 generator streams / 1233 calls -- three of them stations that send every
+RDS group type in versions A and B, clean and weak) against
 
   * the CPU oracle (`-m "not gpu"`): the restatement meets the reference's recorded outputs on every
     CPU run, not only when somebody re-runs the cross-check tool;
@@ -48,13 +49,15 @@ IDS = [s[0]["name"].replace(" ", "_")[:48] for s in STREAMS]
 def _blocks(fmsig, d):
     gen = dict(d["gen"])
     mono = gen.pop("mono", False)
+    sched = gen.pop("schedule", None)  # a station with a group schedule of its own (every group type, A and B)
     p = (fmsig.mono_params if mono else fmsig.default_params)(d["fs"], **{"noise_sigma": 0.01, **gen})
+    dbits = fmsig.sched_dbits(fmsig.group_schedule(sched)) if sched else None
     blocks, pos, sha = [], 0, hashlib.sha256()
     for n in d["calls"]:
         if n < 0:
             blocks.append(None)
         else:
-            b = fmsig.generate_f32(p, pos, n)
+            b = fmsig.generate_f32_bits(p, dbits, pos, n) if sched else fmsig.generate_f32(p, pos, n)
             sha.update(np.ascontiguousarray(b, dtype=np.float32).tobytes())
             blocks.append(b)
             pos += n

@@ -78,6 +78,33 @@ void fmsig_rds_dbits(const fmsig_params* p, uint8_t* dbits)
   }
 }
 
+unsigned fmsig_sched_dbits(const uint16_t* groups, unsigned ngroups, uint8_t* dbits)
+{
+  /* offset words A, B, C, D and C' (block 3 of version-B groups: bit 11 of block 2 set) */
+  static const uint32_t offs[5] = {0x0FC, 0x198, 0x168, 0x1B4, 0x350};
+  const unsigned nraw = ngroups * 104u;
+  unsigned k = 0;
+  uint8_t d = 0;
+  /* two passes over the schedule: a period that leaves the differential encoder where it started */
+  for (unsigned pass = 0; pass < 2; pass++)
+    for (unsigned g = 0; g < ngroups; g++)
+    {
+      const uint16_t* bl = groups + 4u * g;
+      const int ver_b = (bl[1] >> 11) & 1;
+      for (int b = 0; b < 4; b++)
+      {
+        const uint32_t off = (b == 2 && ver_b) ? offs[4] : offs[b];
+        const uint32_t word = ((uint32_t)bl[b] << 10) | rds_checkword(bl[b], off);
+        for (int i = 25; i >= 0; i--)
+        {
+          d ^= (uint8_t)((word >> i) & 1u);
+          dbits[k++] = d;
+        }
+      }
+    }
+  return 2u * nraw;
+}
+
 static void to_chan(const fmsig_params* p, fmsig_chan* c)
 {
   c->inv_fs = 1.0 / p->fs;
@@ -120,6 +147,20 @@ void fmsig_generate_f32(const fmsig_params* p, uint64_t start, uint32_t n, float
   {
     uint8_t a, b;
     fmsig_sample_u8(&c, start + i, dbits, FMSIG_RDS_PERIOD_BITS, &a, &b);
+    out[2 * i] = fmsig_u8_to_float(a);
+    out[2 * i + 1] = fmsig_u8_to_float(b);
+  }
+}
+
+void fmsig_generate_f32_bits(const fmsig_params* p, const uint8_t* dbits, unsigned period_bits, uint64_t start,
+                             uint32_t n, float* out)
+{
+  fmsig_chan c;
+  to_chan(p, &c);
+  for (uint32_t i = 0; i < n; i++)
+  {
+    uint8_t a, b;
+    fmsig_sample_u8(&c, start + i, dbits, period_bits, &a, &b);
     out[2 * i] = fmsig_u8_to_float(a);
     out[2 * i + 1] = fmsig_u8_to_float(b);
   }

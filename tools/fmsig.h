@@ -48,6 +48,15 @@ void fmsig_rds_dbits(const fmsig_params* p, uint8_t* dbits);
 /* the undifferentiated 104-bit groups (for tests): 4 groups x 4 blocks x 26 bits */
 void fmsig_rds_groups(const fmsig_params* p, uint16_t blocks[4][4]);
 
+/* A station with a group schedule of its own: `ngroups` groups of four 16-bit blocks, sent in a loop.
+ * Version-B groups (bit 11 of block 2) get offset word C' on block 3.  Writes the differentially encoded
+ * bit table of TWO passes (2 * ngroups * 104 entries: the encoder is back at its start after an even number
+ * of passes whatever the schedule's parity) and returns its length. */
+unsigned fmsig_sched_dbits(const uint16_t* groups, unsigned ngroups, uint8_t* dbits);
+/* like fmsig_generate_f32 with the station's RDS bits taken from a table of the caller's */
+void fmsig_generate_f32_bits(const fmsig_params* p, const uint8_t* dbits, unsigned period_bits, uint64_t start,
+                             uint32_t n, float* iq_f32);
+
 /* generate n IQ samples starting at absolute sample index start */
 void fmsig_generate_u8(const fmsig_params* p, uint64_t start, uint32_t n, uint8_t* iq_u8);
 void fmsig_generate_f32(const fmsig_params* p, uint64_t start, uint32_t n, float* iq_f32);

@@ -44,6 +44,10 @@ def lib():
         L.fmsig_rds_dbits.argtypes = [C.POINTER(FmsigParams), C.c_void_p]
         L.fmsig_rds_groups.argtypes = [C.POINTER(FmsigParams), C.c_void_p]
         L.fmsig_u8_to_f32.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.fmsig_sched_dbits.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
+        L.fmsig_sched_dbits.restype = C.c_uint
+        L.fmsig_generate_f32_bits.argtypes = [C.POINTER(FmsigParams), C.c_void_p, C.c_uint, C.c_uint64, C.c_uint32,
+                                              C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -95,6 +99,86 @@ def rds_groups(p):
     out = np.empty((4, 4), dtype=np.uint16)
     lib().fmsig_rds_groups(C.byref(p), out.ctypes.data)
     return out
+
+
+# ---- stations with a group schedule of their own ---------------------------------------------------
+def sched_dbits(groups):
+    """Differentially encoded bit table of a looped schedule of groups ((A, B, C, D) 16-bit blocks each;
+    version-B groups get offset word C' on their third block)."""
+    g = np.ascontiguousarray(np.array(groups, dtype=np.uint16).reshape(-1, 4))
+    out = np.empty(2 * 104 * len(g), dtype=np.uint8)
+    n = lib().fmsig_sched_dbits(g.ctypes.data, len(g), out.ctypes.data)
+    assert n == out.size
+    return out
+
+
+def generate_f32_bits(p, dbits, start, n):
+    dbits = np.ascontiguousarray(dbits, dtype=np.uint8)
+    out = np.empty(2 * n, dtype=np.float32)
+    lib().fmsig_generate_f32_bits(C.byref(p), dbits.ctypes.data, dbits.size, start, n, out.ctypes.data)
+    return out
+
+
+def block_b(group, ver_b=0, tp=0, pty=10, low5=0):
+    """Second block of a group: type, version, TP, PTY and the five type-specific bits."""
+    return (group << 12) | (int(ver_b) << 11) | (int(tp) << 10) | (pty << 5) | (low5 & 0x1F)
+
+
+def group_schedule(name):
+    """Named group schedules (lists of (A, B, C, D)).
+
+    "all_types": every group type the reference's group decoder acts on (RDSGroupDecoder.cpp:166-945) and
+    the ones it ignores, version A and B (block sync then has to follow offset word C',
+    RDSProcess.cpp:13-17, 302-305), open-data applications mapped onto carrier groups by 3A, a PTY change and
+    a PI change (which resets the decoder) -- in an order that makes the stateful decoders fire (a radiotext
+    frame needs a second pass over segment 0; an RT+ payload only counts right behind a finished text)."""
+    if name != "all_types":
+        raise KeyError(name)
+    pi, pi2 = 0xD314, 0x1234
+    two = lambda b: int.from_bytes(b, "big")  # noqa: E731
+    g = []
+    ps_a, ps_b = b"RADIO-A1", b"Radio B2"
+    for seg in range(4):  # 0A: PS name, MS = 1, TP = 1, DI bits d0 (seg 3) and d2 (seg 1) set
+        di = 1 if seg in (1, 3) else 0
+        g.append((pi, block_b(0, 0, tp=1, low5=(1 << 3) | (di << 2) | seg), 0xE0CD, two(ps_a[2 * seg:2 * seg + 2])))
+    g.append((pi, block_b(1, 0, tp=1, low5=0x05), 0x80E0, 0x1234))            # 1A: PIN + slow labelling codes
+    g.append((pi, block_b(8, 0, tp=1, low5=9), 0xAAAA, 0xBBBB))               # 8A: TMC (not yet an ODA carrier)
+    g.append((pi, block_b(3, 0, tp=1, low5=0x16), 0x1234, 0x4BD7))            # 3A: RT+ on 11A
+    g.append((pi, block_b(3, 0, tp=1, low5=0x18), 0x0042, 0xCD46))            # 3A: TFC on 12A
+    g.append((pi, block_b(3, 0, tp=1, low5=0x1A), 0x0001, 0x1111))            # 3A: unknown application on 13A
+    g.append((pi, block_b(3, 0, tp=1, low5=0x10), 0x0000, 0xCD46))            # 3A: TFC on 8A
+    g.append((pi, block_b(3, 0, tp=1, low5=0x0A), 0x0000, 0x4BD7))            # 3A: RT+ on 5A
+    g.append((pi, block_b(3, 0, tp=1, low5=0x0F), 0x0000, 0xCD46))            # 3A: TFC on 7B
+    rt_a = b"Now: MI355X - HBM"[:16].ljust(16)
+    for seg in range(4):  # 2A: radiotext, text flag 0 ...
+        g.append((pi, block_b(2, 0, tp=1, low5=seg), two(rt_a[4 * seg:4 * seg + 2]), two(rt_a[4 * seg + 2:4 * seg + 4])))
+    g.append((pi, block_b(2, 0, tp=1, low5=0), two(rt_a[0:2]), two(rt_a[2:4])))  # ... segment 0 again: text complete
+    g.append((pi, block_b(11, 0, tp=1, low5=3), 0x2222, 0x3333))              # 11A: RT+ payload right behind it
+    g.append((pi, block_b(12, 0, tp=1, low5=1), 0x4444, 0x5555))              # 12A: TFC payload
+    g.append((pi, block_b(8, 0, tp=1, low5=9), 0xAAAA, 0xBBBB))               # 8A: now a TFC carrier
+    g.append((pi, block_b(13, 0, tp=1, low5=2), 0x6666, 0x7777))              # 13A: mapped to nothing
+    g.append((pi, block_b(4, 0, tp=1, low5=0x01), 0xCF51, 0x2C40))            # 4A: clock time and date
+    g.append((pi, block_b(10, 0, tp=1, low5=0), two(b"JA"), two(b"ZZ")))      # 10A: PTYN, two segments,
+    g.append((pi, block_b(10, 0, tp=1, low5=1), two(b" F"), two(b"M ")))
+    g.append((pi, block_b(10, 0, tp=1, low5=0x10), two(b"RO"), two(b"CK")))   # ... and the flag toggled
+    for seg in range(4):  # 0B: another PS name, TA = 1, MS = 0, other DI bits; block 3 repeats the PI (C')
+        di = 1 if seg in (0, 2) else 0
+        g.append((pi, block_b(0, 1, tp=1, low5=(1 << 4) | (di << 2) | seg), pi, two(ps_b[2 * seg:2 * seg + 2])))
+    g.append((pi, block_b(1, 1, tp=1), pi, 0x2345))                           # 1B: PIN only
+    rt_b = b"B text!!"
+    for seg in range(4):  # 2B: two characters per group, text flag 1
+        g.append((pi, block_b(2, 1, tp=1, low5=0x10 | seg), pi, two(rt_b[2 * seg:2 * seg + 2])))
+    g.append((pi, block_b(2, 1, tp=1, low5=0x10), pi, two(rt_b[0:2])))        # segment 0 again: text complete
+    g.append((pi, block_b(5, 0, tp=1, low5=4), 0x0102, 0x0304))               # 5A: an RT+ carrier now
+    g.append((pi, block_b(7, 1, tp=1, low5=6), pi, 0x0A0B))                   # 7B: a TFC carrier
+    for grp, ver in ((14, 0), (14, 1), (15, 0), (15, 1), (5, 1), (6, 0), (6, 1), (7, 0), (9, 0), (3, 1), (4, 1),
+                     (10, 1), (11, 1), (12, 1), (13, 1), (8, 1), (9, 1)):     # decoded to nothing
+        g.append((pi, block_b(grp, ver, tp=1, low5=grp & 3), pi if ver else 0x1357, 0x2468))
+    for seg in range(4):  # programme type changes (0A again, PTY 5, TP 0)
+        g.append((pi, block_b(0, 0, tp=0, pty=5, low5=(1 << 3) | seg), 0xE0CD, two(ps_a[2 * seg:2 * seg + 2])))
+    for seg in range(4):  # another station: the decoder starts over
+        g.append((pi2, block_b(0, 0, tp=0, pty=5, low5=seg), 0xE0CD, two(b"OTHER FM"[2 * seg:2 * seg + 2])))
+    return g
 
 
 # ---- device generator (libfmsig_hip.so, HIP) ---------------------------------------------------

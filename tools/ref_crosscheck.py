@@ -151,7 +151,163 @@ int main(int argc, char** argv)
 }
 """
 
+# ---- driver 2: a list of groups straight into the reference's cRDSGroupDecoder::DecodeRDS ------------
+# in : u32 n; n x 4 u16        out: frames and names like the stream driver's tail
+DRIVER_GROUPS = r"""
+#include <cstdio>
+#include <cstdlib>
+#include <new>
+#include <vector>
+#include "RDSGroupDecoder.h"
+#include "RadioReceiver.h"
+int main(int argc, char** argv)
+{
+  FILE* in = fopen(argv[1], "rb");
+  FILE* out = fopen(argv[2], "wb");
+  unsigned n;
+  if (!in || !out || fread(&n, 4, 1, in) != 1)
+    return 2;
+  std::vector<uint16_t> g(4 * size_t(n));
+  if (fread(g.data(), 8, n, in) != n)
+    return 3;
+  cRadioReceiver rx;
+  void* mem = calloc(1, sizeof(cRDSGroupDecoder)); // like the member of a decoder constructed in zeroed storage
+  cRDSGroupDecoder* dec = new (mem) cRDSGroupDecoder(&rx);
+  dec->Reset(); // what its owner's constructor does before the first group (RDSProcess.cpp:80, 94)
+  for (unsigned i = 0; i < n; i++)
+    dec->DecodeRDS(&g[4 * size_t(i)]);
+  unsigned nfr = rx.frames.size();
+  fwrite(&nfr, 4, 1, out);
+  for (auto& f : rx.frames)
+  {
+    unsigned l = f.size();
+    fwrite(&l, 4, 1, out);
+    fwrite(f.data(), 1, l, out);
+  }
+  unsigned nn = rx.names.size();
+  fwrite(&nn, 4, 1, out);
+  for (auto& s : rx.names)
+  {
+    unsigned l = s.size();
+    fwrite(&l, 4, 1, out);
+    fwrite(s.data(), 1, l, out);
+  }
+  fclose(out);
+  return 0;
+}
+"""
+
+# ---- driver 3: cFineTuner + cDownsampleFilter(complex) on their own (FmDecode.cpp:45-82, DownConvert.cpp:63-154)
+# in : u32 table, i32 shift, u32 order, u32 D, u32 ncalls; per call i32 n, n complex<float>
+# out: per call u32 m, m complex<float>
+DRIVER_FIR = r"""
+#include <cstdio>
+#include <vector>
+#include "DownConvert.h"
+#include "FmDecode.h"
+int main(int argc, char** argv)
+{
+  FILE* in = fopen(argv[1], "rb");
+  FILE* out = fopen(argv[2], "wb");
+  unsigned table, order, D, ncalls;
+  int shift;
+  if (!in || !out || fread(&table, 4, 1, in) != 1 || fread(&shift, 4, 1, in) != 1 || fread(&order, 4, 1, in) != 1 ||
+      fread(&D, 4, 1, in) != 1 || fread(&ncalls, 4, 1, in) != 1)
+    return 2;
+  cFineTuner tuner(table, shift);
+  cDownsampleFilter fir(order, 0.6 / D, D, true); // the constructor's arguments at FmDecode.cpp:262, order free
+  std::vector<ComplexType> iq(65536), tuned(65536), dem(65536);
+  for (unsigned k = 0; k < ncalls; k++)
+  {
+    int n;
+    if (fread(&n, 4, 1, in) != 1 || fread(iq.data(), sizeof(ComplexType), n, in) != (size_t)n)
+      return 3;
+    tuner.Process(iq.data(), tuned.data(), n);
+    unsigned m = fir.Process(tuned.data(), dem.data(), n);
+    fwrite(&m, 4, 1, out);
+    fwrite(dem.data(), sizeof(ComplexType), m, out);
+  }
+  fclose(out);
+  return 0;
+}
+"""
+
 N = 65536
+
+
+def group_sequences():
+    """(name, uint16 [n][4]): group lists pushed straight into DecodeRDS."""
+    import numpy as np
+    from tools import fmsig_py
+    sched = fmsig_py.group_schedule("all_types")
+    B = fmsig_py.block_b
+    two = lambda b: int.from_bytes(b, "big")  # noqa: E731
+    out = [("the all_types schedule, three passes", sched * 3)]
+    # a full 64-character radiotext in 2A, 32 characters in 2B, incomplete texts, flag toggles in the middle
+    g = []
+    pi = 0xABCD
+    text = b"Sixty-four characters of radiotext, sent in sixteen 2A segments."
+    assert len(text) == 64
+    for rep in range(3):
+        for seg in range(16):
+            if rep == 1 and seg == 7:
+                continue  # a segment is missing: the text must not be published
+            g.append((pi, B(2, 0, low5=((rep & 1) << 4) | seg), two(text[4 * seg:4 * seg + 2]), two(text[4 * seg + 2:4 * seg + 4])))
+        g.append((pi, B(2, 0, low5=((rep & 1) << 4) | 0), two(text[0:2]), two(text[2:4])))
+        g.append((pi, B(3, 0, low5=0x16), 0x1FFF, 0x4BD7))
+        g.append((pi, B(11, 0, low5=rep), 0x0102, 0x0304))
+        g.append((pi, B(2, 0, low5=((rep & 1) << 4) | 0), two(text[0:2]), two(text[2:4])))
+        g.append((pi, B(11, 0, low5=rep), 0x0506, 0x0708))
+    for seg in list(range(16)) + [0, 5, 0]:
+        g.append((pi, B(2, 1, low5=seg), pi, two(text[2 * seg:2 * seg + 2])))
+    for k in range(40):  # clock: dates around the month / year corrections, hours' top bit in block C
+        mjd = 40587 + 397 * k
+        g.append((pi, B(4, 0, low5=(mjd >> 15) & 3), ((mjd << 1) & 0xFFFE) | (k & 1), ((k % 16) << 12) | ((k * 7 % 60) << 6) | (k & 0x3F)))
+    for k in range(12):  # PS segments out of order, DI and TA/TP in all combinations, both versions
+        seg = (3 * k + 1) & 3
+        g.append((pi, B(0, k & 1, tp=(k >> 1) & 1, low5=((k >> 2) & 1) << 4 | (k % 3 == 0) << 3 | (k % 5 == 0) << 2 | seg),
+                  pi if k & 1 else 0xE0CD, two(b"ABCDEFGH"[2 * seg:2 * seg + 2])))
+    for k in range(8):  # frames whose payload needs byte stuffing further up (0xFD..0xFF) and long PTYN runs
+        g.append((pi, B(10, 0, low5=((k >> 2) << 4) | (k & 1)), 0xFDFE, 0xFF00 | k))
+        g.append((pi, B(8, 0, low5=k), 0xFFFF, 0xFEFD))
+    out.append(("crafted: texts, clocks, PS / DI / TA combinations", g))
+    # random groups: every type and version with arbitrary payloads, three stations taking turns, every
+    # sixth group a 3A that maps one of the two known applications (or an unknown one) onto a random carrier
+    rng = np.random.default_rng(20260)
+    g = []
+    pis = [0x1000, 0xD314, 0xFFFF]
+    cur = pis[0]
+    for k in range(6000):
+        if rng.random() < 0.004:
+            cur = pis[int(rng.integers(0, 3))]
+        b = int(rng.integers(0, 65536))
+        c, d = int(rng.integers(0, 65536)), int(rng.integers(0, 65536))
+        if k % 6 == 0:
+            b = (b & 0x07E0) | (3 << 12) | int(rng.integers(0, 32))
+            d = [0x4BD7, 0xCD46, d][int(rng.integers(0, 3))]
+        elif k % 6 == 1:
+            b = (b & 0x0FFF) | (2 << 12)  # radiotext
+        g.append((cur, b, c, d))
+    out.append(("random: 6000 groups, three stations", g))
+    # the first station's PI is 0: the decoder does not start over (its PI register reads 0 already)
+    g = [(0, B(0, 0, low5=s), 0xE0CD, two(b"ZEROPI  "[2 * s:2 * s + 2])) for s in range(4)]
+    g += [(0, B(2, 0, low5=s), 0x4142, 0x4344) for s in (0, 1, 0)]
+    g += [(7, B(0, 0, low5=s), 0xE0CD, two(b"SEVEN   "[2 * s:2 * s + 2])) for s in range(4)]
+    out.append(("PI 0 first", g))
+    return [(n, np.array(x, dtype=np.uint16).reshape(-1, 4)) for n, x in out]
+
+
+def fir_cases():
+    """(name, fs, D, table, shift, order, generator seed, call sizes): the IF stage at the parameters of
+    BASELINE configs[2] (256-entry tuner, one capture, many shifts) and configs[4] (4096 taps, D = 46),
+    which the reference's own constructor never builds (FmDecode.cpp:249, 262)."""
+    c3 = [N, N, 30001, 88, 500, N, 8192, 131, N]
+    c5 = [N, N, 3000, 4095, 4097, 1000, N, 20000, 2048, N]
+    out = [("config 3: table 256, shift %d" % k, 2.4e6, 11, 256, k, 88, 31, c3) for k in (38, -77, 1, 255, 128, 0, -256, 1000)]
+    out.append(("config 5: 4096 taps, D = 46", 10e6, 46, 64, 10, 4096, 32, c5))
+    out.append(("4096 taps, D = 46, table 256, shift -41", 10e6, 46, 256, -41, 4096, 33, c5[:6]))
+    out.append(("2048 taps, D = 11", 2.4e6, 11, 64, 10, 2048, 34, [N, 1000, 2047, 2049, N]))
+    return out
 
 
 def streams(quick):
@@ -175,10 +331,130 @@ def streams(quick):
         ("1.2 MS/s, D = 5", 1.2e6, 5, 0, {"seed": 19}, full(30)),
         ("1.8 MS/s, D = 8", 1.8e6, 8, 0, {"seed": 20}, full(30)),
         ("2.4 MS/s mono station (no pilot)", 2.4e6, 11, 0, {"seed": 21, "mono": True}, full(24)),
+        # a station that sends every group type, version A and B (offset word C'), open-data carriers, a PTY
+        # and a PI change (tools/fmsig_py.py: group_schedule): the block sync's version-B branch and every
+        # decoder of RDSGroupDecoder.cpp end to end
+        ("2.4 MS/s all group types, 62-group schedule", 2.4e6, 11, 0, {"seed": 22, "schedule": "all_types"}, full(230)),
+        ("2.4 MS/s all group types, weak RDS (FEC, sync loss)", 2.4e6, 11, 0,
+         {"seed": 23, "schedule": "all_types", "noise_sigma": 0.11, "a_rds": 0.02}, full(400)),
+        ("1.0 MS/s all group types", 1.0e6, 4, 0, {"seed": 24, "schedule": "all_types"}, full(100)),
     ]
     if quick:
         s = [(n, fs, D, us, kw, calls[:max(6, len(calls) // 5)]) for n, fs, D, us, kw, calls in s]
     return s
+
+
+def _read_frames(raw, at):
+    (nfr,) = struct.unpack_from("<I", raw, at)
+    at += 4
+    frames = []
+    for _ in range(nfr):
+        (l,) = struct.unpack_from("<I", raw, at)
+        frames.append(raw[at + 4:at + 4 + l])
+        at += 4 + l
+    (nn,) = struct.unpack_from("<I", raw, at)
+    at += 4
+    names = []
+    for _ in range(nn):
+        (l,) = struct.unpack_from("<I", raw, at)
+        names.append(raw[at + 4:at + 4 + l])
+        at += 4 + l
+    return frames, names, at
+
+
+def check_groups(td, exe, args):
+    """Group lists through the reference's DecodeRDS and through the oracle's group decoder."""
+    import ctypes
+    from oracle import oracle_py
+    L = oracle_py.lib()
+    L.fmo_debug_push_group.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    bad, emit = 0, {}
+    for i, (name, g) in enumerate(group_sequences()):
+        fin, fout = os.path.join(td, "g_in.bin"), os.path.join(td, "g_out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<I", len(g)))
+            f.write(np.ascontiguousarray(g).tobytes())
+        subprocess.check_call([exe, fin, fout], stderr=subprocess.DEVNULL)
+        frames, names, _ = _read_frames(open(fout, "rb").read(), 0)
+        o = oracle_py.OracleDecoder(2.4e6, -0.36e6, 48000.0, 15000.0, 11)
+        for row in g:
+            L.fmo_debug_push_group(o._h, (ctypes.c_uint16 * 4)(*[int(x) for x in row]))
+        fr_o = o.uecp_frames()
+        last = names[-1][:8].decode("latin1") if names else ""
+        ok = fr_o == frames and o.channel_name()[:8] == last
+        print("groups: %-52s %5d groups -> %4d UECP frames, %3d names: %s" % (
+            name, len(g), len(frames), len(names), "equal" if ok else "DIFFER (oracle has %d frames, name %r / %r)" % (
+                len(fr_o), o.channel_name(), last)))
+        bad += not ok
+        emit["g%02d_name" % i] = np.array(name)
+        emit["g%02d_groups" % i] = g
+        emit["g%02d_frames" % i] = np.frombuffer(b"".join(frames), dtype=np.uint8)
+        emit["g%02d_frame_len" % i] = np.array([len(f) for f in frames], dtype=np.uint32)
+        emit["g%02d_names" % i] = np.frombuffer(b"".join(n[:8].ljust(8, b"\0") for n in names), dtype=np.uint8)
+    if args.emit and not args.quick:
+        path = os.path.join(os.path.dirname(os.path.abspath(args.emit)), "ref_groups.npz")
+        np.savez_compressed(path, **emit)
+        print("wrote %s (%d group lists)" % (path, len(emit) // 5))
+    return bad
+
+
+def fir_blocks(fs, seed, calls):
+    from tools import fmsig_py
+    p = fmsig_py.default_params(fs, noise_sigma=0.01, seed=seed)
+    blocks, pos = [], 0
+    for n in calls:
+        blocks.append(fmsig_py.generate_f32(p, pos, n))
+        pos += n
+    return blocks
+
+
+def check_fir(td, exe, args):
+    """cFineTuner + cDownsampleFilter(complex) alone, at table sizes and filter orders the reference's
+    constructor never uses, against the oracle's `demod` tap."""
+    from oracle import oracle_py
+    bad, emit = 0, {}
+    cache = {}
+    for i, (name, fs, D, table, shift, order, seed, calls) in enumerate(fir_cases()):
+        if args.quick:
+            calls = calls[:4]
+        key = (fs, seed, tuple(calls))
+        if key not in cache:
+            cache[key] = fir_blocks(fs, seed, calls)
+        blocks = cache[key]
+        fin, fout = os.path.join(td, "f_in.bin"), os.path.join(td, "f_out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<IiIII", table, shift, order, D, len(calls)))
+            for n, b in zip(calls, blocks):
+                f.write(struct.pack("<i", n))
+                f.write(np.ascontiguousarray(b, dtype=np.float32).tobytes())
+        subprocess.check_call([exe, fin, fout])
+        raw = open(fout, "rb").read()
+        o = oracle_py.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D, table_size=table,
+                                    if_filter_order=0 if order == 8 * D else order, tuning_shift=shift)
+        at, nbad, sha, cnt = 0, 0, [], []
+        iq_sha = hashlib.sha256()
+        for n, b in zip(calls, blocks):
+            iq_sha.update(np.ascontiguousarray(b, dtype=np.float32).tobytes())
+            (m,) = struct.unpack_from("<I", raw, at)
+            ref = np.frombuffer(raw, dtype=np.uint32, count=2 * m, offset=at + 4)
+            at += 4 + 8 * m
+            o.process_stream(b)
+            mine = o.taps()["demod"].view(np.uint32)
+            nbad += not (mine.size == ref.size and np.array_equal(mine, ref))
+            sha.append(np.frombuffer(hashlib.sha256(ref.tobytes()).digest(), dtype=np.uint8))
+            cnt.append(m)
+        print("IF stage: %-48s %2d calls: %s" % (name, len(calls), "all equal" if not nbad else "%d calls DIFFER" % nbad))
+        bad += nbad
+        emit["f%02d_def" % i] = np.array(json.dumps({"name": name, "fs": fs, "D": D, "table": table, "shift": shift,
+                                                      "order": order, "seed": seed, "calls": calls,
+                                                      "iq_sha256": iq_sha.hexdigest()}))
+        emit["f%02d_sha256" % i] = np.stack(sha)
+        emit["f%02d_count" % i] = np.array(cnt, dtype=np.uint32)
+    if args.emit and not args.quick:
+        path = os.path.join(os.path.dirname(os.path.abspath(args.emit)), "ref_fir.npz")
+        np.savez_compressed(path, **emit)
+        print("wrote %s (%d cases)" % (path, len(emit) // 3))
+    return bad
 
 
 def main():
@@ -200,21 +476,31 @@ def main():
         for rel, text in SHIMS.items():
             os.makedirs(os.path.dirname(os.path.join(td, rel)) or td, exist_ok=True)
             open(os.path.join(td, rel), "w").write(text)
-        open(os.path.join(td, "driver.cpp"), "w").write(DRIVER)
-        exe = os.path.join(td, "refdrv")
-        subprocess.check_call(["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-w", "-I", td, "driver.cpp"] + SOURCES +
-                              ["-o", exe], cwd=td)
+        cxx = ["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-w", "-I", td]
+        subprocess.check_call(cxx + ["-c"] + SOURCES, cwd=td)
+        objs = [f[:-4] + ".o" for f in SOURCES]
+        exes = {}
+        for key, text in (("refdrv", DRIVER), ("refgroups", DRIVER_GROUPS), ("reffir", DRIVER_FIR)):
+            open(os.path.join(td, key + ".cpp"), "w").write(text)
+            exes[key] = os.path.join(td, key)
+            subprocess.check_call(cxx + [key + ".cpp"] + objs + ["-o", exes[key]], cwd=td)
+        exe = exes["refdrv"]
         bad = 0
+        bad += check_groups(td, exes["refgroups"], args)
+        bad += check_fir(td, exes["reffir"], args)
         for name, fs, D, us, kw, calls in streams(args.quick):
             kw = dict(kw)
             mono = kw.pop("mono", False)
+            sched = kw.pop("schedule", None)
             p = (fmsig_py.mono_params if mono else fmsig_py.default_params)(fs, **{"noise_sigma": 0.01, **kw})
+            dbits = fmsig_py.sched_dbits(fmsig_py.group_schedule(sched)) if sched else None
             blocks, pos = [], 0
             for n in calls:
                 if n < 0:
                     blocks.append(None)
                 else:
-                    blocks.append(fmsig_py.generate_f32(p, pos, n))
+                    blocks.append(fmsig_py.generate_f32_bits(p, dbits, pos, n) if sched
+                                  else fmsig_py.generate_f32(p, pos, n))
                     pos += n
             fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
             with open(fin, "wb") as f:
@@ -275,7 +561,8 @@ def main():
             if args.emit:
                 i = len(emit) // 6
                 emit["s%02d_def" % i] = np.array(json.dumps(
-                    {"name": name, "fs": fs, "D": D, "us": us, "gen": dict(kw, mono=mono), "calls": calls,
+                    {"name": name, "fs": fs, "D": D, "us": us,
+                     "gen": dict(kw, mono=mono, **({"schedule": sched} if sched else {})), "calls": calls,
                      "iq_sha256": iq_sha.hexdigest()}))
                 emit["s%02d_audio_sha256" % i] = np.stack(rec_sha)
                 emit["s%02d_meta" % i] = np.array(rec_meta, dtype=np.uint32)  # nfloats, stereo, 4 getters' bits
