@@ -634,6 +634,7 @@ def main():
                         bad.append(("rds", i, r))
             vb.close()
             verify = {"steps": V, "channels_per_rank": picks, "ranks": world, "mismatches": bad,
+                      "per_rank_ok": [not any(b[2] == r for b in bad) for r in range(world)],
                       "ok": not bad}
             ok = 0.0 if bad else 1.0
             if bad:
@@ -737,6 +738,18 @@ def main():
         per_rank = [{"rank": r, "ms_per_step": round(float(t[0]), 4), "if_fir_ms": round(float(t[1]), 4),
                      "gather_ms_per_step": None if float(t[2]) < 0 else round(float(t[2]), 4)}
                     for r, t in enumerate(allr)]
+        if gth is not None:
+            # what every rank's OWN communicator says about itself (ncclCommCount / ncclCommUserRank of the
+            # gather's communicator, include/fmd_gather.h): N processes that each ran a world of one would
+            # show ranks_seen 1 here
+            gi = gth.info()
+            mine_i = torch.tensor([gi["ranks_seen"], gi["rank"], gi["device"], gi["steps_issued"]],
+                                  dtype=torch.int64, device=dev)
+            alli = [torch.zeros_like(mine_i) for _ in range(world)]
+            dist.all_gather(alli, mine_i)
+            for r, t in enumerate(alli):
+                per_rank[r].update({"rccl_ranks_seen": int(t[0]), "rccl_rank": int(t[1]), "rccl_device": int(t[2]),
+                                    "gather_steps_issued": int(t[3])})
     host_ms = {k: v / K * 1e3 for k, v in host_t.items()}  # the timed region's, before the extra steps
 
     # after the timed region: four more steps with the stages one after the other on one stream and
@@ -861,6 +874,10 @@ def main():
             out["verify"] = verify
         if per_rank is not None:
             out["per_rank"] = per_rank
+            if gth is not None:
+                seen = [p_.get("rccl_ranks_seen") for p_ in per_rank]
+                out["rccl_ranks_seen"] = min(seen)  # == n_gpus when RCCL really connected every rank
+                out["rccl_ranks_distinct"] = len({p_.get("rccl_rank") for p_ in per_rank})
             out["per_rank_note"] = ("ms_per_step: each rank's own clock around the timed region (value uses "
                                     "the max); gather_ms_per_step: the two gather calls of a step on the "
                                     "side stream (device events; host time of the staging copies with gloo)")

@@ -68,6 +68,18 @@ int fmd_gather_barrier(fmd_gather* g, double value, double* max_value);
  * since the last call (device events); < 0 when there was none.  Synchronises that stream. */
 float fmd_gather_ms_per_step(fmd_gather* g);
 
+/* What the communicator itself says it is (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): a bench line
+ * that carries ranks_seen proves RCCL connected N ranks, not that N processes each ran a world of one. */
+typedef struct fmd_gather_info_t
+{
+  int ranks_seen;   /* ncclCommCount */
+  int rank;         /* ncclCommUserRank */
+  int device;       /* ncclCommCuDevice */
+  int world_asked;  /* fmd_gather_create's argument */
+  uint64_t steps_issued;
+} fmd_gather_info_t;
+int fmd_gather_info(fmd_gather* g, fmd_gather_info_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,7 +55,8 @@ struct fmd_gather
   static constexpr unsigned kRing = 16;
   hipEvent_t done[kRing] = {};     // side -> whoever reuses the buffers, one per step in flight
   uint64_t issued = 0;
-  std::vector<hipEvent_t> t0, t1;  // timing of the steps since the last query
+  static constexpr size_t kTimed = 1024; // timing covers at most the last kTimed steps since the last query
+  std::vector<hipEvent_t> t0, t1;  // timing of the steps since the last query (a ring of kTimed pairs)
   size_t timed = 0;
   double* d_word = nullptr;        // the barrier's all-reduce
 };
@@ -157,7 +158,8 @@ int fmd_gather_step(fmd_gather* g, fmd_batch* batch, int lag, unsigned channel_o
   }
   GHIP(hipEventRecord(g->ready, stream));
   GHIP(hipStreamWaitEvent(g->side, g->ready, 0));
-  if (g->timed == g->t0.size())
+  const size_t tslot = g->timed % fmd_gather::kTimed; // a caller that never asks for timings keeps 1024 pairs
+  if (tslot == g->t0.size())
   {
     hipEvent_t a, b;
     GHIP(hipEventCreate(&a));
@@ -165,27 +167,45 @@ int fmd_gather_step(fmd_gather* g, fmd_batch* batch, int lag, unsigned channel_o
     g->t0.push_back(a);
     g->t1.push_back(b);
   }
-  GHIP(hipEventRecord(g->t0[g->timed], g->side));
+  GHIP(hipEventRecord(g->t0[tslot], g->side));
   const size_t rds_ints = size_t(g->rds_rows) * 4;
   GNCCL(ncclGroupStart());
-  if (g->rank != 0)
-  {
-    GNCCL(ncclSend(d_audio, g->audio_floats, ncclFloat, 0, g->comm, g->side));
-    GNCCL(ncclSend(d_rds, rds_ints, ncclInt32, 0, g->comm, g->side));
-  }
-  else
-    for (int r = 1; r < g->world; r++)
+  { // a failed send / receive must not leave the group open: later calls on the communicator would hang in it
+    ncclResult_t r_ = ncclSuccess;
+    const char* what = "";
+    auto op = [&](ncclResult_t r, const char* w) {
+      if (r_ == ncclSuccess && r != ncclSuccess)
+      {
+        r_ = r;
+        what = w;
+      }
+      return r_ == ncclSuccess;
+    };
+    if (g->rank != 0)
     {
-      GNCCL(ncclRecv(d_all_audio + size_t(r) * g->audio_floats, g->audio_floats, ncclFloat, r, g->comm, g->side));
-      GNCCL(ncclRecv(d_all_rds + size_t(r) * rds_ints, rds_ints, ncclInt32, r, g->comm, g->side));
+      if (op(ncclSend(d_audio, g->audio_floats, ncclFloat, 0, g->comm, g->side), "ncclSend(audio)"))
+        op(ncclSend(d_rds, rds_ints, ncclInt32, 0, g->comm, g->side), "ncclSend(rds)");
     }
+    else
+      for (int r = 1; r < g->world && r_ == ncclSuccess; r++)
+      {
+        if (op(ncclRecv(d_all_audio + size_t(r) * g->audio_floats, g->audio_floats, ncclFloat, r, g->comm, g->side),
+               "ncclRecv(audio)"))
+          op(ncclRecv(d_all_rds + size_t(r) * rds_ints, rds_ints, ncclInt32, r, g->comm, g->side), "ncclRecv(rds)");
+      }
+    if (r_ != ncclSuccess)
+    {
+      (void)ncclGroupEnd();
+      return gfail(FMD_ERR_DEVICE, std::string(what) + ": " + ncclGetErrorString(r_));
+    }
+  }
   GNCCL(ncclGroupEnd());
   if (g->rank == 0)
   { // rank 0's own outputs: a device copy, on the same stream
     GHIP(hipMemcpyAsync(d_all_audio, d_audio, g->audio_floats * sizeof(float), hipMemcpyDeviceToDevice, g->side));
     GHIP(hipMemcpyAsync(d_all_rds, d_rds, rds_ints * sizeof(int32_t), hipMemcpyDeviceToDevice, g->side));
   }
-  GHIP(hipEventRecord(g->t1[g->timed], g->side));
+  GHIP(hipEventRecord(g->t1[tslot], g->side));
   g->timed++;
   GHIP(hipEventRecord(g->done[g->issued % fmd_gather::kRing], g->side));
   g->issued++;
@@ -228,15 +248,32 @@ float fmd_gather_ms_per_step(fmd_gather* g)
   if (hipStreamSynchronize(g->side) != hipSuccess)
     return -1.0f;
   double sum = 0.0;
-  for (size_t i = 0; i < g->timed; i++)
+  const size_t n = g->timed < fmd_gather::kTimed ? g->timed : fmd_gather::kTimed;
+  for (size_t i = 0; i < n; i++)
   {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, g->t0[i], g->t1[i]) == hipSuccess)
       sum += ms;
   }
-  const float mean = float(sum / double(g->timed));
+  const float mean = float(sum / double(n));
   g->timed = 0;
   return mean;
+}
+
+int fmd_gather_info(fmd_gather* g, fmd_gather_info_t* out)
+{
+  if (!g || !out)
+    return gfail(FMD_ERR_ARG, "null argument");
+  int count = 0, rank = -1, dev = -1;
+  GNCCL(ncclCommCount(g->comm, &count));
+  GNCCL(ncclCommUserRank(g->comm, &rank));
+  GNCCL(ncclCommCuDevice(g->comm, &dev));
+  out->ranks_seen = count;
+  out->rank = rank;
+  out->device = dev;
+  out->world_asked = g->world;
+  out->steps_issued = g->issued;
+  return FMD_OK;
 }
 
 } // extern "C"

@@ -9,8 +9,13 @@ LIB_PATH = os.path.join(_HERE, "libfmd_gather.so")
 ID_BYTES = 128
 EXPORTS = ["fmd_gather_last_error", "fmd_gather_unique_id", "fmd_gather_create", "fmd_gather_destroy",
            "fmd_gather_step", "fmd_gather_wait", "fmd_gather_wait_lagged", "fmd_gather_barrier",
-           "fmd_gather_ms_per_step"]
+           "fmd_gather_ms_per_step", "fmd_gather_info"]
 _LIB = None
+
+
+class GatherInfo(C.Structure):
+    _fields_ = [("ranks_seen", C.c_int), ("rank", C.c_int), ("device", C.c_int), ("world_asked", C.c_int),
+                ("steps_issued", C.c_uint64)]
 
 
 def lib():
@@ -31,6 +36,7 @@ def lib():
         L.fmd_gather_barrier.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
         L.fmd_gather_ms_per_step.restype = C.c_float
         L.fmd_gather_ms_per_step.argtypes = [vp]
+        L.fmd_gather_info.argtypes = [vp, C.POINTER(GatherInfo)]
         _LIB = L
     return _LIB
 
@@ -91,3 +97,10 @@ class Gather:
     def ms_per_step(self):
         v = lib().fmd_gather_ms_per_step(self._h)
         return None if v < 0 else float(v)
+
+    def info(self):
+        """What the communicator itself reports: ranks_seen (ncclCommCount), rank, device, steps issued."""
+        out = GatherInfo()
+        _check(lib().fmd_gather_info(self._h, C.byref(out)))
+        return {"ranks_seen": out.ranks_seen, "rank": out.rank, "device": out.device,
+                "world_asked": out.world_asked, "steps_issued": int(out.steps_issued)}

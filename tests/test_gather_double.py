@@ -1,0 +1,47 @@
+"""The whole-node gather (include/fmd_gather.h, csrc/fmd_gather.hip) with a world of 2, 3 and 8 ranks in
+the build container.  No N > 1 hardware run has been possible on this pool, and a world of one issues
+neither ncclSend nor ncclRecv -- so the product's gather source is compiled here with g++ and linked against
+a TEST DOUBLE of the HIP-runtime and RCCL calls it makes (tests/cpp/gather_double/fake_hip_rccl.cpp: streams
+as in-order worker queues, events, grouped send / receive over shared-memory rings between processes) in
+place of libamdhip64 / librccl.  tests/cpp/gather_double/world_n.cpp forks the ranks, produces every step's
+outputs late on the caller's stream, rotates six buffers over 40 steps (the 16-event ring wraps) and has
+rank 0 compare every byte it received with what rank r must have sent.
+
+The double replaces libraries under the product's source for this test only; nothing of it is linked into,
+or loaded by, the product.  (Mutations of fmd_gather.hip that drop the ordering behind the caller's stream
+or shift a receive offset make this test fail: checked when it was written.)"""
+import json
+import os
+import subprocess
+
+import pytest
+
+from __graft_entry__ import ROOT
+
+HERE = os.path.join(ROOT, "tests", "cpp", "gather_double")
+
+
+@pytest.fixture(scope="module")
+def world_n(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("gather_double") / "world_n")
+    cmd = ["g++", "-std=c++17", "-O1", "-w", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-x", "c++",
+           os.path.join(ROOT, "pvr.rtl.radiofm_amd", "csrc", "fmd_gather.hip"),
+           os.path.join(HERE, "fake_hip_rccl.cpp"), os.path.join(HERE, "world_n.cpp"), "-o", exe, "-lpthread", "-lrt"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return exe
+
+
+@pytest.mark.parametrize("world,steps", [(2, 40), (3, 40), (8, 20)])
+def test_gather_step_with_real_peers_against_the_double(world_n, world, steps):
+    out = subprocess.run([world_n, str(world), str(steps)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["world"] == world and line["rccl_ranks_seen"] == world
+    assert line["rank_step_messages_checked"] == world * steps
+
+
+def test_a_failed_receive_reports_and_closes_its_group(world_n):
+    env = dict(os.environ, FAKE_RCCL_FAIL_RECV="1")
+    out = subprocess.run([world_n, "2", "1"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]

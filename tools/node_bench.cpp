@@ -4,7 +4,7 @@
  * over RCCL (include/fmd_gather.h).  The same loop as bench.py's (calls overlapped, outputs consumed
  * LAG steps late), same JSON keys; bench.py stays the driver's entry point.
  *
- *   tools/node_bench --gpus N [--steps K] [--warmup W] [--channels C]
+ *   tools/node_bench --gpus N [--steps K] [--warmup W] [--channels C] [--verify]
  *
  * The parent forks the N ranks BEFORE anything touches HIP; rank 0 writes the communicator's id into a
  * file the others wait for.  Build: make -C pvr.rtl.radiofm_amd/csrc ../../tools/node_bench
@@ -13,6 +13,8 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -27,7 +29,24 @@
 extern "C" int fmsig_device_generate(const void*, const void*, unsigned, unsigned, uint64_t, unsigned, void*, size_t, void*);
 #define CHECK(x) do { if (!(x)) { fprintf(stderr, "rank %d: %s failed (%s / %s)\n", rank, #x, fmd_last_error(), fmd_gather_last_error()); _exit(1); } } while (0)
 
-static int rank_main(int rank, int world, int K, int W, unsigned C, const std::string& idfile)
+/* station g of the synthetic node-wide workload (tools/fmsig_py.channel_params) */
+static void make_station(double fs, unsigned g, fmsig_chan* ch, uint8_t* dbits)
+{
+  fmsig_params p;
+  fmsig_default(&p, fs);
+  p.noise_sigma = 0.01;
+  p.seed = 1000 + g;
+  p.f_left = 400.0 + 13.0 * (g % 97);
+  p.f_right = 2500.0 + 7.0 * (g % 211);
+  p.pi = uint16_t(0x1000 + (g % 0xE000));
+  char ps[16];
+  snprintf(ps, sizeof ps, "C%07u", g % 10000000u);
+  memcpy(p.ps, ps, 8);
+  *ch = fmsig_chan{1.0 / p.fs, p.f_offset, p.dev, p.amp, p.a_mono, p.a_stereo, p.a_pilot, p.a_rds, p.f_left, p.f_right, p.noise_sigma, p.seed};
+  fmsig_rds_dbits(&p, dbits);
+}
+
+static int rank_main(int rank, int world, int K, int W, unsigned C, const std::string& idfile, bool verify)
 {
   const double fs = 2.4e6;
   const unsigned N = 65536, D = 11, RING = 10, LAG = 3, NBUF = LAG + 3;
@@ -53,21 +72,7 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
   std::vector<fmsig_chan> ch(C);
   std::vector<uint8_t> dbits(size_t(C) * FMSIG_RDS_PERIOD_BITS);
   for (unsigned c = 0; c < C; c++)
-  {
-    const unsigned g = unsigned(rank) * C + c;
-    fmsig_params p;
-    fmsig_default(&p, fs);
-    p.noise_sigma = 0.01;
-    p.seed = 1000 + g;
-    p.f_left = 400.0 + 13.0 * (g % 97);
-    p.f_right = 2500.0 + 7.0 * (g % 211);
-    p.pi = uint16_t(0x1000 + (g % 0xE000));
-    char ps[16];
-    snprintf(ps, sizeof ps, "C%07u", g % 10000000u);
-    memcpy(p.ps, ps, 8);
-    ch[c] = fmsig_chan{1.0 / p.fs, p.f_offset, p.dev, p.amp, p.a_mono, p.a_stereo, p.a_pilot, p.a_rds, p.f_left, p.f_right, p.noise_sigma, p.seed};
-    fmsig_rds_dbits(&p, &dbits[size_t(c) * FMSIG_RDS_PERIOD_BITS]);
-  }
+    make_station(fs, unsigned(rank) * C + c, &ch[c], &dbits[size_t(c) * FMSIG_RDS_PERIOD_BITS]);
   void *d_ch, *d_bits;
   float* iq;
   CHECK(hipMalloc(&d_ch, ch.size() * sizeof(fmsig_chan)) == hipSuccess && hipMalloc(&d_bits, dbits.size()) == hipSuccess);
@@ -123,6 +128,97 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
   for (int i = 0; i < W; i++)
     step(i);
   drain();
+  // what the communicator says about itself: N processes that each ran a world of one would read 1 here
+  fmd_gather_info_t inf;
+  CHECK(fmd_gather_info(g, &inf) == FMD_OK);
+  double seen_short = 0.0;
+  CHECK(fmd_gather_barrier(g, double(world - inf.ranks_seen), &seen_short) == FMD_OK);
+  CHECK(seen_short == 0.0 && inf.rank == rank);
+  /* --verify: what rank 0 received from every rank in the last warm-up steps against a recomputation of four
+   * stations per rank in a batch of its own (same generator, same call sequence), bit for bit: audio rows and
+   * RDS records.  Every rank learns the verdict (the barrier's maximum) and leaves with code 4 on a mismatch. */
+  std::vector<int> rank_ok(size_t(world), 1);
+  int verified_steps = 0;
+  if (verify)
+  {
+    double bad = 0.0;
+    if (rank == 0)
+    {
+      std::vector<unsigned> picks = {0u, 1u, C / 2, C - 1};
+      std::sort(picks.begin(), picks.end());
+      picks.erase(std::unique(picks.begin(), picks.end()), picks.end());
+      const unsigned np = unsigned(picks.size()), nv = unsigned(world) * np;
+      std::vector<fmsig_chan> vch(nv);
+      std::vector<uint8_t> vbits(size_t(nv) * FMSIG_RDS_PERIOD_BITS);
+      for (int r = 0; r < world; r++)
+        for (unsigned k = 0; k < np; k++)
+          make_station(fs, unsigned(r) * C + picks[k], &vch[size_t(r) * np + k], &vbits[(size_t(r) * np + k) * FMSIG_RDS_PERIOD_BITS]);
+      void *d_vch, *d_vbits;
+      float *viq, *vaudio;
+      int32_t* vrds;
+      const unsigned vrows = 4 * nv;
+      CHECK(hipMalloc(&d_vch, vch.size() * sizeof(fmsig_chan)) == hipSuccess && hipMalloc(&d_vbits, vbits.size()) == hipSuccess);
+      CHECK(hipMemcpy(d_vch, vch.data(), vch.size() * sizeof(fmsig_chan), hipMemcpyHostToDevice) == hipSuccess);
+      CHECK(hipMemcpy(d_vbits, vbits.data(), vbits.size(), hipMemcpyHostToDevice) == hipSuccess);
+      CHECK(hipMalloc(reinterpret_cast<void**>(&viq), size_t(nv) * N * 8) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&vaudio), size_t(nv) * stride * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&vrds), size_t(vrows) * 16) == hipSuccess);
+      fmd_batch* vb = nullptr;
+      CHECK(fmd_batch_create(&par, nv, nullptr, rank, nullptr, nullptr, &vb) == FMD_OK);
+      std::vector<float> ha(stride), hb(stride);
+      std::vector<int32_t> hv(size_t(vrows) * 4), hg(size_t(C) * 4);
+      const int V = std::min(W, int(NBUF));
+      for (int i = 0; i < W; i++)
+      {
+        unsigned vnf = 0;
+        CHECK(fmsig_device_generate(d_vch, d_vbits, FMSIG_RDS_PERIOD_BITS, nv, uint64_t(i % int(RING)) * N, N, viq, N, st) == 0);
+        CHECK(fmd_batch_process_device(vb, viq, N, N, vaudio, stride, &vnf, st) == FMD_OK);
+        CHECK(fmd_batch_wait(vb, st) >= 0);
+        CHECK(fmd_batch_export_rds_device(vb, vrds, vrows, 0, 0, st) >= 0);
+        CHECK(hipStreamSynchronize(st) == hipSuccess);
+        if (i < W - V)
+          continue;
+        verified_steps++;
+        const int s = i % int(NBUF);
+        CHECK(hipMemcpy(hv.data(), vrds, hv.size() * 4, hipMemcpyDeviceToHost) == hipSuccess);
+        for (int r = 0; r < world; r++)
+        {
+          CHECK(hipMemcpy(hg.data(), all_r + (size_t(s) * world + r) * C * 4, hg.size() * 4, hipMemcpyDeviceToHost) == hipSuccess);
+          for (unsigned k = 0; k < np; k++)
+          {
+            CHECK(hipMemcpy(ha.data(), all_a + (size_t(s) * world + r) * afl + size_t(picks[k]) * stride, stride * 4, hipMemcpyDeviceToHost) == hipSuccess);
+            CHECK(hipMemcpy(hb.data(), vaudio + (size_t(r) * np + k) * stride, stride * 4, hipMemcpyDeviceToHost) == hipSuccess);
+            if (vnf != nf || memcmp(ha.data(), hb.data(), size_t(vnf) * 4) != 0)
+              rank_ok[size_t(r)] = 0;
+            // records: [channel + 1, call index, blocks]; the same groups of the same call on both sides
+            std::vector<std::array<int32_t, 3>> got, want;
+            for (unsigned q = 0; q < C; q++)
+              if (hg[size_t(q) * 4] == int32_t(unsigned(r) * C + picks[k] + 1))
+                got.push_back({hg[size_t(q) * 4 + 1], hg[size_t(q) * 4 + 2], hg[size_t(q) * 4 + 3]});
+            for (unsigned q = 0; q < vrows; q++)
+              if (hv[size_t(q) * 4] == int32_t(unsigned(r) * np + k + 1))
+                want.push_back({hv[size_t(q) * 4 + 1], hv[size_t(q) * 4 + 2], hv[size_t(q) * 4 + 3]});
+            std::sort(got.begin(), got.end());
+            std::sort(want.begin(), want.end());
+            if (got != want)
+              rank_ok[size_t(r)] = 0;
+          }
+        }
+      }
+      fmd_batch_destroy(vb);
+      (void)hipFree(d_vch); (void)hipFree(d_vbits); (void)hipFree(viq); (void)hipFree(vaudio); (void)hipFree(vrds);
+      for (int r = 0; r < world; r++)
+        if (!rank_ok[size_t(r)])
+        {
+          fprintf(stderr, "node_bench --verify: what rank 0 received from rank %d differs from the recomputation\n", r);
+          bad = 1.0;
+        }
+    }
+    double worst = 0.0;
+    CHECK(fmd_gather_barrier(g, bad, &worst) == FMD_OK);
+    if (worst != 0.0)
+      _exit(4);
+  }
   (void)fmd_gather_ms_per_step(g);
   CHECK(fmd_gather_barrier(g, 0.0, nullptr) == FMD_OK);
   const auto t0 = std::chrono::steady_clock::now();
@@ -132,13 +228,21 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), dmax = dt;
   CHECK(fmd_gather_barrier(g, dt, &dmax) == FMD_OK); // the slowest rank's time
   const float gms = fmd_gather_ms_per_step(g);
+  std::string vjson = "null";
+  if (verify)
+  {
+    vjson = "{\"steps\": " + std::to_string(verified_steps) + ", \"ranks\": " + std::to_string(world) + ", \"per_rank_ok\": [";
+    for (int r = 0; r < world; r++)
+      vjson += std::string(r ? ", " : "") + (rank_ok[size_t(r)] ? "true" : "false");
+    vjson += "], \"ok\": true}";
+  }
   if (rank == 0)
     printf("{\"metric\": \"IQ MS/s demodulated (whole node) + achieved HBM GB/s on FIR stage\", \"value\": %.1f, \"unit\": \"MS/s\", "
            "\"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.4f, \"higher_is_better\": true, \"scaling\": \"weak\", "
            "\"vs_baseline\": null, \"dtype\": \"f32\", \"data\": \"synthetic\", \"config\": {\"workload\": \"BASELINE configs[3] per-GPU shard: "
            "%u independent FM stereo+RDS channels/GPU @2.4 MS/s, 65536 IQ/channel/step (tools/node_bench.cpp: C++ host, RCCL gather to rank 0)\", "
-           "\"audio_floats_per_channel_step\": %u, \"gather_ms_per_step_rank0\": %.4f}}\n",
-           double(world) * C * N * K / dmax / 1e6, world, K, W, dmax / K * 1e3, C, nf, gms);
+           "\"audio_floats_per_channel_step\": %u, \"gather_ms_per_step_rank0\": %.4f}, \"rccl_ranks_seen\": %d, \"verify\": %s}\n",
+           double(world) * C * N * K / dmax / 1e6, world, K, W, dmax / K * 1e3, C, nf, gms, inf.ranks_seen, vjson.c_str());
   fflush(stdout); // (the rank leaves through _exit)
   fmd_gather_destroy(g);
   fmd_batch_destroy(b);
@@ -149,6 +253,16 @@ int main(int argc, char** argv)
 {
   int gpus = 1, K = 40, W = 8;
   unsigned C = 8192;
+  bool verify = false;
+  for (int i = 1; i < argc; i++)
+    if (std::string(argv[i]) == "--verify")
+    { // a flag without a value: take it out of the key / value pairs
+      verify = true;
+      for (int j = i; j + 1 < argc; j++)
+        argv[j] = argv[j + 1];
+      argc--;
+      i--;
+    }
   for (int i = 1; i + 1 < argc; i += 2)
   {
     const std::string k = argv[i];
@@ -165,7 +279,7 @@ int main(int argc, char** argv)
   {
     const pid_t p = fork();
     if (p == 0)
-      _exit(rank_main(r, gpus, K, W, C, idfile));
+      _exit(rank_main(r, gpus, K, W, C, idfile, verify));
     kids.push_back(p);
   }
   int worst = 0;
