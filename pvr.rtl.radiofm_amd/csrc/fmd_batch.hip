@@ -171,7 +171,14 @@ struct fmd_batch
                                // (2: 288 600 MS/s and the FIR 0.975 ms inside the pipeline; 3: 287 500 and 1.00)
   int dbg_heavy_prio = 2;      // s_setprio of k_halfband_chain's (tens) and k_resample_ring's (units) waves
   int dbg_rsr_wgs = 0;         // workgroups of k_resample_ring (0: the library decides)
-  int dbg_lpf_late = -1;       // the post chain's two low-pass filters on their own stream: -1 the library decides
+  int dbg_lpf_late = -1;       // where the post chain's low-pass filters run: -1 the library decides, 0 heavy
+                               // stream, 1 a stream of their own, 2 the light stream (in front of their readers)
+  int dbg_level_in_fir = 0;    // 1: RMSLevelApprox inside k_if_fir_mt3's first workgroup of a channel (0: k_if_level)
+  int dbg_light_split = 1;     // the light part's audio half on its own stream, beside the RDS half
+  int dbg_alt_prio = 3;        // wave priority of k_audio_lpf_tail29
+  int dbg_fuse_alp = 0;        // 1: 29-tap audio low-pass inside the audio tail's kernel (k_audio_lpf_tail29): 0.15 GB
+                               // per call less, bit-identical, but no faster as a whole and the IF FIR beside it
+                               // slower (0.57 against 0.59 of the HBM peak): measured, left off
   // where a host-buffer call's time goes (fmd_batch_debug_host_ms): copy in, submission, wait + copy
   // out, RDS collection + group decoder callbacks; sums since the last query
   double host_ms[4] = {0, 0, 0, 0};
@@ -234,9 +241,12 @@ struct fmd_batch
   // needs to know about its call: see launch_light.
   struct LightJob
   {
-    unsigned R = 0, A = 0, mf_g = 0;
+    unsigned R = 0, A = 0, mf_g = 0, alpf_g = 0;
     int q = 0, es = 0, sq = 0;
     bool tail_after_alp = false; // the audio tail waits for EV_ALP (the audio low-pass behind EV_HEAVY)
+    bool fuse_alp = false;       // audio low-pass inside the tail kernel (k_audio_lpf_tail29)
+    std::function<void()> before_tail; // the audio low-pass where it runs on the light stream, unfused
+    hipStream_t s_audio = nullptr;     // the audio half on a stream of its own (beside the RDS half), or null
     uint32_t call_index = 0;
     float* d_audio = nullptr;
     size_t audio_stride = 0;
@@ -861,7 +871,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->alp[1].alloc(size_t(b->Amax) * CP);
   bad |= b->rds_lpf_taps.alloc(T_lpf);
   bad |= b->mf_taps2.alloc(size_t(2) * T_mf);
-  bad |= b->audio_taps.alloc(T_alp);
+  bad |= b->audio_taps.alloc(2 * size_t(T_alp)); // twice in a row: k_audio_lpf_tail29 reads T taps from any a0
   b->rs_margin = fmd::rs_table_margin(d.rs_step); // zeros around every output's taps: k_resample
   b->rs_row = d.rs_order + 1 + 2 * b->rs_margin;
   bad |= b->ktab.alloc(size_t(b->Amax) * b->rs_row + 64);
@@ -914,6 +924,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= upload(b->rs_coeff.p, d.rs_coeff.data(), d.rs_coeff.size() * sizeof(float));
   bad |= upload(b->rds_lpf_taps.p, d.rds_lpf_taps.data(), T_lpf * sizeof(float));
   bad |= upload(b->audio_taps.p, d.lpf_taps.data(), T_alp * sizeof(float));
+  bad |= upload(b->audio_taps.p + T_alp, d.lpf_taps.data(), T_alp * sizeof(float));
   bad |= upload(b->sctab.p, d.sincos_tab.data(), d.sincos_tab.size() * sizeof(double));
   bad |= upload(b->sctab256.p, d.sincos_tab256.data(), d.sincos_tab256.size() * sizeof(double));
   bad |= upload(b->mf_taps2.p, d.rds_mf_taps.data(), T_mf * sizeof(float));
@@ -1049,6 +1060,11 @@ using FirFn = void (*)(const typename IN::elem*, size_t, unsigned, const float2*
                        unsigned, unsigned, const float*, unsigned, unsigned, unsigned, unsigned, float2*,
                        unsigned, unsigned, unsigned);
 
+template <class IN>
+using FirFn3 = void (*)(const typename IN::elem*, size_t, unsigned, const float2*, float2*, const float2*,
+                        unsigned, unsigned, const float*, unsigned, unsigned, unsigned, unsigned, float2*,
+                        unsigned, unsigned, unsigned, float*);
+
 template <class IN, int TILE, int E, bool RB128 = false>
 int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
                       unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
@@ -1099,6 +1115,8 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   const int fir_nt = b->dbg_fir_nt ? b->dbg_fir_nt : (b->concurrency == 2 && b->serial_exclusive ? 2 : 1);
   unsigned nblocks = C * ntiles, ntiles_l = ntiles;
   size_t lds_l = lds;
+  FirFn3<IN> kfn3 = nullptr; // k_if_fir_mt3 (one more argument: where the level meter goes)
+  bool level_in_fir = false;
   if (TILE == 64 && E == 0 && pow2 && rounds == 7 && fir_nt > 1 && !shfl)
   {
     const unsigned nt = fir_nt >= 8 ? 8u : fir_nt >= 4 ? 4u : fir_nt == 3 ? 3u : 2u;
@@ -1113,10 +1131,14 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
     if (RO > 1 && nt == 2 && d.if_order == 88 && D == 11 && (size_t(T3) * D) % T == 0 &&
         rounds3 <= (RO == 3 ? 18u : 12u))
     {
-      kfn = RO == 3 ? &fmd::k_if_fir_mt3<IN, 18, 2, 3> : &fmd::k_if_fir_mt3<IN, 12, 2, 2>;
+      kfn3 = RO == 3 ? &fmd::k_if_fir_mt3<IN, 18, 2, 3> : &fmd::k_if_fir_mt3<IN, 12, 2, 2>;
       ntiles_l = (M + T3 - 1) / T3;
       lds_l = (size_t(T3 - 1) * D + d.if_order + 4) * sizeof(float2);
       nblocks = C * ((ntiles_l + 1) / 2);
+      // the level meter inside the first tile's workgroup: its (N + 63) / 64 samples have to lie in that tile's
+      // window, which ends in front of the tile's last output position pos + (nout - 1) D
+      const unsigned nout0 = std::min(T3, M);
+      level_in_fir = b->dbg_level_in_fir != 0 && (N + 63u) / 64u <= pos + (nout0 - 1u) * D;
     }
   }
   if (lds > 64 * 1024)
@@ -1126,7 +1148,19 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   mark(0);
   // profiled calls: the two events take the kernel's own start and stop (hipExtLaunchKernelGGL),
   // not the stream's state around it (a recorded event also counts the dispatch gap behind it)
-  if (ev_start)
+  float* const lvl = level_in_fir ? b->st.F(fmd::F_IF_LEVEL) : static_cast<float*>(nullptr);
+  if (kfn3 && ev_start)
+    hipExtLaunchKernelGGL(kfn3, dim3(nblocks), dim3(TILE), unsigned(lds_l), sF, ev_start, ev_stop, 0u, x,
+                          iq_channel_stride, N, (const float2*)b->hist[b->hist_sel].p,
+                          (float2*)b->hist[b->hist_sel ^ 1].p, (const float2*)b->lut.p, T, b->lut_idx,
+                          (const float*)b->if_coeff.p, d.if_order, D, pos, M, (float2*)b->demod[q].p,
+                          b->Mstride, ntiles_l, (C % 8 == 0) ? 1u : 0u, lvl);
+  else if (kfn3)
+    hipLaunchKernelGGL(kfn3, dim3(nblocks), dim3(TILE), lds_l, sF, x, iq_channel_stride, N,
+                       b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, T, b->lut_idx,
+                       b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles_l,
+                       (C % 8 == 0) ? 1u : 0u, lvl);
+  else if (ev_start)
     hipExtLaunchKernelGGL(kfn, dim3(nblocks), dim3(TILE), unsigned(lds_l), sF, ev_start, ev_stop, 0u, x,
                           iq_channel_stride, N, (const float2*)b->hist[b->hist_sel].p,
                           (float2*)b->hist[b->hist_sel ^ 1].p, (const float2*)b->lut.p, T, b->lut_idx,
@@ -1138,8 +1172,9 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
                        b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles_l,
                        (C % 8 == 0) ? 1u : 0u);
   mark(1);
-  hipLaunchKernelGGL(fmd::k_if_level<IN>, dim3(C), dim3(64), 0, sF, x, iq_channel_stride, N, b->lut.p, T,
-                     b->lut_idx, b->st);
+  if (!level_in_fir)
+    hipLaunchKernelGGL(fmd::k_if_level<IN>, dim3(C), dim3(64), 0, sF, x, iq_channel_stride, N, b->lut.p, T,
+                       b->lut_idx, b->st);
   return FMD_OK;
 }
 
@@ -1224,7 +1259,7 @@ void queue_is_free(fmd_batch* b, int es, hipStream_t s)
 /* The light part of one call's post chain on stream s: cRDSRxSignalProcessor's PLL, matched filter
  * and bit recovery, then the audio tail; records the call's EV_RDS / EV_AUD. */
 void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, bool record)
-{
+{ // (s by value: the audio half may move to j.s_audio)
   const fmd::Design& d = b->des;
   const unsigned C = b->C, CP = b->CP;
   const unsigned T_mf = unsigned(d.rds_mf_taps.size());
@@ -1264,6 +1299,9 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     mark_failed(b, "hipEventRecord failed behind the RDS part of a call");
   // the RDS part above only needed the RDS half of the call's heavy part (EV_RDSH, waited for by the
   // caller); the audio tail needs the other half too
+  const hipStream_t s_rds_part = s;
+  if (j.s_audio && record)
+    s = j.s_audio; // the two halves side by side: two chains of lane-per-channel kernels, each shorter than a period
   if (record && hipStreamWaitEvent(s, b->cev[j.es][j.tail_after_alp ? fmd_batch::EV_ALP : fmd_batch::EV_HEAVY], 0) != hipSuccess)
     mark_failed(b, "hipStreamWaitEvent failed in front of the audio tail of a call");
   {
@@ -1274,13 +1312,26 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     k.n_b2 = d.notch.b2;
     k.n_a1 = d.notch.a1;
     k.n_a2 = d.notch.a2;
-    if (j.tl0)
+    if (j.before_tail)
+      j.before_tail();
+    if (j.fuse_alp && j.tl0)
+      hipExtLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3(CP / 64), dim3(64), 0u, s, j.tl0, j.tl1, 0u,
+                            (const float2*)b->rs[j.q].p, b->rs[j.q ^ 1].p, j.A, j.alpf_g,
+                            (const float*)b->audio_taps.p, C, CP, k, b->st, j.d_audio, j.audio_stride,
+                            unsigned(j.sq), j.call_index, unsigned(b->dbg_alt_prio));
+    else if (j.fuse_alp)
+      hipLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3(CP / 64), dim3(64), 0, s, b->rs[j.q].p, b->rs[j.q ^ 1].p,
+                         j.A, j.alpf_g, b->audio_taps.p, C, CP, k, b->st, j.d_audio, j.audio_stride,
+                         unsigned(j.sq), j.call_index, unsigned(b->dbg_alt_prio));
+    else if (j.tl0)
       hipExtLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0u, s, j.tl0, j.tl1, 0u,
                             (const float2*)b->alp[j.q].p, j.A, C, CP, k, b->st, j.d_audio, j.audio_stride,
                             unsigned(j.sq), j.call_index);
     else
       hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, s, b->alp[j.q].p, j.A, C, CP, k,
                          b->st, j.d_audio, j.audio_stride, unsigned(j.sq), j.call_index);
+    if (s != s_rds_part && hipStreamWaitEvent(s, b->cev[j.es][fmd_batch::EV_RDS], 0) != hipSuccess)
+      mark_failed(b, "hipStreamWaitEvent failed in front of the status record of a call"); // its RDS state is the other half's
     hipLaunchKernelGGL(fmd::k_status_publish, dim3((C + 255) / 256), dim3(256), 0, s, b->st, C, j.call_index);
   }
   if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_AUD], s) != hipSuccess)
@@ -1639,10 +1690,18 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   /* Only where the two loops of the pipeline are balanced (short IF filters): with a long IF filter the FIR
    * alone sets the period and the fifth stream only gets in its way (config 5: 3.41 ms per call with it,
    * 3.16 without -- its head waits for events in a hardware queue the FIR's stream shares). */
-  const bool lpf_late = !serial_mode && !b->split_post && b->s_lpf &&
-                        (b->dbg_lpf_late > 0 || (b->dbg_lpf_late < 0 && d.if_order <= 512));
+  /* Round 5: the audio low-pass lives inside the audio tail's kernel (fuse_alp: 29 taps, every reference
+   * configuration), and the RDS low-pass runs at the head of the LIGHT stream, behind the decimator's event and in
+   * front of the RDS PLL that reads it (lpf_light): no fifth stream, nothing of either filter beside the next IF FIR
+   * but what the light part itself does.  "lpf_late" = 0 / 1 brings the heavy-stream / own-stream forms back. */
+  const bool fuse_alp = T_alp == 29 && b->dbg_fuse_alp != 0;
+  const bool lpf_late = !serial_mode && !b->split_post && b->s_lpf && b->dbg_lpf_late == 1;
+  const bool lpf_light = !serial_mode && !b->split_post && (b->dbg_lpf_late < 0 || b->dbg_lpf_late == 2);
   std::function<void()> rds_lpf_late, audio_lpf_late, mix_tail;
-  hipStream_t sLPr = lpf_late ? b->s_lpf : sR, sLPa = lpf_late ? b->s_lpf : sA;
+  // ... and the light part's audio half (the tail's kernel) on the stream the filters had, beside its RDS half
+  const bool light_split = lpf_light && b->s_lpf && b->dbg_light_split != 0;
+  hipStream_t sLPr = lpf_late ? b->s_lpf : lpf_light ? sL : sR;
+  hipStream_t sLPa = (lpf_late || light_split) ? b->s_lpf : lpf_light ? sL : sA;
   // the resampler's form and its plan kernel (tap tables of this call's phases: no input but the positions)
   const unsigned per_step = unsigned(std::max(b->rsr_NW * b->rsr_R, 1));
   const unsigned rs_steps = (A + per_step - 1) / per_step;
@@ -1781,7 +1840,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     else
       hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, sLPr, b->rdsraw[q].p, b->rdsraw[q ^ 1].p, T_lpf - 1, R, CP);
     };
-    if (lpf_late)
+    if (lpf_late || lpf_light)
     { // the low-pass later (see above); what the decimator left to roll waits for the resampler's roll: one
       // launch behind EV_HEAVY (k_roll_set takes four)
       if (nrolls > 3)
@@ -1879,6 +1938,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     roll_later(b->brp(q), b->brp(q ^ 1), Hbb, M); // with the low-pass's own roll, at the chain's end
     mark(6);
     auto lpf = [&]() {
+    if (!fuse_alp)
+    { // (fused: the tail's kernel filters, and keeps the delay line's rows itself)
     const int ring4a = b->dbg_ring4;
     if (ring4a && T_alp >= unsigned(fmd::RG))
       hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (A + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
@@ -1888,9 +1949,10 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                        size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), sLPa, b->rs[q].p, b->alp[q].p, A,
                        int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
     roll_later(b->rs[q].p, b->rs[q ^ 1].p, T_alp - 1, A);
+    }
     roll_flush(sLPa);
     };
-    if (lpf_late)
+    if (lpf_late || lpf_light)
     { // the low-pass (and its own roll) later; the baseband rows' history behind EV_HEAVY (below)
       audio_lpf_late = lpf;
       return;
@@ -1907,6 +1969,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       k.n_b2 = d.notch.b2;
       k.n_a1 = d.notch.a1;
       k.n_a2 = d.notch.a2;
+      if (fuse_alp)
+        hipLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3(CP / 64), dim3(64), 0, sA, b->rs[q].p, b->rs[q ^ 1].p, A,
+                           b->alpf_g, b->audio_taps.p, C, CP, k, b->st, d_audio, audio_channel_stride, unsigned(sq), ci,
+                           unsigned(b->dbg_alt_prio));
+      else
       hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, sA, b->alp[q].p, A, C, CP, k,
                          b->st, d_audio, audio_channel_stride, unsigned(sq), ci);
     }
@@ -1941,10 +2008,12 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       after(sP, pe2[fmd_batch::EV_RDSH]);
       after(sP, pe2[fmd_batch::EV_ALP]);
     }
-    if (lpf_late)
+    if (lpf_light && have_prev2) // (rs[q]'s reader of two calls ago is in front of EV_AUD, waited for above)
+      after(sP, pe2[fmd_batch::EV_RDSH]);
+    if (lpf_late || lpf_light)
       rs_plan(sP); // off the path between the half-band chain and the resampler
     rds_heavy();
-    signal(ce[lpf_late ? fmd_batch::EV_DEC : fmd_batch::EV_RDSH], sR);
+    signal(ce[(lpf_late || lpf_light) ? fmd_batch::EV_DEC : fmd_batch::EV_RDSH], sR);
     audio_heavy();
     signal(ce[fmd_batch::EV_HEAVY], sP); // the next-but-one call's IF FIR may go
     if (mix_tail)
@@ -1970,6 +2039,19 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       signal(ce[fmd_batch::EV_ALP], sl);
     }
     fmd_batch::LightJob job;
+    if (lpf_light)
+    { // the RDS low-pass at the head of the light stream, behind the decimator; the audio one (where it is not
+      // part of the tail's kernel) in front of the tail, behind EV_HEAVY
+      after(sL, ce[fmd_batch::EV_DEC]);
+      rds_lpf_late();
+      signal(ce[fmd_batch::EV_RDSH], sL);
+      if (!fuse_alp)
+        job.before_tail = audio_lpf_late;
+    }
+    job.fuse_alp = fuse_alp;
+    job.alpf_g = b->alpf_g;
+    if (light_split)
+      job.s_audio = b->s_lpf;
     job.R = R;
     job.A = A;
     job.mf_g = b->mf_g;
@@ -2148,7 +2230,15 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
   else if (k == "ring4")
     b->dbg_ring4 = value != 0;
   else if (k == "lpf_late")
-    b->dbg_lpf_late = value < 0 ? -1 : (value ? 1 : 0);
+    b->dbg_lpf_late = value < 0 ? -1 : std::min(value, 2);
+  else if (k == "level_in_fir")
+    b->dbg_level_in_fir = value != 0;
+  else if (k == "light_split")
+    b->dbg_light_split = value != 0;
+  else if (k == "alt_prio")
+    b->dbg_alt_prio = std::max(0, std::min(3, value));
+  else if (k == "fuse_alp")
+    b->dbg_fuse_alp = value != 0;
   else if (k == "prof_dump")
     b->dbg_prof_dump = value != 0;
   else if (k == "fir_ro")

@@ -318,3 +318,34 @@ def test_two_post_streams_overlapped_at_4096_channels(oracle, fmsig, debug):
     pkg = load_package()
     _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, 4096, [N, N, 30001, N, N, 12345, N, N],
                     check=[0, 63, 2047, 2048, 4095], u8=False, debug=debug)
+
+
+def test_fused_audio_tail_and_level_meter_inside_the_fir(oracle, fmsig):
+    """Two opt-in forms (fmd_batch_debug_set "fuse_alp", "level_in_fir"): the 29-tap audio low-pass inside the
+    audio tail's kernel (k_audio_lpf_tail29: cFirFilter::ProcessTwo's ring buffer in registers, FirFilter.cpp:387-413,
+    whole rounds of 29 frames as straight-line code, the frames around them through the generic body) and
+    RMSLevelApprox (FmDecode.cpp:505-519) in the IF FIR's first workgroup of a channel -- on ragged calls: fewer
+    audio frames than taps, calls that start and end in the middle of a round, full blocks."""
+    pkg = load_package()
+    sizes = [N, 10007, 1001, 330, 65535, 150, 33001, N, 2000, 21120, N]
+    _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, 1024, sizes, check=[0, 63, 64, 511, 1023], u8=False,
+                    debug=(("fuse_alp", 1), ("level_in_fir", 1)))
+
+
+def test_audio_low_pass_forms_follow_each_other(oracle, fmsig):
+    """The fused form keeps the low-pass's delay line where the separate kernel's roll keeps it (the front rows of
+    the resampler's output buffer): a batch may change form between any two calls."""
+    pkg = load_package()
+    fs, D, C = 2.4e6, 11, 8
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
+    refs = [oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for _ in range(C)]
+    ps = [fmsig.channel_params(fs, c) for c in range(C)]
+    pos = 0
+    for k, n in enumerate([N, 30001, 500, N, 12345, 200, N, N]):
+        b.debug_set("fuse_alp", k & 1)
+        iq = np.stack([fmsig.generate_f32(p, pos, n) for p in ps]).view(np.complex64)
+        a = b.process_host(iq)
+        for c in range(C):
+            assert _bits_equal(a[c], refs[c].process_stream(iq[c])), (k, c, n)
+        pos += n
+    b.close()
