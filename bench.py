@@ -276,6 +276,9 @@ def main():
     ap.add_argument("--channels", type=int, default=8192, help="channels per GPU")
     ap.add_argument("--ring", type=int, default=10, help="distinct input blocks resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--captures", type=int, default=1,
+                    help="config3 only: G captures x 256 stations each in one batch (config 3 scaled out until it "
+                         "fills the chip; fmd_batch_set_channels_per_capture)")
     ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config5", "config2"],
                     help="config4 (default, the metric's workload): independent channels @2.4 MS/s; "
                          "config2: ONE stereo+RDS decoder through the cFmDecoder surface (fmd_process_stream, host "
@@ -384,7 +387,7 @@ def main():
     elif args.workload == "config3":
         table, shared = 256, True
         if args.channels == 8192:
-            args.channels = 256
+            args.channels = 256 * max(1, args.captures)
     u8 = args.input == "u8"
     if u8 and shared:
         raise SystemExit("--input u8 is implemented for the per-channel workloads")
@@ -403,12 +406,20 @@ def main():
         st = [fmsig_py.default_params(FS, f_offset=f0, amp=0.12, noise_sigma=0.004, seed=50 + i,
                                       pi=0x5000 + i, ps="CAP%05d" % i, f_left=500.0 + 300 * i)
               for i, f0 in enumerate(offs)]
-        gen = fmsig_py.DeviceGenerator(st, dev)
+        G = max(1, args.captures)
+        if C % G:
+            raise SystemExit("--captures must divide --channels")
         tmp = torch.empty((len(st), N, 2), dtype=torch.float32, device=dev)
-        iq = torch.empty((ring, 1, N, 2), dtype=torch.float32, device=dev)
-        for r in range(ring):
-            gen.generate(tmp, r * N, N)
-            iq[r, 0] = tmp.sum(dim=0)
+        iq = torch.empty((ring, G, N, 2), dtype=torch.float32, device=dev)
+        for g in range(G):  # every capture its own six stations (other seeds, tones and PI codes)
+            stg = [fmsig_py.default_params(FS, f_offset=f0, amp=0.12, noise_sigma=0.004, seed=50 + i + 16 * g,
+                                           pi=0x5000 + i + 16 * g, ps="CAP%05d" % (i + 16 * g),
+                                           f_left=500.0 + 300 * i + 7 * g)
+                   for i, f0 in enumerate(offs)] if g else st
+            gen = fmsig_py.DeviceGenerator(stg, dev)
+            for r in range(ring):
+                gen.generate(tmp, r * N, N)
+                iq[r, g] = tmp.sum(dim=0)
     else:
         chans = [fmsig_py.channel_params(FS, rank * C + c) for c in range(C)]
         gen = fmsig_py.DeviceGenerator(chans, dev)
@@ -425,11 +436,15 @@ def main():
     # development aid: other users of hardware queues in the process, created first
     extra_streams = [torch.cuda.Stream(device=dev)
                      for _ in range(int(os.environ.get("FMD_BENCH_EXTRA_STREAMS", "0")))]
+    G = max(1, args.captures) if shared else 1
+    cpc = C // G  # channels per capture
     shifts = (np.arange(C, dtype=np.int32) % table) - table // 2 if shared else None
     batch = pkg.Batch(pkg.make_params(FS, 0.0 if shared else -0.15 * FS, 48000.0, 15000.0, D,
                                       table_size=table, if_filter_order=order,
                                       fir_reduction=0x101 if args.fir_reduction else 0),
                       C, tuning_shifts=shifts, device=local_rank, record_callbacks=False)
+    if G > 1:
+        batch.set_channels_per_capture(cpc)
     for kv in args.debug_set:
         key, _, val = kv.partition("=")
         batch.debug_set(key, int(val))
@@ -533,7 +548,7 @@ def main():
         slot = i % NBUF
         release(slot)
         th0 = time.perf_counter()
-        nf = batch.process_device(iq[i % ring].data_ptr(), 0 if shared else N, N,
+        nf = batch.process_device(iq[i % ring].data_ptr(), (N if G > 1 else 0) if shared else N, N,
                                   audio[slot].data_ptr(), a_stride, stream, u8=u8)
         host_t["process"] += time.perf_counter() - th0
         state["submitted"] = i
@@ -608,7 +623,11 @@ def main():
             vaudio = torch.zeros((nv, a_stride), dtype=torch.float32, device=dev)
             bad = []
             for i in range(V):
-                if shared:
+                if shared and G > 1:  # the verify batch takes a row per channel: each pick's own capture
+                    for j in range(nv):
+                        viq[j].copy_(iq[i % ring][picks[j % len(picks)] // cpc])
+                    src, vstride = viq, N
+                elif shared:
                     src, vstride = iq[i % ring], 0
                 else:
                     vgen.generate(viq, (i % ring) * N, N)
@@ -792,7 +811,7 @@ def main():
         # algorithmic bytes of the fused tuner+FIR kernel: read 8 B per IQ sample (8/C for a capture
         # shared by C channels), write 8/D B; one launch processes C*N samples.
         in_bytes = 2.0 if u8 else 8.0
-        bytes_per_launch = samples_per_step * ((in_bytes / C if shared else in_bytes) + 8.0 / D)
+        bytes_per_launch = samples_per_step * ((in_bytes / cpc if shared else in_bytes) + 8.0 / D)
         taps = order if order else 8 * D
         flops_per_launch = samples_per_step * (6.0 + 4.0 * taps / D)
         achieved = bytes_per_launch / (fir_ms * 1e-3) / 1e9
@@ -805,8 +824,10 @@ def main():
                 "config4": "BASELINE configs[3] per-GPU shard: %d independent FM stereo+RDS "
                            "channels/GPU @2.4 MS/s, 65536 IQ/channel/step, D=11, 88-tap IF FIR, "
                            "full ProcessStream path" % C,
-                "config3": "BASELINE configs[2]: %d channels freq-shifted from ONE shared 2.4 MS/s "
-                           "capture (table_size 256), full ProcessStream path" % C,
+                "config3": ("BASELINE configs[2]: %d channels freq-shifted from ONE shared 2.4 MS/s "
+                            "capture (table_size 256), full ProcessStream path" % C) if G == 1 else
+                           ("BASELINE configs[2] scaled out: %d captures x %d channels freq-shifted from each "
+                            "(2.4 MS/s, table_size 256), full ProcessStream path" % (G, cpc)),
                 "config5": ("BASELINE configs[4]: %d channels @10 MS/s, D=46, 4096-tap IF FIR, full "
                             "ProcessStream path" % C) if not os.environ.get("FMD_BENCH_GEOM") else
                            ("dev geometry %d channels @%.3g MS/s, D=%d, %d-tap IF FIR" % (C, FS / 1e6, D, order))}[
@@ -817,6 +838,8 @@ def main():
                        "fir_reduction": "sequential (bit-exact)" if args.fir_reduction == 0
                        else "shuffle (opt-in, NOT bit-exact)",
                        "channels_per_gpu": C, "samples_per_call": N, "input_ring_blocks": ring,
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "internal_streams_sharing_a_hw_queue": batch.streams_sharing_queue(),
                        "audio_floats_per_channel_step": nf, "rds_groups_in_timed_region": total_groups,
                        "gather": ("rank-0 gather of audio + RDS records per step over %s (%d rank%s)"
                                   % ("RCCL, grouped ncclSend / ncclRecv from C++ (include/fmd_gather.h)"
@@ -857,7 +880,7 @@ def main():
                 out["roofline"]["traffic"] = t["bytes_per_launch"]
                 out["roofline"]["traffic_source"] = t["source"]
         # what the whole path moves per call against what the algorithm needs (input once, audio once)
-        algo_call = samples_per_step * ((in_bytes / C if shared else in_bytes)) + C * nf * 4.0
+        algo_call = samples_per_step * ((in_bytes / cpc if shared else in_bytes)) + C * nf * 4.0
         out["algorithmic_bytes_per_call"] = int(algo_call)
         fpath = os.path.join(ROOT, "profiles", "traffic_per_call.json")
         out["fabric_bytes_per_call"] = None

@@ -147,6 +147,12 @@ int fmd_batch_reset(fmd_batch* b);
 
 /* upper bounds for sizing caller buffers */
 unsigned fmd_batch_channels(const fmd_batch* b);
+/* How many of the batch's internal streams share a hardware queue with another stream of the process
+ * (found by a probe when the batch was created; 0 = every chain of a call can overlap the others as measured).
+ * HIP maps streams onto GPU_MAX_HW_QUEUES queues -- 4 unless the host process sets that variable before the
+ * runtime initialises; the library reads no environment variable.  When the number is not 0, fmd_batch_create
+ * still returns FMD_OK and leaves a sentence saying so in fmd_last_error(). */
+int fmd_batch_streams_sharing_queue(const fmd_batch* b);
 /* smallest `samples` a process call of this batch accepts (see FMD_MIN_BLOCK) */
 unsigned fmd_batch_min_samples(const fmd_batch* b);
 unsigned fmd_batch_max_audio_floats(const fmd_batch* b, unsigned samples);
@@ -208,6 +214,14 @@ int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap,
  * One stream at a time: concurrent exports of one batch on different streams are not supported. */
 int fmd_batch_export_rds_device(fmd_batch* b, int32_t* d_records, unsigned cap, unsigned channel_offset,
                                 int lag, void* stream);
+
+/* Several captures in one batch (BASELINE configs[2] scaled out: G captures x k stations each, where config 3
+ * as written is one capture x 256): channels [g k, (g + 1) k) all tune capture g -- the only stage that sees the
+ * capture is the tuner in front of the IF filter (cFineTuner::Process, FmDecode.cpp:66-82); everything behind it is
+ * per channel as ever.  With k > 1 the iq_channel_stride of the process calls is the distance between CAPTURES
+ * (G = channels / k input rows instead of one per channel); k = 0 / 1 restores one row per channel.  iq_channel_stride
+ * == 0 still means a single capture for the whole batch.  Not while calls are in flight (the device is drained). */
+int fmd_batch_set_channels_per_capture(fmd_batch* b, unsigned channels_per_capture);
 
 /* Internal execution.  A call is four independent kernel chains (FIR -> serial demodulator ->
  * {RDS branch, audio branch}); mode selects where they run:

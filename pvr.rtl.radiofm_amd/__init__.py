@@ -106,7 +106,7 @@ EXPORTS = [
     "fmd_batch_min_samples",
     "fmd_batch_max_audio_floats", "fmd_batch_process_device", "fmd_batch_process_host",
     "fmd_batch_collect_rds", "fmd_batch_collect_rds_lagged", "fmd_batch_export_rds_device",
-    "fmd_batch_set_concurrency",
+    "fmd_batch_set_concurrency", "fmd_batch_set_channels_per_capture", "fmd_batch_streams_sharing_queue",
     "fmd_batch_wait", "fmd_batch_wait_lagged", "fmd_batch_get_status", "fmd_batch_get_tap", "fmd_batch_get_design",
     "fmd_batch_set_debug_taps", "fmd_batch_set_profiling", "fmd_batch_get_stage_ms", "fmd_stage_name", "fmd_last_error",
     "fmd_version", "fmd_group_decoder_create", "fmd_group_decoder_destroy",
@@ -163,6 +163,8 @@ def lib():
         L.fmd_batch_collect_rds_lagged.argtypes = [vp, vp, u, i, i, vp]
         L.fmd_batch_export_rds_device.argtypes = [vp, vp, u, u, i, vp]
         L.fmd_batch_set_concurrency.argtypes = [vp, i]
+        L.fmd_batch_set_channels_per_capture.argtypes = [vp, u]
+        L.fmd_batch_streams_sharing_queue.argtypes = [vp]
         L.fmd_batch_wait.argtypes = [vp, vp]
         L.fmd_batch_wait_lagged.argtypes = [vp, i, vp]
         L.fmd_batch_get_status.argtypes = [vp, u, C.POINTER(FmdStatus)]
@@ -295,7 +297,7 @@ class Batch:
             n = iq.size
             stride = 0
         else:
-            iq = iq.reshape(self.n_channels, -1)
+            iq = iq.reshape(self.n_channels // getattr(self, "channels_per_capture", 1), -1)
             n = iq.shape[1]
             stride = n
         a_stride = self.max_audio_floats(n)
@@ -351,6 +353,15 @@ class Batch:
         (fmd_batch_export_rds_device), asynchronously on `stream`.  True: groups were lost."""
         return _check(lib().fmd_batch_export_rds_device(self._h, d_records_ptr, cap, channel_offset, lag,
                                                         stream)) == FMD_WARN_RDS_LOST
+
+    def streams_sharing_queue(self):
+        """Internal streams that share a hardware queue with another stream of the process (0: none)."""
+        return lib().fmd_batch_streams_sharing_queue(self._h)
+
+    def set_channels_per_capture(self, k):
+        """k consecutive channels tune the same capture; the process calls then take one input row per capture."""
+        _check(lib().fmd_batch_set_channels_per_capture(self._h, int(k)))
+        self.channels_per_capture = max(1, int(k))
 
     def set_concurrency(self, mode):
         _check(lib().fmd_batch_set_concurrency(self._h, int(mode)))

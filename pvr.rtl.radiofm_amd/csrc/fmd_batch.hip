@@ -106,6 +106,8 @@ struct fmd_batch
 
   // geometry
   unsigned min_samples = 0; // smallest call this geometry takes (fmd_batch_min_samples)
+  int streams_sharing = 0;  // internal streams the create-time probe found sharing a hardware queue
+  unsigned cpc = 1;         // channels per capture (fmd_batch_set_channels_per_capture): channel c reads capture c / cpc
   unsigned Mmax = 0, Mstride = 0, Amax = 0, Rmax = 0;
   std::vector<unsigned> hb_nmax; // max input length per HB stage
   // last call
@@ -175,6 +177,7 @@ struct fmd_batch
                                // stream, 1 a stream of their own, 2 the light stream (in front of their readers)
   int dbg_level_in_fir = 0;    // 1: RMSLevelApprox inside k_if_fir_mt3's first workgroup of a channel (0: k_if_level)
   int dbg_light_split = 1;     // the light part's audio half on its own stream, beside the RDS half
+  int dbg_lpf_prio = 0;        // wave priority of the two complex low-pass filters (k_ring_fir4<float2>)
   int dbg_alt_prio = 3;        // wave priority of k_audio_lpf_tail29
   int dbg_fuse_alp = 0;        // 1: 29-tap audio low-pass inside the audio tail's kernel (k_audio_lpf_tail29): 0.15 GB
                                // per call less, bit-identical, but no faster as a whole and the IF FIR beside it
@@ -556,8 +559,8 @@ int do_reset(fmd_batch* b)
  * chain: measured -13 % when just one unrelated stream created earlier shifted the assignment).
  * So the internal streams are picked by measurement: candidates are created until `n` of them run
  * a no-op kernel at once while all already chosen ones are kept busy by a spinning wave. */
-int pick_independent_streams(int n, const int* priority, hipStream_t* out)
-{
+int pick_independent_streams(int n, const int* priority, hipStream_t* out, int* n_sharing)
+{ // *n_sharing: how many of the n streams had to be taken although the probe found them behind another one
   std::vector<hipStream_t> rejected;
   int have = 0;
   for (int attempt = 0; attempt < 24 && have < n; attempt++)
@@ -588,10 +591,12 @@ int pick_independent_streams(int n, const int* priority, hipStream_t* out)
       rejected.push_back(cand);
   }
   // whatever is still missing (no independent queue left): take the rejected ones, it still works
+  *n_sharing = 0;
   while (have < n && !rejected.empty())
   {
     out[have++] = rejected.back();
     rejected.pop_back();
+    ++*n_sharing;
   }
   for (hipStream_t s : rejected)
     (void)hipStreamDestroy(s);
@@ -971,7 +976,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     // low-pass filters' as well: -1.6 %)
     const int prio[5] = {hi, hi, lo, lo, lo};
     hipStream_t st4[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (pick_independent_streams(nstreams, prio, st4) != 0)
+    if (pick_independent_streams(nstreams, prio, st4, &b->streams_sharing) != 0)
       return fail(FMD_ERR_DEVICE, "could not create the internal streams");
     b->s_fir = st4[0];
     b->s_ser = st4[1];
@@ -1009,6 +1014,15 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     if (rc != FMD_OK)
       return rc;
   }
+  if (b->streams_sharing > 0)
+    // not an error: the batch works, its chains just queue behind each other where they were meant to overlap.
+    // The text stays in fmd_last_error() (the call still returns FMD_OK); fmd_batch_streams_sharing_queue() has
+    // the number.  HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the HOST sets the
+    // variable before the runtime starts -- the library reads no environment variable itself).
+    (void)fail(FMD_OK, std::to_string(b->streams_sharing) +
+                           " of the batch's 5 internal streams share a hardware queue with another stream of this "
+                           "process: overlapped calls will be slower than measured (host: GPU_MAX_HW_QUEUES=8 "
+                           "before the HIP runtime initialises)");
   *out = b.release();
   return FMD_OK;
 }
@@ -1035,6 +1049,11 @@ unsigned fmd_batch_channels(const fmd_batch* b)
   return b ? b->C : 0;
 }
 
+int fmd_batch_streams_sharing_queue(const fmd_batch* b)
+{
+  return b ? b->streams_sharing : -1;
+}
+
 unsigned fmd_batch_min_samples(const fmd_batch* b)
 {
   return b ? b->min_samples : 0;
@@ -1058,12 +1077,12 @@ namespace
 template <class IN>
 using FirFn = void (*)(const typename IN::elem*, size_t, unsigned, const float2*, float2*, const float2*,
                        unsigned, unsigned, const float*, unsigned, unsigned, unsigned, unsigned, float2*,
-                       unsigned, unsigned, unsigned);
+                       unsigned, unsigned, unsigned, unsigned);
 
 template <class IN>
 using FirFn3 = void (*)(const typename IN::elem*, size_t, unsigned, const float2*, float2*, const float2*,
                         unsigned, unsigned, const float*, unsigned, unsigned, unsigned, unsigned, float2*,
-                        unsigned, unsigned, unsigned, float*);
+                        unsigned, unsigned, unsigned, unsigned, float*);
 
 template <class IN, int TILE, int E, bool RB128 = false>
 int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
@@ -1154,27 +1173,27 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
                           iq_channel_stride, N, (const float2*)b->hist[b->hist_sel].p,
                           (float2*)b->hist[b->hist_sel ^ 1].p, (const float2*)b->lut.p, T, b->lut_idx,
                           (const float*)b->if_coeff.p, d.if_order, D, pos, M, (float2*)b->demod[q].p,
-                          b->Mstride, ntiles_l, (C % 8 == 0) ? 1u : 0u, lvl);
+                          b->Mstride, ntiles_l, (C % 8 == 0) ? 1u : 0u, b->cpc, lvl);
   else if (kfn3)
     hipLaunchKernelGGL(kfn3, dim3(nblocks), dim3(TILE), lds_l, sF, x, iq_channel_stride, N,
                        b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, T, b->lut_idx,
                        b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles_l,
-                       (C % 8 == 0) ? 1u : 0u, lvl);
+                       (C % 8 == 0) ? 1u : 0u, b->cpc, lvl);
   else if (ev_start)
     hipExtLaunchKernelGGL(kfn, dim3(nblocks), dim3(TILE), unsigned(lds_l), sF, ev_start, ev_stop, 0u, x,
                           iq_channel_stride, N, (const float2*)b->hist[b->hist_sel].p,
                           (float2*)b->hist[b->hist_sel ^ 1].p, (const float2*)b->lut.p, T, b->lut_idx,
                           (const float*)b->if_coeff.p, d.if_order, D, pos, M, (float2*)b->demod[q].p,
-                          b->Mstride, ntiles_l, (C % 8 == 0) ? 1u : 0u);
+                          b->Mstride, ntiles_l, (C % 8 == 0) ? 1u : 0u, b->cpc);
   else
     hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(TILE), lds_l, sF, x, iq_channel_stride, N,
                        b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, T, b->lut_idx,
                        b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles_l,
-                       (C % 8 == 0) ? 1u : 0u);
+                       (C % 8 == 0) ? 1u : 0u, b->cpc);
   mark(1);
   if (!level_in_fir)
     hipLaunchKernelGGL(fmd::k_if_level<IN>, dim3(C), dim3(64), 0, sF, x, iq_channel_stride, N, b->lut.p, T,
-                       b->lut_idx, b->st);
+                       b->lut_idx, b->st, b->cpc);
   return FMD_OK;
 }
 
@@ -1284,7 +1303,7 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     if (T_mf >= unsigned(fmd::RG))
       hipLaunchKernelGGL(fmd::k_ring_fir4<float>, dim3(CP / 64, (j.R + 4 * fmd::RG - 1) / (4 * fmd::RG)),
                          dim3(64, 4), 0, s, b->rpll.p, b->rmf.p, j.R, int(T_mf), b->mf_taps2.p, j.mf_g, C, CP,
-                         0u);
+                         0u, 3u);
     else
       hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (j.R + fmd::RF_TI - 1) / fmd::RF_TI),
                          dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), s, b->rpll.p,
@@ -1827,7 +1846,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     if (ring4 && T_lpf >= unsigned(fmd::RG))
       hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
                          sLPr, b->rdsraw[q].p, b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C,
-                         CP, 0u);
+                         CP, 0u, unsigned(b->dbg_lpf_prio));
     else
     hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
                        size_t(T_lpf - 1 + fmd::RF_TI) * 64 * sizeof(float2), sLPr, b->rdsraw[q].p,
@@ -1876,7 +1895,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       if (T_mf >= unsigned(fmd::RG))
         hipLaunchKernelGGL(fmd::k_ring_fir4<float>, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)),
                            dim3(64, 4), 0, sR, b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C,
-                           CP, 0u);
+                           CP, 0u, 3u);
       else
         hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI),
                            dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), sR,
@@ -1943,7 +1962,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     const int ring4a = b->dbg_ring4;
     if (ring4a && T_alp >= unsigned(fmd::RG))
       hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (A + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
-                         sLPa, b->rs[q].p, b->alp[q].p, A, int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
+                         sLPa, b->rs[q].p, b->alp[q].p, A, int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u, unsigned(b->dbg_lpf_prio));
     else
     hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (A + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
                        size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), sLPa, b->rs[q].p, b->alp[q].p, A,
@@ -2235,6 +2254,8 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
     b->dbg_level_in_fir = value != 0;
   else if (k == "light_split")
     b->dbg_light_split = value != 0;
+  else if (k == "lpf_prio")
+    b->dbg_lpf_prio = std::max(0, std::min(3, value));
   else if (k == "alt_prio")
     b->dbg_alt_prio = std::max(0, std::min(3, value));
   else if (k == "fuse_alp")
@@ -2310,6 +2331,19 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
 int fmd_batch_wait(fmd_batch* b, void* stream_)
 {
   return fmd_batch_wait_lagged(b, 0, stream_);
+}
+
+int fmd_batch_set_channels_per_capture(fmd_batch* b, unsigned channels_per_capture)
+{
+  if (!b)
+    return fail(FMD_ERR_ARG, "null batch");
+  const unsigned k = channels_per_capture ? channels_per_capture : 1u;
+  if (b->C % k)
+    return fail(FMD_ERR_ARG, "fmd_batch_set_channels_per_capture: the channel count is not a multiple of it");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  b->cpc = k;
+  return FMD_OK;
 }
 
 int fmd_batch_set_concurrency(fmd_batch* b, int mode)
@@ -2464,7 +2498,8 @@ static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t 
   // device copy: one row per channel, rows padded to a whole pair of samples
   const size_t dev_row = (size_t(samples) + 1) / 2 * 2 * esz;
   const size_t dev_iq_stride = iq_channel_stride ? dev_row / esz : 0;
-  const size_t iq_floats = (dev_row * (iq_channel_stride ? C : 1) + 3) / 4;
+  const unsigned streams = iq_channel_stride ? C / b->cpc : 1u; // input rows: one per channel, per capture, or one
+  const size_t iq_floats = (dev_row * streams + 3) / 4;
   const size_t a_stride = (size_t(fmd_batch_max_audio_floats(b, samples)) + 3) & ~size_t(3);
   if (iq_floats > b->h_iq_cap)
   {
@@ -2484,7 +2519,7 @@ static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t 
   auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
   clk::time_point tp = clk::now();
   if (iq_channel_stride)
-    HIPCHK(hipMemcpy2D(b->h_iq.p, dev_row, iq, iq_channel_stride * esz, size_t(samples) * esz, C,
+    HIPCHK(hipMemcpy2D(b->h_iq.p, dev_row, iq, iq_channel_stride * esz, size_t(samples) * esz, streams,
                        hipMemcpyHostToDevice));
   else
     HIPCHK(hipMemcpy(b->h_iq.p, iq, size_t(samples) * esz, hipMemcpyHostToDevice));

@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
                                                  unsigned lut_idx0, const float* __restrict__ coeff,
                                                  unsigned order, unsigned D, unsigned pos, unsigned M,
                                                  float2* __restrict__ out, unsigned Mstride,
-                                                 unsigned ntiles, unsigned xcd_map)
+                                                 unsigned ntiles, unsigned xcd_map, unsigned cpc)
 {
   typedef typename IN::pair pair_t;
   constexpr int G = 1 << E; // regions of the de-interleaved window
@@ -1127,7 +1127,8 @@ __global__ __launch_bounds__(TILE) void k_if_fir(const typename IN::elem* __rest
   const int k_hi = p_first + (int)((nout - 1) * D); // one past the last sample it needs
   // floor to a pair boundary (and to a region-0 slot): window slot of sample k is k - k_al
   const int k_al = k_lo & ~((G > 2 ? G : 2) - 1);
-  const typename IN::elem* __restrict__ x = iq + (size_t)c * chan_stride;
+  // (cpc > 1: channels_per_capture consecutive channels tune the same capture, chan_stride apart)
+  const typename IN::elem* __restrict__ x = iq + (size_t)(cpc > 1u ? c / cpc : c) * chan_stride;
   const float2* __restrict__ l = lut + (size_t)c * T;
 
   if (k_lo < 0)
@@ -1420,7 +1421,7 @@ __global__ __launch_bounds__(64) void k_if_fir_mt(const typename IN::elem* __res
                                                   unsigned lut_idx0, const float* __restrict__ coeff,
                                                   unsigned order, unsigned D, unsigned pos, unsigned M,
                                                   float2* __restrict__ out, unsigned Mstride,
-                                                  unsigned ntiles, unsigned xcd_map)
+                                                  unsigned ntiles, unsigned xcd_map, unsigned cpc)
 {
   typedef typename IN::pair pair_t;
   constexpr int TILE = 64;
@@ -1440,7 +1441,8 @@ __global__ __launch_bounds__(64) void k_if_fir_mt(const typename IN::elem* __res
     tg = blockIdx.x % ngroups;
   }
   const unsigned tid = threadIdx.x;
-  const typename IN::elem* __restrict__ x = iq + (size_t)c * chan_stride;
+  // (cpc > 1: channels_per_capture consecutive channels tune the same capture, chan_stride apart)
+  const typename IN::elem* __restrict__ x = iq + (size_t)(cpc > 1u ? c / cpc : c) * chan_stride;
   const float2* __restrict__ l = lut + (size_t)c * T;
   const unsigned mask = T - 1;
   const int kfull_all = (int)(N & ~1u);
@@ -1581,7 +1583,7 @@ __global__ __launch_bounds__(64) void k_if_fir_mt3(const typename IN::elem* __re
                                                    unsigned lut_idx0, const float* __restrict__ coeff,
                                                    unsigned order, unsigned D, unsigned pos, unsigned M,
                                                    float2* __restrict__ out, unsigned Mstride,
-                                                   unsigned ntiles, unsigned xcd_map,
+                                                   unsigned ntiles, unsigned xcd_map, unsigned cpc,
                                                    float* __restrict__ if_level)
 {
   typedef typename IN::pair pair_t;
@@ -1605,7 +1607,8 @@ __global__ __launch_bounds__(64) void k_if_fir_mt3(const typename IN::elem* __re
     tg = blockIdx.x % ngroups;
   }
   const unsigned tid = threadIdx.x;
-  const typename IN::elem* __restrict__ x = iq + (size_t)c * chan_stride;
+  // (cpc > 1: channels_per_capture consecutive channels tune the same capture, chan_stride apart)
+  const typename IN::elem* __restrict__ x = iq + (size_t)(cpc > 1u ? c / cpc : c) * chan_stride;
   const float2* __restrict__ l = lut + (size_t)c * T;
   const unsigned mask = T - 1;
   const int kfull_all = (int)(N & ~1u);
@@ -1792,12 +1795,13 @@ template <class IN>
 __global__ __launch_bounds__(64) void k_if_level(const typename IN::elem* __restrict__ iq,
                                                  size_t chan_stride, unsigned N,
                                                  const float2* __restrict__ lut, unsigned T,
-                                                 unsigned lut_idx0, ChannelState st)
+                                                 unsigned lut_idx0, ChannelState st, unsigned cpc)
 {
   __shared__ float term[1024];
   const unsigned c = blockIdx.x;
   const unsigned n = (N + 63) / 64; // <= 1024 for N <= 65536
-  const typename IN::elem* __restrict__ x = iq + (size_t)c * chan_stride;
+  // (cpc > 1: channels_per_capture consecutive channels tune the same capture, chan_stride apart)
+  const typename IN::elem* __restrict__ x = iq + (size_t)(cpc > 1u ? c / cpc : c) * chan_stride;
   const float2* __restrict__ l = lut + (size_t)c * T;
   for (unsigned i = threadIdx.x; i < n; i += 64)
   {
@@ -2859,12 +2863,12 @@ __device__ __forceinline__ void ring_dispatch(unsigned take, const E* __restrict
 template <typename E>
 __global__ __launch_bounds__(256) void k_ring_fir4(const E* __restrict__ in, E* __restrict__ out,
                                                    unsigned n, int T, const float* __restrict__ taps,
-                                                   unsigned g0, unsigned C, unsigned CP, unsigned Hout)
+                                                   unsigned g0, unsigned C, unsigned CP, unsigned Hout,
+                                                   unsigned prio)
 {
   // the real instance is the matched filter between two lane-per-channel kernels of the light part:
-  // short, and the light part should be over before the next FIR starts -> issue first, like them
-  if (sizeof(E) == sizeof(float))
-    __builtin_amdgcn_s_setprio(3);
+  // short, and the light part should be over before the next FIR starts -> issue first, like them (prio 3)
+  wave_prio(prio);
   const unsigned c = blockIdx.x * 64 + threadIdx.x; // < CP: the row buffers are padded
   const unsigned y = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
   unsigned i = (blockIdx.y * blockDim.y + y) * RG;

@@ -45,6 +45,69 @@ def test_config3_many_channels_from_one_capture(oracle, fmsig):
     assert b.status(64).pilot_level > 0.08 > abs(b.status(0).pilot_level)
 
 
+@pytest.mark.parametrize("device_call", [False, True], ids=["host-buffers", "device-buffers-overlapped"])
+def test_config3_scaled_out_several_captures_in_one_batch(oracle, fmsig, device_call):
+    """Config 3 scaled out ("a shared capture"): G captures x k stations each in ONE batch
+    (fmd_batch_set_channels_per_capture) -- channels [g k, (g + 1) k) tune capture g, the process calls take one
+    input row per capture.  4 captures x 64 channels = 256 here, through the host-buffer call and through
+    device-resident overlapped calls with ragged sizes; per capture several channels bit for bit against the
+    oracle fed THAT capture with the same shift (the only stage that sees the capture is the tuner,
+    FmDecode.cpp:66-82)."""
+    pkg = load_package()
+    fs, D, G, k, T = 2.4e6, 11, 4, 64, 256
+    C = G * k
+    offs = (-600e3, -360e3, -150e3, 75e3, 300e3, 600e3)
+    caps = [[fmsig.default_params(fs, f_offset=f0, amp=0.12, noise_sigma=0.004, seed=50 + i + 16 * g,
+                                  pi=0x5000 + i + 16 * g, ps="CAP%05d" % (i + 16 * g), f_left=500.0 + 300 * i + 7 * g)
+             for i, f0 in enumerate(offs)] for g in range(G)]
+    shifts = (np.arange(C, dtype=np.int32) % k) * 4 - 128  # every capture: 64 shifts across the band
+    b = pkg.Batch(pkg.make_params(fs, 0.0, 48000.0, 15000.0, D, table_size=T), C, tuning_shifts=shifts,
+                  record_callbacks=False)
+    b.set_channels_per_capture(k)
+    check = [0, 16, 63, 64, 80, 127, 128 + 48, 255]
+    refs = {c: oracle.OracleDecoder(fs, 0.0, 48000.0, 15000.0, D, table_size=T, tuning_shift=int(shifts[c]))
+            for c in check}
+    sizes = [N, 30001, N, 12346, N, N] if device_call else [N] * 5
+    pos, blocks = 0, []
+    for n in sizes:
+        cap = np.zeros((G, 2 * n), dtype=np.float32)
+        for g in range(G):
+            for p in caps[g]:
+                cap[g] += fmsig.generate_f32(p, pos, n)
+        blocks.append(cap)
+        pos += n
+    if not device_call:
+        for blk, cap in enumerate(blocks):
+            audio = b.process_host(cap.view(np.complex64))
+            for c in check:
+                assert _bits_equal(audio[c], refs[c].process_stream(cap[c // k])), (blk, c)
+    else:
+        import torch
+        b.set_concurrency(2)
+        a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
+        st = torch.cuda.current_stream().cuda_stream
+        d_iq, d_audio, nf = [], [], []
+        for cap in blocks:
+            n = cap.shape[1] // 2
+            n_al = (n + 1) // 2 * 2
+            t = torch.zeros((G, n_al, 2), dtype=torch.float32, device="cuda")
+            t[:, :n] = torch.from_numpy(cap.reshape(G, n, 2)).cuda()
+            d_iq.append((t, n, n_al))
+            d_audio.append(torch.zeros((C, a_stride), dtype=torch.float32, device="cuda"))
+        torch.cuda.synchronize()
+        for i, (t, n, n_al) in enumerate(d_iq):
+            nf.append(b.process_device(t.data_ptr(), n_al, n, d_audio[i].data_ptr(), a_stride, st))
+        b.wait(stream=st)
+        torch.cuda.synchronize()
+        for blk, cap in enumerate(blocks):
+            a = d_audio[blk][:, :nf[blk]].cpu().numpy()
+            for c in check:
+                assert _bits_equal(a[c], refs[c].process_stream(cap[c // k])), (blk, c)
+    # capture g's station at +600 kHz is brought to 0 by shift -64: channel g k + 16 sees a pilot
+    assert all(b.status(g * k + 16).pilot_level > 0.08 for g in range(G))
+    b.close()
+
+
 def test_config5_long_fir_10msps(oracle, fmsig):
     """BASELINE config 5 geometry: 4096-tap cDownsampleFilter at 10 MS/s, D = 46."""
     pkg = load_package()
