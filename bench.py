@@ -367,11 +367,16 @@ def main():
     if dist_on and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29549")
+    # FMD_BENCH_RENDEZVOUS=gloo (with the nccl data path): torch.distributed only carries the rendezvous and the
+    # barriers, over gloo on the host -- then the process holds ONE RCCL communicator (the C++ gather's) instead of
+    # two (torch's process group has its own, with its streams and proxy thread)
+    pg_backend = os.environ.get("FMD_BENCH_RENDEZVOUS", backend)
+    pg_dev = dev if pg_backend == "nccl" else "cpu"
     if dist_on:
-        if backend == "nccl":
+        if pg_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=pg_backend, rank=rank, world_size=world)
 
     global FS, D
     order = 0
@@ -431,7 +436,7 @@ def main():
     # the communicator (and its streams) first: the decoder picks its internal streams by a probe
     # when the batch is created and should see everything else that uses hardware queues
     if dist_on:
-        dg.gather_preflight(dev if backend == "nccl" else "cpu")
+        dg.gather_preflight(pg_dev)
     comm_stream = torch.cuda.Stream(device=dev) if dist_on else None
     # development aid: other users of hardware queues in the process, created first
     extra_streams = [torch.cuda.Stream(device=dev)
@@ -465,12 +470,19 @@ def main():
         # rank * size; torch.distributed.gather takes the list of the parts)
         g_audio = [torch.empty((world, C, a_stride), dtype=torch.float32, device=on) for _ in range(NBUF)]
         g_rds = [torch.empty((world, RCAP, 4), dtype=torch.int32, device=on) for _ in range(NBUF)]
+        if on == dev and backend == "nccl" and dist_on:
+            # rank 0 has its own outputs produced IN PLACE, in its part of the receive buffers: the gather then has
+            # nothing to copy for it (fmd_gather_step: d_audio == d_all_audio), 88 MB per step less through HBM
+            audio = [g[0] for g in g_audio]
+            rds_dev = [g[0] for g in g_rds]
+            for t in rds_dev:
+                t.zero_()
     # RCCL: the data path is the C++ gather of include/fmd_gather.h (grouped ncclSend / ncclRecv on a
     # stream of its own); its communicator's id travels over the torch.distributed rendezvous
     gth = None
     if dist_on and backend == "nccl":
         gmod = importlib.import_module(pkg.__name__ + ".gather")
-        uid = torch.zeros(gmod.ID_BYTES, dtype=torch.uint8, device=dev)
+        uid = torch.zeros(gmod.ID_BYTES, dtype=torch.uint8, device=pg_dev)
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(gmod.unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, src=0)
@@ -593,7 +605,7 @@ def main():
             dist.barrier()
 
     def reduce_scalar(x, op):
-        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t = torch.tensor([x], dtype=torch.float64, device=pg_dev)
         dist.all_reduce(t, op=op)
         return float(t.item())
 
@@ -751,7 +763,7 @@ def main():
     per_rank = None
     if dist_on:
         mine = torch.tensor([dt_own / K * 1e3, fir_ms, -1.0 if gather_ms is None else gather_ms],
-                            dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                            dtype=torch.float64, device=pg_dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "ms_per_step": round(float(t[0]), 4), "if_fir_ms": round(float(t[1]), 4),
@@ -763,7 +775,7 @@ def main():
             # show ranks_seen 1 here
             gi = gth.info()
             mine_i = torch.tensor([gi["ranks_seen"], gi["rank"], gi["device"], gi["steps_issued"]],
-                                  dtype=torch.int64, device=dev)
+                                  dtype=torch.int64, device=pg_dev)
             alli = [torch.zeros_like(mine_i) for _ in range(world)]
             dist.all_gather(alli, mine_i)
             for r, t in enumerate(alli):

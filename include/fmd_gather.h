@@ -49,7 +49,8 @@ void fmd_gather_destroy(fmd_gather* g);
  * offset by channel_offset, on `stream`); then, behind everything `stream` has been given so far
  * (the caller has ordered it behind the calls whose audio is in d_audio: fmd_batch_wait_lagged), the
  * library's own stream sends d_audio and d_rds; rank 0 receives rank r's into
- * d_all_audio + r * audio_floats and d_all_rds + r * rds_rows * 4 (its own by a device copy).  Returns
+ * d_all_audio + r * audio_floats and d_all_rds + r * rds_rows * 4 (its own by a device copy -- none where the
+ * caller passes d_audio == d_all_audio / d_rds == d_all_rds, i.e. had rank 0's outputs produced in place).  Returns
  * at once; FMD_WARN_RDS_LOST like the export.  batch may be NULL (d_rds is sent as it is). */
 int fmd_gather_step(fmd_gather* g, fmd_batch* batch, int lag, unsigned channel_offset, const float* d_audio,
                     int32_t* d_rds, float* d_all_audio, int32_t* d_all_rds, void* stream);

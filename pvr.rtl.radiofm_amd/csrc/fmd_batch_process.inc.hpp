@@ -1,0 +1,1072 @@
+/*
+ * fmd_batch_process.inc.hpp -- one call of a batch: the position plan the host replays (DownConvert.cpp:112-132,
+ * 203-232; FirFilter.cpp:346), the choice of kernel forms, and the launches of all stages on the batch's internal
+ * streams with the events that tie them (process_device_impl); the IF stage's launch helpers and the light part's.
+ * Included by fmd_batch.hip (one translation unit: it uses that file's fmd_batch struct and helpers).
+ */
+namespace
+{
+
+/* The IF FIR kernel is instantiated for a few load depths (two-sample loads in flight per lane);
+ * the launch takes the smallest one that stages a tile's window in a single round trip. */
+template <class IN>
+using FirFn = void (*)(const typename IN::elem*, size_t, unsigned, const float2*, float2*, const float2*,
+                       unsigned, unsigned, const float*, unsigned, unsigned, unsigned, unsigned, float2*,
+                       unsigned, unsigned, unsigned, unsigned);
+
+template <class IN>
+using FirFn3 = void (*)(const typename IN::elem*, size_t, unsigned, const float2*, float2*, const float2*,
+                        unsigned, unsigned, const float*, unsigned, unsigned, unsigned, unsigned, float2*,
+                        unsigned, unsigned, unsigned, unsigned, float*);
+
+template <class IN, int TILE, int E, bool RB128 = false>
+int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
+                      unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
+                      hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+  const fmd::Design& d = b->des;
+  const unsigned C = b->C, D = d.D, T = d.table_size;
+  const unsigned ntiles = (M + TILE - 1) / TILE;
+  // 2^E regions of ((TILE-1)*D + order + slack) >> E slots each (see k_if_fir)
+  // (+ 1: the regions of the 16-byte-read form are rounded up to an even size)
+  const size_t region = ((size_t(TILE - 1) * D + d.if_order + 2u * (1u << E) + 2u) >> E) + 2u;
+  // long filter: one workgroup per CU, hand-scheduled tap loop for every window layout (k_if_fir
+  // LONGASM: plain window read 16 bytes at a time for D = 2 * odd, 8 bytes at a time for odd D, and
+  // the two- and four-region windows)
+  const bool longasm = TILE == 256 && d.if_order >= 512;
+  // + 32 slots in front of the window for the tap loops' dummy last prefetch (k_if_fir WIN_PAD)
+  const size_t lds = (region << E) * sizeof(float2) + (longasm ? 32 * sizeof(float2) : 0);
+  if (lds > 160 * 1024)
+    return fail(FMD_ERR_ARG, "IF filter window does not fit in LDS");
+  if (b->if_dry_run) // fmd_batch_create: only whether this geometry can be launched at all
+    return FMD_OK;
+  // fast staging: the tuner table is a power of two that divides a tile's sample span, so a lane
+  // needs the same two table entries for every load (all reference configurations: T = 64)
+  const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
+  // loads per lane needed to stage one tile in a single round trip (two samples per load)
+  const unsigned rounds = unsigned(((size_t(TILE - 1) * D + d.if_order + 2) / 2 + TILE - 1) / TILE);
+  FirFn<IN> kfn = &fmd::k_if_fir<IN, TILE, 1, false, E>;
+  if (pow2)
+    kfn = rounds <= 2 ? &fmd::k_if_fir<IN, TILE, 2, true, E>
+        : rounds <= 4 ? &fmd::k_if_fir<IN, TILE, 4, true, E>
+        : rounds <= 6 ? &fmd::k_if_fir<IN, TILE, 6, true, E>
+        : rounds <= 7 ? &fmd::k_if_fir<IN, TILE, 7, true, E>
+                      : &fmd::k_if_fir<IN, TILE, 8, true, E>;
+  if (pow2 && longasm)
+    kfn = &fmd::k_if_fir<IN, TILE, 8, true, E, TILE == 256, false, TILE == 256 && RB128 && (E >= 1)>;
+  // opt-in shuffle-reduced tap sum (not bit-exact): headline window layout only
+  const bool shfl = b->params.fir_reduction == 1 && TILE == 64 && E == 0 && pow2 && rounds <= 8;
+  if (shfl)
+    kfn = &fmd::k_if_fir<IN, TILE, 8, true, E, false, TILE == 64 && E == 0>;
+  // several tiles per workgroup with the next tile's loads in flight during the tap loop
+  // (k_if_fir_mt): the headline geometry only.  Two tiles: 0.94-0.95 ms inside the pipeline against
+  // 0.98-1.00 (one tile per workgroup) on the same box, the same alone; 3, 4, 8 tiles: no better
+  // than one ("fir_nt" of fmd_batch_debug_set overrides, 1 = k_if_fir).
+  // With the chip to itself (calls not overlapped) one tile per workgroup is the faster form (0.77
+  // against 0.83 ms), and in the throughput-bound regime (> 8192 channels) the faster FIR only
+  // takes from the kernels beside it (32 768 channels: 228 against 236 GS/s): two tiles only beside
+  // the whole-CU serial stage.
+  const int fir_nt = b->dbg_fir_nt ? b->dbg_fir_nt : (b->concurrency == 2 && b->serial_exclusive ? 2 : 1);
+  unsigned nblocks = C * ntiles, ntiles_l = ntiles;
+  size_t lds_l = lds;
+  FirFn3<IN> kfn3 = nullptr; // k_if_fir_mt3 (one more argument: where the level meter goes)
+  bool level_in_fir = false;
+  if (TILE == 64 && E == 0 && pow2 && rounds == 7 && fir_nt > 1 && !shfl)
+  {
+    const unsigned nt = fir_nt >= 8 ? 8u : fir_nt >= 4 ? 4u : fir_nt == 3 ? 3u : 2u;
+    kfn = nt == 8 ? &fmd::k_if_fir_mt<IN, 7, 8>
+        : nt == 4 ? &fmd::k_if_fir_mt<IN, 7, 4>
+        : nt == 3 ? &fmd::k_if_fir_mt<IN, 7, 3>
+                  : &fmd::k_if_fir_mt<IN, 7, 2>;
+    nblocks = C * ((ntiles + nt - 1) / nt);
+    // two (three) outputs per lane (k_if_fir_mt3): every sample is read from LDS once for up to two (three) taps
+    const unsigned RO = unsigned(b->dbg_fir_ro), T3 = 64 * RO;
+    const unsigned rounds3 = unsigned(((size_t(T3 - 1) * D + d.if_order + 2) / 2 + 63) / 64);
+    if (RO > 1 && nt == 2 && d.if_order == 88 && D == 11 && (size_t(T3) * D) % T == 0 &&
+        rounds3 <= (RO == 3 ? 18u : 12u))
+    {
+      kfn3 = RO == 3 ? &fmd::k_if_fir_mt3<IN, 18, 2, 3> : &fmd::k_if_fir_mt3<IN, 12, 2, 2>;
+      ntiles_l = (M + T3 - 1) / T3;
+      lds_l = (size_t(T3 - 1) * D + d.if_order + 4) * sizeof(float2);
+      nblocks = C * ((ntiles_l + 1) / 2);
+      // the level meter inside the first tile's workgroup: its (N + 63) / 64 samples have to lie in that tile's
+      // window, which ends in front of the tile's last output position pos + (nout - 1) D
+      const unsigned nout0 = std::min(T3, M);
+      level_in_fir = b->dbg_level_in_fir != 0 && (N + 63u) / 64u <= pos + (nout0 - 1u) * D;
+    }
+  }
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const typename IN::elem* x = static_cast<const typename IN::elem*>(d_iq);
+  mark(0);
+  // profiled calls: the two events take the kernel's own start and stop (hipExtLaunchKernelGGL),
+  // not the stream's state around it (a recorded event also counts the dispatch gap behind it)
+  float* const lvl = level_in_fir ? b->st.F(fmd::F_IF_LEVEL) : static_cast<float*>(nullptr);
+  if (kfn3 && ev_start)
+    hipExtLaunchKernelGGL(kfn3, dim3(nblocks), dim3(TILE), unsigned(lds_l), sF, ev_start, ev_stop, 0u, x,
+                          iq_channel_stride, N, (const float2*)b->hist[b->hist_sel].p,
+                          (float2*)b->hist[b->hist_sel ^ 1].p, (const float2*)b->lut.p, T, b->lut_idx,
+                          (const float*)b->if_coeff.p, d.if_order, D, pos, M, (float2*)b->demod[q].p,
+                          b->Mstride, ntiles_l, (C % 8 == 0) ? 1u : 0u, b->cpc, lvl);
+  else if (kfn3)
+    hipLaunchKernelGGL(kfn3, dim3(nblocks), dim3(TILE), lds_l, sF, x, iq_channel_stride, N,
+                       b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, T, b->lut_idx,
+                       b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles_l,
+                       (C % 8 == 0) ? 1u : 0u, b->cpc, lvl);
+  else if (ev_start)
+    hipExtLaunchKernelGGL(kfn, dim3(nblocks), dim3(TILE), unsigned(lds_l), sF, ev_start, ev_stop, 0u, x,
+                          iq_channel_stride, N, (const float2*)b->hist[b->hist_sel].p,
+                          (float2*)b->hist[b->hist_sel ^ 1].p, (const float2*)b->lut.p, T, b->lut_idx,
+                          (const float*)b->if_coeff.p, d.if_order, D, pos, M, (float2*)b->demod[q].p,
+                          b->Mstride, ntiles_l, (C % 8 == 0) ? 1u : 0u, b->cpc);
+  else
+    hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(TILE), lds_l, sF, x, iq_channel_stride, N,
+                       b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, T, b->lut_idx,
+                       b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles_l,
+                       (C % 8 == 0) ? 1u : 0u, b->cpc);
+  mark(1);
+  if (!level_in_fir)
+    hipLaunchKernelGGL(fmd::k_if_level<IN>, dim3(C), dim3(64), 0, sF, x, iq_channel_stride, N, b->lut.p, T,
+                       b->lut_idx, b->st, b->cpc);
+  return FMD_OK;
+}
+
+/* Window layout by the power-of-two factor of D (k_if_fir): D odd -> plain, D = 2 * odd and
+ * 4 * odd -> de-interleaved into 2 / 4 regions; higher powers of two keep 4 regions (their
+ * lane stride stays even: fewer conflicts, not none). */
+template <class IN, int TILE>
+int launch_if_stage_e(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
+                      unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
+                      hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+  const unsigned D = b->des.D;
+  if (D % 2 != 0)
+    return launch_if_stage_t<IN, TILE, 0>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
+  if (D % 4 != 0)
+  { // D = 2 * odd.  Long filters: plain window read two samples at a time (fir_long_b128_asm: the b128
+    // lane groups are conflict-free at this stride); otherwise the two-region window.  "fir_b128" = 0
+    // keeps the two-region form for long filters too (fir_long_e1_asm).
+    const int b128 = b->dbg_fir_b128;
+    const unsigned T = b->des.table_size;
+    const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
+    if (b128 && TILE == 256 && b->des.if_order >= 512 && pow2)
+      return launch_if_stage_t<IN, TILE, 0>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
+    return launch_if_stage_t<IN, TILE, 1>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
+  }
+  { // D = 4 * odd and above.  Long filters: one region fewer than the power of two in D asks for, so
+    // that the lane stride inside a region stays EVEN and two adjacent positions come with one
+    // 16-byte read (fir_long_e1_b128_asm / fir_long_e2_b128_asm); FMD_FIR_B128=0 keeps the 8-byte reads
+    // of the four-region window (fir_long_e2_asm).  Short filters: four regions (odd stride for 4 * odd).
+    const int b128 = b->dbg_fir_b128;
+    const unsigned T = b->des.table_size;
+    const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
+    if (b128 && TILE == 256 && b->des.if_order >= 512 && pow2)
+    {
+      if (D % 8 != 0)
+        return launch_if_stage_t<IN, TILE, 1, true>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start,
+                                                    ev_stop);
+      return launch_if_stage_t<IN, TILE, 2, true>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start,
+                                                  ev_stop);
+    }
+  }
+  return launch_if_stage_t<IN, TILE, 2>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
+}
+
+/* Outputs per workgroup.  Small workgroups suffer least from the serial stage: its two role waves
+ * issue with priority on two SIMDs of half the CUs, a bandwidth wave sharing such a SIMD runs at a
+ * fraction of its speed, and a multi-wave workgroup waits for its slowest wave.  One wave per
+ * workgroup (measured, 8192 channels, in the pipeline): 0.89 ms against 0.98 ms for four waves,
+ * alone 0.77 against 0.78.  Long filters keep 256 outputs per workgroup so the `order`-sample
+ * halo is amortised and the window fits LDS a useful number of times. */
+template <class IN>
+int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
+                    unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
+                      hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+  const fmd::Design& d = b->des;
+  const unsigned T = d.table_size;
+  auto fits = [&](unsigned tile) {
+    const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * tile && (size_t(tile) * d.D) % T == 0;
+    const size_t lds = (size_t(tile - 1) * d.D + d.if_order + 4) * sizeof(float2);
+    return pow2 && d.if_order <= 4u * tile * d.D / 8u && lds <= 16 * 1024; // halo <= half the tile span
+  };
+  if (fits(64))
+    return launch_if_stage_e<IN, 64>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
+  if (fits(128))
+    return launch_if_stage_e<IN, 128>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
+  return launch_if_stage_e<IN, 256>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
+}
+
+/* A call appends its RDS groups to queue[es]; if the queue's previous contents were handed to an
+ * asynchronous drain (fmd_batch_export_rds_device), stream s first waits for that drain. */
+void queue_is_free(fmd_batch* b, int es, hipStream_t s)
+{
+  if (b->drained_pending[es])
+  {
+    if (hipStreamWaitEvent(s, b->ev_drained[es], 0) != hipSuccess)
+      mark_failed(b, "hipStreamWaitEvent failed in front of an RDS queue");
+    b->drained_pending[es] = false;
+  }
+}
+
+/* The light part of one call's post chain on stream s: cRDSRxSignalProcessor's PLL, matched filter
+ * and bit recovery, then the audio tail; records the call's EV_RDS / EV_AUD. */
+void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, bool record)
+{ // (s by value: the audio half may move to j.s_audio)
+  const fmd::Design& d = b->des;
+  const unsigned C = b->C, CP = b->CP;
+  const unsigned T_mf = unsigned(d.rds_mf_taps.size());
+  const dim3 rt(256);
+  auto rgrid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
+  queue_is_free(b, j.es, s);
+  {
+    fmd::RdsConsts k{};
+    k.pll_alpha = d.rds_pll_alpha;
+    k.pll_beta = d.rds_pll_beta;
+    k.nco_hl = d.rds_nco_hl;
+    k.nco_ll = d.rds_nco_ll;
+    k.bs_b0 = d.bitsync.b0;
+    k.bs_b1 = d.bitsync.b1;
+    k.bs_b2 = d.bitsync.b2;
+    k.bs_a1 = d.bitsync.a1;
+    k.bs_a2 = d.bitsync.a2;
+    k.mf_taps = int(T_mf);
+    const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
+    hipLaunchKernelGGL(fmd::k_rds_pll, dim3((CP / 64 + fmd::RP_WAVES - 1) / fmd::RP_WAVES), dim3(64, fmd::RP_WAVES), 0, s, b->rlpf[j.q].p, j.R, C, CP, k, b->st,
+                       b->rpll.p, T_mf - 1, b->sctab.p, sct);
+    if (T_mf >= unsigned(fmd::RG))
+      hipLaunchKernelGGL(fmd::k_ring_fir4<float>, dim3(CP / 64, (j.R + 4 * fmd::RG - 1) / (4 * fmd::RG)),
+                         dim3(64, 4), 0, s, b->rpll.p, b->rmf.p, j.R, int(T_mf), b->mf_taps2.p, j.mf_g, C, CP,
+                         0u, 3u);
+    else
+      hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (j.R + fmd::RF_TI - 1) / fmd::RF_TI),
+                         dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), s, b->rpll.p,
+                         b->rmf.p, j.R, int(T_mf), b->mf_taps2.p, j.mf_g, C, CP, 0u);
+    hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, s, b->rpll.p, b->rpll.p, T_mf - 1, j.R,
+                       CP);
+    hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, s, b->rmf.p, j.R, C, CP, k, b->st,
+                       j.call_index, b->queue[j.es].p, b->qcount(j.es), b->queue_cap,
+                       b->tap_sync.p, b->write_taps);
+  }
+  if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_RDS], s) != hipSuccess)
+    mark_failed(b, "hipEventRecord failed behind the RDS part of a call");
+  // the RDS part above only needed the RDS half of the call's heavy part (EV_RDSH, waited for by the
+  // caller); the audio tail needs the other half too
+  const hipStream_t s_rds_part = s;
+  if (j.s_audio && record)
+    s = j.s_audio; // the two halves side by side: two chains of lane-per-channel kernels, each shorter than a period
+  if (record && hipStreamWaitEvent(s, b->cev[j.es][j.tail_after_alp ? fmd_batch::EV_ALP : fmd_batch::EV_HEAVY], 0) != hipSuccess)
+    mark_failed(b, "hipStreamWaitEvent failed in front of the audio tail of a call");
+  {
+    fmd::AudioConsts k{};
+    k.de_alpha = d.de_alpha;
+    k.n_b0 = d.notch.b0;
+    k.n_b1 = d.notch.b1;
+    k.n_b2 = d.notch.b2;
+    k.n_a1 = d.notch.a1;
+    k.n_a2 = d.notch.a2;
+    if (j.before_tail)
+      j.before_tail();
+    if (j.fuse_alp && j.tl0)
+      hipExtLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3(CP / 64), dim3(64), 0u, s, j.tl0, j.tl1, 0u,
+                            (const float2*)b->rs[j.q].p, b->rs[j.q ^ 1].p, j.A, j.alpf_g,
+                            (const float*)b->audio_taps.p, C, CP, k, b->st, j.d_audio, j.audio_stride,
+                            unsigned(j.sq), j.call_index, unsigned(b->dbg_alt_prio));
+    else if (j.fuse_alp)
+      hipLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3(CP / 64), dim3(64), 0, s, b->rs[j.q].p, b->rs[j.q ^ 1].p,
+                         j.A, j.alpf_g, b->audio_taps.p, C, CP, k, b->st, j.d_audio, j.audio_stride,
+                         unsigned(j.sq), j.call_index, unsigned(b->dbg_alt_prio));
+    else if (j.tl0)
+      hipExtLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0u, s, j.tl0, j.tl1, 0u,
+                            (const float2*)b->alp[j.q].p, j.A, C, CP, k, b->st, j.d_audio, j.audio_stride,
+                            unsigned(j.sq), j.call_index);
+    else
+      hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, s, b->alp[j.q].p, j.A, C, CP, k,
+                         b->st, j.d_audio, j.audio_stride, unsigned(j.sq), j.call_index);
+    if (s != s_rds_part && hipStreamWaitEvent(s, b->cev[j.es][fmd_batch::EV_RDS], 0) != hipSuccess)
+      mark_failed(b, "hipStreamWaitEvent failed in front of the status record of a call"); // its RDS state is the other half's
+    hipLaunchKernelGGL(fmd::k_status_publish, dim3((C + 255) / 256), dim3(256), 0, s, b->st, C, j.call_index);
+  }
+  if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_AUD], s) != hipSuccess)
+    mark_failed(b, "hipEventRecord failed behind the audio tail of a call");
+}
+
+enum IqFormat
+{
+  IQ_F32 = 0, // complex<float>, the ProcessStream argument (FmDecode.h:135)
+  IQ_U8 = 1   // RTL-SDR byte pairs, converted like ReadAsyncCB (RTL_SDR_Source.cpp:207-211)
+};
+
+int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_channel_stride,
+                        unsigned samples, float* d_audio, size_t audio_channel_stride,
+                        unsigned* out_floats, void* stream_)
+{
+  if (!b || !d_iq || !d_audio)
+    return fail(FMD_ERR_ARG, "fmd_batch_process_device: null argument");
+  if (samples > FMD_MAX_BLOCK || samples < b->min_samples)
+    return fail(FMD_ERR_SIZE, "samples must be within [fmd_batch_min_samples(), the largest block] = [" +
+                                  std::to_string(b->min_samples) + ", 65536]");
+  // a lane loads two IQ samples at a time: every channel's stream has to start on a pair boundary
+  {
+    const size_t pair = fmt == IQ_U8 ? 4 : 16;
+    if ((reinterpret_cast<uintptr_t>(d_iq) % pair) || ((iq_channel_stride * (pair / 2)) % pair))
+      return fail(FMD_ERR_ARG, "IQ pointer and channel stride must be multiples of two IQ samples");
+  }
+  const fmd::Design& d = b->des;
+  const unsigned C = b->C, CP = b->CP, N = samples, D = d.D;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIPCHK(hipSetDevice(b->device));
+  if (int rc = check_device_errors(b)) // a failed batch takes no more calls (fmd_batch_reset clears it)
+    return rc;
+
+  /* ---- position plan (batch-uniform, mirrors the reference's bookkeeping) ---- */
+  const unsigned pos = b->if_pos;
+  const unsigned M = pos < N ? (N - pos + D - 1) / D : 0; // DownConvert.cpp:112,123
+  if (M == 0)
+    return fail(FMD_ERR_SIZE, "block shorter than the decimator phase");
+  // the reference's half-band delay lines hold 32768 samples (DownConvert.cpp:267,500); longer
+  // baseband blocks overrun its heap, so they are outside the contract here too
+  if ((N + D - 1) / D + 51 > 32768)
+    return fail(FMD_ERR_SIZE, "baseband block longer than the reference's half-band buffers (32768)");
+  // Per stage of the half-band chain: how many inputs it sees and which of the reference's regimes
+  // that is (see k_hb_pass / k_roll_hb_mixed): HB_PASS below L inputs, HB_MIXED below 2 (L - 1).
+  enum HbMode { HB_NORMAL, HB_MIXED, HB_PASS };
+  std::vector<unsigned> hb_in(d.hb.size());
+  std::vector<HbMode> hb_mode(d.hb.size(), HB_NORMAL);
+  unsigned R = M;
+  for (size_t s = 0; s < d.hb.size(); s++)
+  {
+    hb_in[s] = R;
+    const unsigned L = unsigned(d.hb[s].len);
+    if (L == 11)
+    { // the unrolled class reads InLength - 10 .. and its first nine outputs unconditionally (:596-661)
+      if (R < 20)
+        return fail(FMD_ERR_SIZE, "block too short for the 11-tap half-band stage");
+      R = R / 2; // :688
+    }
+    else if (R < L)
+    {
+      hb_mode[s] = HB_PASS;
+      R = R / 2; // :519-520
+    }
+    else
+    { // one output per even input index (:526-543)
+      hb_mode[s] = R >= 2u * (L - 1u) ? HB_NORMAL : HB_MIXED;
+      R = (R + 1) / 2;
+    }
+  }
+  if (R == 0)
+    return fail(FMD_ERR_SIZE, "block too short: no sample reaches the RDS rate");
+  // fractional resampler walk (DownConvert.cpp:203-232), float arithmetic as written there
+  const float p = b->rs_pos;
+  const float pstep = d.rs_step;
+  unsigned A = 0;
+  float pf = p;
+  unsigned pi = unsigned(int(pf));
+  while (pi < M)
+  {
+    A++;
+    pf = p + float(A) * pstep;
+    pi = unsigned(int(pf));
+  }
+  float new_rs_pos = pf - float(M);
+  if (new_rs_pos < 0)
+    new_rs_pos = 0;
+  if (A > b->Amax || M > b->Mmax)
+    return fail(FMD_ERR_STATE, "internal: plan exceeds buffer geometry");
+  if (A == 0)
+    return fail(FMD_ERR_SIZE, "block too short: no audio frame falls into it");
+  if (size_t(2) * A > audio_channel_stride && C > 1)
+    return fail(FMD_ERR_ARG, "audio_channel_stride smaller than the audio produced");
+
+  const unsigned T_lpf = unsigned(d.rds_lpf_taps.size());
+  const unsigned T_mf = unsigned(d.rds_mf_taps.size());
+  const unsigned T_alp = unsigned(d.lpf_taps.size());
+  const unsigned Hbb = d.rs_order;
+  // The call's index and everything derived from it (buffer parity, event slot) are locals until the
+  // call has been submitted: a call that is refused leaves the batch exactly as it was.
+  const uint32_t ci = b->call_index + 1;
+  const int q = int(ci & 1u);  // buffer parity: demod, br, mix
+  const int es = int(ci % fmd_batch::NSLOT); // event set / RDS queue of this call
+  const int sq = int(ci & 3u); // this call's copy of the stereo flag (see ISlot)
+  // call k-2 used the same buffers; its events say when they are free again
+  const bool have_prev2 = ci > 2;
+  hipEvent_t* pe2 = b->cev[(ci + fmd_batch::NSLOT - 2) % fmd_batch::NSLOT];
+  const bool serial_mode = b->concurrency == 0 || b->profiling >= 2;
+  hipStream_t sF = serial_mode ? stream : b->s_fir;
+  hipStream_t sS = serial_mode ? stream : b->s_ser;
+  hipStream_t sP = serial_mode ? stream : b->s_post;
+  hipStream_t sA = sP, sR = (!serial_mode && b->split_post) ? b->s_rds : sP;
+  // one-stream form: the light parts of the post chain go to their own stream (see below)
+  hipStream_t sL = serial_mode ? stream : b->s_rds;
+  hipEvent_t* ce = b->cev[es];
+  // the first failing event operation of the call (checked once, behind the launches)
+  hipError_t herr = hipSuccess;
+  auto note = [&](hipError_t e) {
+    if (e != hipSuccess && herr == hipSuccess)
+      herr = e;
+  };
+  auto after = [&](hipStream_t s, hipEvent_t e) {
+    if (!serial_mode)
+      note(hipStreamWaitEvent(s, e, 0));
+  };
+  auto signal = [&](hipEvent_t e, hipStream_t s) {
+    if (!serial_mode)
+      note(hipEventRecord(e, s));
+  };
+
+  hipEvent_t* evset = nullptr;
+  if (b->profiling && b->prof_calls < kMaxProfCalls)
+  {
+    const size_t need = size_t(b->prof_calls + 1) * (ST_COUNT + 1);
+    while (b->ev.size() < need)
+    {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      b->ev.push_back(e);
+    }
+    evset = &b->ev[size_t(b->prof_calls) * (ST_COUNT + 1)]; // prof_calls advances with call_index
+  }
+  // level 2: events between all stages (serial mode); level 1: only around the FIR kernel, on
+  // the stream that kernel is launched on
+  auto mark = [&](int i) { // events 0 and 1 are the FIR kernel's own start and stop (launch_if_stage)
+    if (evset && b->profiling >= 2 && i > 1)
+      note(hipEventRecord(evset[i], sF));
+  };
+
+  /* ---- which form the RDS decimator takes: decided here, the serial stage's form follows from it ---- */
+  bool hb_all_normal = d.hb.size() <= 3;
+  for (size_t s = 0; s < d.hb.size(); s++)
+    hb_all_normal = hb_all_normal && hb_mode[s] == HB_NORMAL && d.hb[s].len != 11;
+  /* Large batches in the usual geometries: the three half-band stages as one stream, intermediate rows in
+   * LDS (k_halfband_chain).  Everything else -- short calls with a stage outside its normal regime, the
+   * 11-tap class, chains of another length, small batches -- keeps one launch per stage. */
+  fmd_batch::HbfPlan* hbf_pl = nullptr;
+  int hbf_kind = -1; // 0: 15 / 23 / 43 taps, 1: 15 / 19 / 35
+  if (hb_all_normal && d.hb.size() == 3 && b->hbf_mode != 0 && (b->hbf_mode == 1 || CP / 64 >= 64))
+  {
+    const int h0 = (d.hb[0].len - 1) / 2, h1 = (d.hb[1].len - 1) / 2, h2 = (d.hb[2].len - 1) / 2;
+    hbf_kind = (h0 == 7 && h1 == 11 && h2 == 21) ? 0 : (h0 == 7 && h1 == 9 && h2 == 17) ? 1 : -1;
+    if (hbf_kind >= 0)
+    {
+      const unsigned groups = CP / 64;
+      const unsigned ncu = unsigned(b->n_cus) - ((b->serial_exclusive && !serial_mode) ? (groups + 1) / 2 : 0u);
+      const unsigned S = std::max(1u, std::min({8u, (2u * ncu + groups / 2u) / groups, R / 32u}));
+      hbf_pl = hbf_plan(b, hb_in[0], S);
+    }
+  }
+  // ... and then the serial stage writes no mixed rows: the chain multiplies the baseband with the
+  // oscillator's sequence itself (computed here, once per batch and call, and copied over on the IF stream:
+  // long before anything needs it)
+  const bool nomix = hbf_pl != nullptr && b->osc_on && b->dbg_nomix != 0;
+  const unsigned osc_slot = ci & 3u;
+  float osc_re = b->osc_re, osc_im = b->osc_im; // committed with the positions, at the end
+  if (b->osc_on)
+  {
+    // the staging slot was last read by the copy of the call 8 calls ago: complete unless the caller has
+    // submitted eight calls without ever waiting
+    if (b->osc_ev_used[es])
+      note(hipEventSynchronize(b->osc_ev[es]));
+    float2* h = b->h_osc + size_t(es) * b->h_osc_stride;
+    const float2* hp = b->h_osc + size_t((ci + fmd_batch::NSLOT - 1) % fmd_batch::NSLOT) * b->h_osc_stride;
+    std::memcpy(h, hp + b->lastM, fmd_batch::kOscH * sizeof(float2)); // the previous call's last entries
+    const float oc = d.rds_osc_cos, os = d.rds_osc_sin;
+    float2* o = h + fmd_batch::kOscH;
+    for (unsigned t = 0; t < M; t++)
+    { // the statements of k_demod_serial's MIX form (this file is compiled with -ffp-contract=off too)
+      const float x = osc_re * oc - osc_im * os;
+      const float y = osc_im * oc + osc_re * os;
+      const float gn = float(1.95 - double(osc_re * osc_re + osc_im * osc_im));
+      osc_re = gn * x;
+      osc_im = gn * y;
+      o[t] = make_float2(x, y);
+    }
+    note(hipMemcpyAsync(b->osc_tab[osc_slot].p, h, (fmd_batch::kOscH + M) * sizeof(float2), hipMemcpyHostToDevice, sF));
+    note(hipEventRecord(b->osc_ev[es], sF));
+    b->osc_ev_used[es] = true;
+  }
+
+  /* ---- K1: tuner + IF decimating FIR  (stream F) ---- */
+  signal(ce[fmd_batch::EV_IN], stream);
+  after(sF, ce[fmd_batch::EV_IN]);
+  if (have_prev2)
+  {
+    after(sF, pe2[fmd_batch::EV_SER]); // demod[q] was last read by the serial stage two calls ago
+    // Also run behind the bandwidth-heavy part of the post chain of two calls ago (half-bands, RDS
+    // low-pass, resamplers, audio low-pass): side by side with those the FIR and they were both
+    // ~25 % slower.  The rest of that chain (RDS PLL, matched filter, bit recovery, audio tail) is
+    // lane-per-channel work that leaves most CUs idle: the FIR runs beside it.
+    // (behind the RDS half only, i.e. beside the resampler and the audio low-pass: measured, the FIR then
+    // takes 1.00 instead of 0.95 ms and the period does not move; again with the faster serial stage of
+    // round 3's end, which has slack: FIR 1.09 instead of 0.98 ms, period the same 2.00-2.01 ms)
+    after(sF, pe2[fmd_batch::EV_HEAVY]);
+  }
+  {
+    // EV_FIR right behind the FIR kernel (the serial stage waits for nothing else); the level meter
+    // behind it also reads the input: EV_INDONE is what tells the caller its buffer is free
+    const std::function<void(int)> markfn = [&](int i) {
+      mark(i);
+      if (i == 1)
+        signal(ce[fmd_batch::EV_FIR], sF);
+    };
+    const int rc = fmt == IQ_U8
+                       ? launch_if_stage<fmd::InU8>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn,
+                                                   evset ? evset[0] : nullptr, evset ? evset[1] : nullptr)
+                       : launch_if_stage<fmd::InF32>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn,
+                                                    evset ? evset[0] : nullptr, evset ? evset[1] : nullptr);
+    if (rc != FMD_OK) // cannot happen: the geometry was checked when the batch was created
+    {
+      mark_failed(b, "the IF stage refused a call after events were recorded");
+      return rc;
+    }
+  }
+  signal(ce[fmd_batch::EV_INDONE], sF);
+
+  /* ---- K2: baseband-rate recurrences  (stream S) ---- */
+  // br[q] / mix[q] were last read by the resampler / first half-band two calls ago: this call's FIR
+  // already waited for that call's whole heavy part (EV_HEAVY above), so EV_FIR covers them and the
+  // serial stream carries one wait instead of three between two serial stages
+  // (EV_HEAVY, which that FIR waited for, is recorded in FRONT of the history rolls behind the heavy part,
+  // so that the FIR starts earlier; the rolls read the tails of br[q] / mix[q]: one more wait here, met long
+  // before the FIR's)
+  if (have_prev2)
+    after(sS, pe2[fmd_batch::EV_ROLL]);
+  after(sS, ce[fmd_batch::EV_FIR]);
+  {
+    fmd::DemodConsts k{};
+    k.pll_alpha = d.pll_alpha;
+    k.pll_beta = d.pll_beta;
+    k.nco_hl = d.nco_hl;
+    k.nco_ll = d.nco_ll;
+    k.demod_gain = d.demod_gain;
+    k.p_minfreq = d.p_minfreq;
+    k.p_maxfreq = d.p_maxfreq;
+    k.p_b0 = d.p_b0;
+    k.p_a1 = d.p_a1;
+    k.p_a2 = d.p_a2;
+    k.p_lf_b0 = d.p_lf_b0;
+    k.p_lf_b1 = d.p_lf_b1;
+    k.p_minsignal = d.p_minsignal;
+    k.p_lock_delay = d.p_lock_delay;
+    k.osc_cos = d.rds_osc_cos;
+    k.osc_sin = d.rds_osc_sin;
+    // Up to 8192 channels the batch is latency-bound by this stage and needs at most 64 CUs for
+    // it: two channel groups per workgroup, one role wave per SIMD of a CU (k_demod_serial).
+    // Larger batches need the CUs for throughput and keep the shared form.
+    const unsigned groups = CP / 64;
+    const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
+    const unsigned Hmix = unsigned(d.hb[0].len - 1);
+    /* Two groups per workgroup = one role wave on each SIMD of a CU, 64 CUs for 8192 channels.  The
+     * waves no longer claim their SIMD's whole register file (round 3): since the staging and the table
+     * read were taken off the stage's critical path it has ~10 % slack against the period, and the
+     * bandwidth kernels' waves that now fit beside it (131 of the CU's 160 KB of LDS are the stage's, so
+     * mostly kernels without LDS) gain more than the stage loses: +2.1 %, +-0, +1.4 % whole path on three
+     * boxes, never slower (stage 1.71 -> 1.83 ms, FIR 1.02 -> 0.97 ms inside the pipeline on the
+     * first).  "serial_claim" = 1 of fmd_batch_debug_set brings the claim back. */
+    const bool serial_claim = b->dbg_serial_claim != 0;
+    auto kser2 = nomix ? (serial_claim ? &fmd::k_demod_serial<2, true, false> : &fmd::k_demod_serial<2, false, false>)
+                       : (serial_claim ? &fmd::k_demod_serial<2, true, true> : &fmd::k_demod_serial<2, false, true>);
+    auto kser1 = nomix ? &fmd::k_demod_serial<1, false, false> : &fmd::k_demod_serial<1, false, true>;
+
+    if (b->serial_exclusive && !serial_mode && evset && b->profiling == 1)
+      // profiling level 1: the stage's own start and stop too (fmd_batch_debug_timeline)
+      hipExtLaunchKernelGGL(kser2, dim3((groups + 1) / 2), dim3(256), 0u, sS, evset[2],
+                            evset[3], 0u, (const float2*)b->demod[q].p, b->Mstride, M, C, CP, k, b->st,
+                            b->brp(q), Hbb, b->mix[q].p, Hmix,
+                            (const double*)(b->sctab256.p), sct, unsigned(sq),
+                            (long long*)nullptr, osc_re, osc_im);
+    else if (b->serial_exclusive && !serial_mode)
+      hipLaunchKernelGGL(kser2, dim3((groups + 1) / 2), dim3(256), 0, sS,
+                         (const float2*)b->demod[q].p, b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p,
+                         Hmix, (const double*)b->sctab256.p, sct, unsigned(sq),
+                         b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : (long long*)nullptr,
+                         osc_re, osc_im);
+    else
+      hipLaunchKernelGGL(kser1, dim3(groups), dim3(128), 0, sS, (const float2*)b->demod[q].p,
+                         b->Mstride, M, C, CP, k, b->st, b->brp(q), Hbb, b->mix[q].p, Hmix,
+                         (const double*)b->sctab256.p, sct, unsigned(sq),
+                         b->serial_probe.p ? b->serial_probe.p + size_t(ci % 8) * 3 * (CP / 64) : (long long*)nullptr,
+                         osc_re, osc_im);
+  }
+  signal(ce[fmd_batch::EV_SER], sS);
+  mark(2);
+
+  const dim3 rt(256);
+  auto rgrid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
+
+  /* With overlapped calls three things become runnable the moment this call's serial stage ends: the
+   * next call's serial stage (already queued behind it), this call's post chain and the previous
+   * call's light part.  The exclusive serial stage needs EMPTY CUs; when the half-band kernel of the
+   * post chain is dispatched first it fills every CU and the serial stage starts only once those
+   * workgroups have drained (measured: 136 us after its predecessor ended, every call).  So the
+   * post chain and the light part start behind a single wave that idles for a few microseconds:
+   * the serial stage is dispatched first (30-50 us after its predecessor, period 2.50 -> 2.42 ms).
+   * "post_delay_us" of fmd_batch_debug_set overrides (0 = off). */
+  const int post_delay_us = b->dbg_post_delay_us;
+  // wave priorities of half-band chain (tens) and ring resampler (units) in the overlapped pipeline
+  const unsigned heavy_prio = (!serial_mode && b->concurrency == 2) ? unsigned(b->dbg_heavy_prio) : 0u;
+  auto post_delay = [&](hipStream_t s) {
+    if (post_delay_us > 0 && b->serial_exclusive && !serial_mode && b->concurrency == 2)
+      hipLaunchKernelGGL(fmd::k_delay, dim3(1), dim3(64), 0, s, unsigned(post_delay_us) * 100u);
+  };
+
+  /* The post chain in four pieces.  "Heavy" = bandwidth / LDS bound and filling the chip; "light" =
+   * lane-per-channel recurrences on CP/64 workgroups. */
+  /* History rolls of a chain whose stages all run in their normal regime: collected and done in one
+   * launch at the chain's end (k_roll_set) instead of one launch behind every stage. */
+  fmd::RollSet rolls{};
+  unsigned nrolls = 0, roll_hmax = 1;
+  auto roll_later = [&](const float2* src, float2* dst, unsigned H, unsigned n) {
+    rolls.src[nrolls] = src;
+    rolls.dst[nrolls] = dst;
+    rolls.H[nrolls] = H;
+    rolls.n[nrolls] = n;
+    nrolls++;
+    roll_hmax = std::max(roll_hmax, H);
+  };
+  auto roll_flush = [&](hipStream_t s) {
+    if (nrolls)
+      hipLaunchKernelGGL(fmd::k_roll_set, dim3((CP + 255) / 256, std::min(roll_hmax, 64u), nrolls), rt, 0, s, rolls,
+                         CP);
+    nrolls = 0;
+    roll_hmax = 1;
+  };
+  /* Default overlapped mode: the two low-pass filters of the post chain (0.1 ms each at 8192 channels, a few
+   * hundred small workgroups) run on a stream of their own, each behind the kernel that feeds it (EV_DEC: the
+   * decimator; EV_HEAVY: the resampler).  On the heavy stream they stood between the half-band chain and the
+   * resampler and in front of the next IF FIR -- 0.2 ms of every period with most of the 192 CUs idle; and
+   * behind EV_HEAVY on that stream they were in the next call's way (the IF FIR, at the high priority, kept
+   * them from running beside it: they ran when it had ended, in front of the half-band chain).  Their
+   * inputs (rdsraw, rs) are buffered by call parity so that the next call's decimator / resampler need not
+   * wait for them.  The light part waits for its low-pass (EV_RDSH behind the RDS one, EV_ALP behind the
+   * audio one). */
+  /* Only where the two loops of the pipeline are balanced (short IF filters): with a long IF filter the FIR
+   * alone sets the period and the fifth stream only gets in its way (config 5: 3.41 ms per call with it,
+   * 3.16 without -- its head waits for events in a hardware queue the FIR's stream shares). */
+  /* Round 5: the audio low-pass lives inside the audio tail's kernel (fuse_alp: 29 taps, every reference
+   * configuration), and the RDS low-pass runs at the head of the LIGHT stream, behind the decimator's event and in
+   * front of the RDS PLL that reads it (lpf_light): no fifth stream, nothing of either filter beside the next IF FIR
+   * but what the light part itself does.  "lpf_late" = 0 / 1 brings the heavy-stream / own-stream forms back. */
+  const bool fuse_alp = T_alp == 29 && b->dbg_fuse_alp != 0;
+  const bool lpf_late = !serial_mode && !b->split_post && b->s_lpf && b->dbg_lpf_late == 1;
+  const bool lpf_light = !serial_mode && !b->split_post && (b->dbg_lpf_late < 0 || b->dbg_lpf_late == 2);
+  std::function<void()> rds_lpf_late, audio_lpf_late, mix_tail;
+  // ... and the light part's audio half (the tail's kernel) on the stream the filters had, beside its RDS half
+  const bool light_split = lpf_light && b->s_lpf && b->dbg_light_split != 0;
+  hipStream_t sLPr = lpf_late ? b->s_lpf : lpf_light ? sL : sR;
+  hipStream_t sLPa = (lpf_late || light_split) ? b->s_lpf : lpf_light ? sL : sA;
+  // the resampler's form and its plan kernel (tap tables of this call's phases: no input but the positions)
+  const unsigned per_step = unsigned(std::max(b->rsr_NW * b->rsr_R, 1));
+  const unsigned rs_steps = (A + per_step - 1) / per_step;
+  const bool ring = b->rsr_R != 0 && b->rsr_mode != 0 &&
+                    (b->rsr_mode == 1 || (CP / 64 >= 64 && rs_steps >= 24 && per_step >= 16));
+  bool rs_planned = false;
+  auto rs_plan = [&](hipStream_t s) {
+    if (!ring || rs_planned)
+      return;
+    rs_planned = true;
+    auto go = [&](auto plan) {
+      hipLaunchKernelGGL(plan, dim3(rs_steps * b->rsr_NW), dim3(64), 0, s, b->rs_coeff.p, d.rs_order, p, pstep, A,
+                         b->rsr_rb, b->rsr_nbr, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p);
+    };
+    if (b->rsr_R == 4)
+      go(&fmd::k_rs_plan<4, 4>);
+    else if (b->rsr_NW == 8)
+      go(&fmd::k_rs_plan<2, 8>);
+    else
+      go(&fmd::k_rs_plan<2, 4>);
+  };
+  auto rds_heavy = [&]() {
+    /* ---- RDS branch  (stream R): half-bands, 75-tap LPF, PLL, matched filter, bits ---- */
+    after(sR, ce[fmd_batch::EV_SER]);
+    // Without mixed rows stage 0 reads the last L0H history rows of br[q]: the PREVIOUS call's roll wrote
+    // them, on the audio stream.  One stream (default): stream order.  Two (split_post): its EV_ROLL.
+    if (nomix && sR != sA && ci > 1)
+      after(sR, b->cev[(ci + fmd_batch::NSLOT - 1) % fmd_batch::NSLOT][fmd_batch::EV_ROLL]);
+    post_delay(sR);
+    /* Large batches in the usual geometries: the three stages as one stream, intermediate rows in LDS
+     * (k_halfband_chain).  Everything else -- short calls with a stage outside its normal regime, the
+     * 11-tap class, chains of another length, small batches -- keeps one launch per stage. */
+    bool chain_done = false;
+    if (hbf_pl)
+    {
+      fmd_batch::HbfPlan* pl = hbf_pl;
+      const unsigned groups = CP / 64;
+      const unsigned L0H = unsigned(d.hb[0].len - 1);
+      const unsigned n0 = (hb_in[0] + 1) / 2, n1 = (n0 + 1) / 2;
+      // stage 0's input rows and, without mixed rows, the oscillator entries that go with them: both
+      // indexed by the stage's input row (0 = the first of its L0H history rows)
+      const float2* in0 = nomix ? (const float2*)(b->brp(q) + size_t(Hbb - L0H) * CP) : (const float2*)b->mix[q].p;
+      const float2* osc = nomix ? (const float2*)(b->osc_tab[osc_slot].p + (fmd_batch::kOscH - L0H)) : nullptr;
+      auto kern = hbf_kind == 0 ? (nomix ? &fmd::k_halfband_chain<7, 11, 21, true> : &fmd::k_halfband_chain<7, 11, 21, false>)
+                                : (nomix ? &fmd::k_halfband_chain<7, 9, 17, true> : &fmd::k_halfband_chain<7, 9, 17, false>);
+      if (evset && b->profiling == 1 && !serial_mode) // its own start and stop (fmd_batch_debug_timeline)
+        hipExtLaunchKernelGGL(kern, dim3(groups, pl->S), dim3(64, 4), 0u, sR, evset[6], evset[7], 0u, in0,
+                              (const float2*)b->hbbuf[0].p, (const float2*)b->hbbuf[1].p, b->rdsraw[q].p, T_lpf - 1,
+                              b->hbf_tail1.p, b->hbf_tail2.p, b->hbcoef[0], b->hbcoef[1], b->hbcoef[2],
+                              (const fmd::HbStep*)pl->steps.p, (const int*)pl->seg_first.p, hb_in[0], n0, n1, C, CP,
+                              osc, (heavy_prio / 10u) % 10u);
+      else
+        hipLaunchKernelGGL(kern, dim3(groups, pl->S), dim3(64, 4), 0, sR, in0, (const float2*)b->hbbuf[0].p,
+                           (const float2*)b->hbbuf[1].p, b->rdsraw[q].p, T_lpf - 1, b->hbf_tail1.p, b->hbf_tail2.p,
+                           b->hbcoef[0], b->hbcoef[1], b->hbcoef[2], (const fmd::HbStep*)pl->steps.p,
+                           (const int*)pl->seg_first.p, hb_in[0], n0, n1, C, CP, osc, (heavy_prio / 10u) % 10u);
+      if (nomix) // the next call's stage-0 history, should it take a launch per stage (it reads mixed rows)
+        mix_tail = [&, L0H]() {
+          hipLaunchKernelGGL(fmd::k_mix_tail, rgrid(L0H), rt, 0, sR,
+                             (const float2*)(b->brp(q) + size_t(Hbb + hb_in[0] - L0H) * CP),
+                             (const float2*)(b->osc_tab[osc_slot].p + fmd_batch::kOscH + hb_in[0] - L0H),
+                             b->mix[q ^ 1].p, L0H, CP);
+        };
+      else
+        roll_later(b->mix[q].p, b->mix[q ^ 1].p, L0H, hb_in[0]);
+      roll_later(b->hbf_tail1.p, b->hbbuf[0].p, unsigned(d.hb[1].len - 1), 0u);
+      roll_later(b->hbf_tail2.p, b->hbbuf[1].p, unsigned(d.hb[2].len - 1), 0u);
+      chain_done = true;
+    }
+    if (!chain_done)
+    {
+      const float2* in = b->mix[q].p;
+      for (size_t s = 0; s < d.hb.size(); s++)
+      {
+        const unsigned n_out =
+            (d.hb[s].len == 11 || hb_mode[s] == HB_PASS) ? hb_in[s] / 2 : (hb_in[s] + 1) / 2;
+        const bool last = (s + 1 == d.hb.size());
+        float2* outp = last ? b->rdsraw[q].p : b->hbbuf[s].p;
+        const unsigned Hout = last ? (T_lpf - 1) : unsigned(d.hb[s + 1].len - 1);
+        const int hb4 = b->dbg_hb4;
+        const unsigned Hs = unsigned(d.hb[s].len - 1);
+        float2* const hist_dst = s == 0 ? b->mix[q ^ 1].p : b->hbbuf[s - 1].p; // where the delay line lives
+        if (hb_mode[s] == HB_PASS)
+        { // unfiltered; the delay line stays (stage 0 keeps it in the other parity's buffer: copy it over)
+          hipLaunchKernelGGL(fmd::k_hb_pass, rgrid(n_out), rt, 0, sR, in, Hs, outp, Hout, n_out, CP);
+          if (s == 0)
+            hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->mix[q].p, b->mix[q ^ 1].p, Hs, 0u, CP);
+          in = outp;
+          continue;
+        }
+        if (d.hb[s].len == 11)
+          hipLaunchKernelGGL(fmd::k_halfband11, dim3(CP / 64, (n_out + 3) / 4), dim3(64, 4), 0, sR, in, outp,
+                             n_out, b->hbcoef[s], C, CP, Hout);
+        else if (hb4 && (d.hb[s].len - 1) / 2 >= 4 && d.hb[s].len <= 55)
+          hipLaunchKernelGGL(fmd::k_halfband4, dim3(CP / 64, (n_out + 15) / 16), dim3(64, 4), 0, sR, in, outp,
+                             n_out, d.hb[s].len, b->hbcoef[s], C, CP, Hout);
+        else
+        hipLaunchKernelGGL(fmd::k_halfband, dim3(CP / 64, (n_out + 4 * fmd::HB_R - 1) / (4 * fmd::HB_R)),
+                           dim3(64, 4), 0, sR, in, outp, n_out, d.hb[s].len, b->hbcoef[s], C, CP, Hout);
+        // keep the last L-1 input rows of this stage for the next call, then its input is free
+        if (hb_mode[s] == HB_MIXED)
+          hipLaunchKernelGGL(fmd::k_roll_hb_mixed, dim3((CP + 255) / 256), rt, 0, sR, in, (const float2*)outp,
+                             hist_dst, Hs, hb_in[s], n_out, Hout, CP);
+        else if (s == 0)
+        { // tail of mix[q] -> history rows of mix[q^1], which the next call's half-band reads
+          if (hb_all_normal)
+            roll_later(b->mix[q].p, b->mix[q ^ 1].p, Hs, hb_in[0]);
+          else
+            hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->mix[q].p, b->mix[q ^ 1].p, Hs,
+                               hb_in[0], CP);
+        }
+        else if (hb_all_normal)
+          roll_later(b->hbbuf[s - 1].p, b->hbbuf[s - 1].p, Hs, hb_in[s]);
+        else
+          hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(Hs), rt, 0, sR, b->hbbuf[s - 1].p,
+                             b->hbbuf[s - 1].p, Hs, hb_in[s], CP);
+        in = outp;
+      }
+    }
+    mark(3);
+    auto lpf = [&]() {
+    const int ring4 = b->dbg_ring4;
+    if (ring4 && T_lpf >= unsigned(fmd::RG))
+      hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
+                         sLPr, b->rdsraw[q].p, b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C,
+                         CP, 0u, unsigned(b->dbg_lpf_prio));
+    else
+    hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
+                       size_t(T_lpf - 1 + fmd::RF_TI) * 64 * sizeof(float2), sLPr, b->rdsraw[q].p,
+                       b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C, CP, 0u);
+    if (hb_all_normal)
+    {
+      roll_later(b->rdsraw[q].p, b->rdsraw[q ^ 1].p, T_lpf - 1, R);
+      roll_flush(sLPr);
+    }
+    else
+      hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, sLPr, b->rdsraw[q].p, b->rdsraw[q ^ 1].p, T_lpf - 1, R, CP);
+    };
+    if (lpf_late || lpf_light)
+    { // the low-pass later (see above); what the decimator left to roll waits for the resampler's roll: one
+      // launch behind EV_HEAVY (k_roll_set takes four)
+      if (nrolls > 3)
+        roll_flush(sR);
+      rds_lpf_late = lpf;
+      return;
+    }
+    if (mix_tail)
+    {
+      mix_tail();
+      mix_tail = nullptr;
+    }
+    lpf();
+    mark(4);
+  };
+  auto rds_light = [&]() {
+    queue_is_free(b, es, sR);
+    {
+      fmd::RdsConsts k{};
+      k.pll_alpha = d.rds_pll_alpha;
+      k.pll_beta = d.rds_pll_beta;
+      k.nco_hl = d.rds_nco_hl;
+      k.nco_ll = d.rds_nco_ll;
+      k.bs_b0 = d.bitsync.b0;
+      k.bs_b1 = d.bitsync.b1;
+      k.bs_b2 = d.bitsync.b2;
+      k.bs_a1 = d.bitsync.a1;
+      k.bs_a2 = d.bitsync.a2;
+      k.mf_taps = int(T_mf);
+      const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
+      hipLaunchKernelGGL(fmd::k_rds_pll, dim3((CP / 64 + fmd::RP_WAVES - 1) / fmd::RP_WAVES), dim3(64, fmd::RP_WAVES), 0, sR, b->rlpf[q].p, R, C, CP, k,
+                         b->st, b->rpll.p, T_mf - 1, b->sctab.p, sct);
+      if (T_mf >= unsigned(fmd::RG))
+        hipLaunchKernelGGL(fmd::k_ring_fir4<float>, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)),
+                           dim3(64, 4), 0, sR, b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C,
+                           CP, 0u, 3u);
+      else
+        hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI),
+                           dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), sR,
+                           b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C, CP, 0u);
+      hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, sR, b->rpll.p, b->rpll.p, T_mf - 1, R, CP);
+      hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, sR, b->rmf.p, R, C, CP, k,
+                         b->st, ci, b->queue[es].p, b->qcount(es), b->queue_cap,
+                         b->tap_sync.p, b->write_taps);
+    }
+  };
+  auto audio_heavy = [&]() {
+
+    /* ---- audio branch  (stream A): resamplers, 15 kHz LPF, de-emphasis / notch / matrix ---- */
+    if (sA != sR) // (one stream: the RDS branch in front has waited)
+      after(sA, ce[fmd_batch::EV_SER]);
+    /* Large batches stream the rows through an LDS ring (k_resample_ring: every row crosses the fabric
+     * once per segment instead of ~6 times); small ones, short calls and geometries whose window does
+     * not fit a CU's LDS keep the window-per-wave form, which has more workgroups to offer. */
+    if (ring)
+    {
+      // one workgroup (a whole CU's LDS) for every CU the serial stage leaves free: one round, with an equal
+      // run of (group, step) units each, >= 8 steps ("rsr_wgs" of fmd_batch_debug_set overrides the count;
+      // 160 / 176 / 184 / 192 of 192: 267 800 / 278 700 / 280 000 / 282 300 MS/s whole path on one box)
+      const unsigned groups = CP / 64;
+      const unsigned ncu = unsigned(b->n_cus) - ((b->serial_exclusive && !serial_mode) ? (groups + 1) / 2 : 0u);
+      const unsigned units = groups * rs_steps;
+      unsigned W = b->dbg_rsr_wgs > 0 ? unsigned(b->dbg_rsr_wgs) : std::max(1u, ncu);
+      W = std::max(1u, std::min(W, units / 8u));
+      const unsigned per_wg = (units + W - 1) / W;
+      W = (units + per_wg - 1) / per_wg;
+      const unsigned lds = b->rsr_nbr * 4096u;
+      rs_plan(sA); // (already done in front of the half-band chain where the two share a stream)
+      auto go = [&](auto kern) {
+        if (evset && b->profiling == 1 && !serial_mode)
+          hipExtLaunchKernelGGL(kern, dim3(W), dim3(64, b->rsr_NW + 1), lds, sA, evset[8], evset[9], 0u,
+                                (const float2*)b->brp(q), Hbb, b->rsr_rb, d.rs_order, (const float*)b->rsr_tab.p,
+                                b->rsr_nbm, (const int*)b->rsr_head.p, (const int*)b->rsr_steps.p, rs_steps, per_wg,
+                                b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, b->rsr_exp | ((heavy_prio % 10u) << 8), b->rsr_pace);
+        else
+        hipLaunchKernelGGL(kern, dim3(W), dim3(64, b->rsr_NW + 1), lds, sA, b->brp(q), Hbb, b->rsr_rb,
+                           d.rs_order, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p, rs_steps, per_wg,
+                           b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, b->rsr_exp | ((heavy_prio % 10u) << 8), b->rsr_pace);
+      };
+      if (b->rsr_R == 4)
+        go(&fmd::k_resample_ring<4, 4>);
+      else if (b->rsr_NW == 8)
+        go(&fmd::k_resample_ring<2, 8>);
+      else
+        go(&fmd::k_resample_ring<2, 4>);
+    }
+    else
+    {
+      hipLaunchKernelGGL(fmd::k_rs_table, dim3(A), dim3(64), 0, sA, b->rs_coeff.p, d.rs_order, p,
+                         pstep, A, b->ktab.p, b->rs_row, b->rs_margin, b->pidx.p);
+      hipLaunchKernelGGL(fmd::k_resample, dim3(CP / 64, (A + 4 * fmd::RS_R - 1) / (4 * fmd::RS_R)),
+                         dim3(64, 4), 0, sA, b->brp(q), Hbb, d.rs_order, b->ktab.p, b->rs_row,
+                         b->rs_margin, b->pidx.p, A, b->rs[q].p, T_alp - 1, C, CP);
+    }
+    roll_later(b->brp(q), b->brp(q ^ 1), Hbb, M); // with the low-pass's own roll, at the chain's end
+    mark(6);
+    auto lpf = [&]() {
+    if (!fuse_alp)
+    { // (fused: the tail's kernel filters, and keeps the delay line's rows itself)
+    const int ring4a = b->dbg_ring4;
+    if (ring4a && T_alp >= unsigned(fmd::RG))
+      hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (A + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
+                         sLPa, b->rs[q].p, b->alp[q].p, A, int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u, unsigned(b->dbg_lpf_prio));
+    else
+    hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (A + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
+                       size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), sLPa, b->rs[q].p, b->alp[q].p, A,
+                       int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
+    roll_later(b->rs[q].p, b->rs[q ^ 1].p, T_alp - 1, A);
+    }
+    roll_flush(sLPa);
+    };
+    if (lpf_late || lpf_light)
+    { // the low-pass (and its own roll) later; the baseband rows' history behind EV_HEAVY (below)
+      audio_lpf_late = lpf;
+      return;
+    }
+    lpf();
+    mark(7);
+  };
+  auto audio_light = [&]() {
+    {
+      fmd::AudioConsts k{};
+      k.de_alpha = d.de_alpha;
+      k.n_b0 = d.notch.b0;
+      k.n_b1 = d.notch.b1;
+      k.n_b2 = d.notch.b2;
+      k.n_a1 = d.notch.a1;
+      k.n_a2 = d.notch.a2;
+      if (fuse_alp)
+        hipLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3(CP / 64), dim3(64), 0, sA, b->rs[q].p, b->rs[q ^ 1].p, A,
+                           b->alpf_g, b->audio_taps.p, C, CP, k, b->st, d_audio, audio_channel_stride, unsigned(sq), ci,
+                           unsigned(b->dbg_alt_prio));
+      else
+      hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, sA, b->alp[q].p, A, C, CP, k,
+                         b->st, d_audio, audio_channel_stride, unsigned(sq), ci);
+    }
+  };
+  if (serial_mode || b->split_post)
+  { // stage order of the reference (what the per-stage profile is keyed to), or two streams
+    rds_heavy();
+    rds_light();
+    signal(ce[fmd_batch::EV_RDS], sR);
+    mark(5);
+    audio_heavy();
+    audio_light();
+    mark(8);
+    after(sA, ce[fmd_batch::EV_RDS]); // the record's RDS state is the other chain's
+    hipLaunchKernelGGL(fmd::k_status_publish, dim3((C + 255) / 256), dim3(256), 0, sA, b->st, C, ci);
+    signal(ce[fmd_batch::EV_AUD], sA);
+    signal(ce[fmd_batch::EV_HEAVY], sA);
+    signal(ce[fmd_batch::EV_ROLL], sA);
+  }
+  else
+  { // Both heavy parts first on the post stream, the light parts behind them on a stream of their
+    // own: the next call's FIR runs beside the light parts, and the next call's heavy parts do
+    // not queue behind them (rlpf / alp, the buffers between a heavy and a light part, are
+    // double-buffered by call parity; their readers of two calls ago are long done).
+    if (have_prev2)
+    {
+      after(sP, pe2[fmd_batch::EV_RDS]);
+      after(sA, pe2[fmd_batch::EV_AUD]);
+    }
+    if (lpf_late && have_prev2)
+    { // rdsraw[q] / rs[q] are written again: their low-pass filters of two calls ago have read them
+      after(sP, pe2[fmd_batch::EV_RDSH]);
+      after(sP, pe2[fmd_batch::EV_ALP]);
+    }
+    if (lpf_light && have_prev2) // (rs[q]'s reader of two calls ago is in front of EV_AUD, waited for above)
+      after(sP, pe2[fmd_batch::EV_RDSH]);
+    if (lpf_late || lpf_light)
+      rs_plan(sP); // off the path between the half-band chain and the resampler
+    rds_heavy();
+    signal(ce[(lpf_late || lpf_light) ? fmd_batch::EV_DEC : fmd_batch::EV_RDSH], sR);
+    audio_heavy();
+    signal(ce[fmd_batch::EV_HEAVY], sP); // the next-but-one call's IF FIR may go
+    if (mix_tail)
+    {
+      mix_tail();
+      mix_tail = nullptr;
+    }
+    roll_flush(sP); // (lpf_late: the history rolls of both heavy parts in one launch)
+    signal(ce[fmd_batch::EV_ROLL], sP);
+    if (lpf_late)
+    { // the two low-pass filters on their own stream
+      hipStream_t sl = b->s_lpf;
+      if (have_prev2)
+      { // rlpf[q] / alp[q] were last read by the light part of two calls ago
+        after(sl, pe2[fmd_batch::EV_RDS]);
+        after(sl, pe2[fmd_batch::EV_AUD]);
+      }
+      after(sl, ce[fmd_batch::EV_DEC]);
+      rds_lpf_late();
+      signal(ce[fmd_batch::EV_RDSH], sl);
+      after(sl, ce[fmd_batch::EV_HEAVY]);
+      audio_lpf_late();
+      signal(ce[fmd_batch::EV_ALP], sl);
+    }
+    fmd_batch::LightJob job;
+    if (lpf_light)
+    { // the RDS low-pass at the head of the light stream, behind the decimator; the audio one (where it is not
+      // part of the tail's kernel) in front of the tail, behind EV_HEAVY
+      after(sL, ce[fmd_batch::EV_DEC]);
+      rds_lpf_late();
+      signal(ce[fmd_batch::EV_RDSH], sL);
+      if (!fuse_alp)
+        job.before_tail = audio_lpf_late;
+    }
+    job.fuse_alp = fuse_alp;
+    job.alpf_g = b->alpf_g;
+    if (light_split)
+      job.s_audio = b->s_lpf;
+    job.R = R;
+    job.A = A;
+    job.mf_g = b->mf_g;
+    job.q = q;
+    job.es = es;
+    job.sq = sq;
+    job.call_index = ci;
+    job.d_audio = d_audio;
+    job.audio_stride = audio_channel_stride;
+    job.tail_after_alp = lpf_late;
+    if (evset && b->profiling == 1)
+    {
+      job.tl0 = evset[4];
+      job.tl1 = evset[5];
+    }
+    /* The light part goes out at once, on its own stream: its RDS half behind the RDS half of the
+     * heavy part (it runs beside the resampler and the audio low-pass), the audio tail behind the
+     * whole heavy part (launch_light).  Until round 3 it was kept back until the NEXT call's serial
+     * stage had ended, so that it ran beside that call's heavy part and not beside a FIR; since its
+     * kernels fetch their input a tile ahead they no longer stretch beside the bandwidth kernels, and
+     * not keeping it back finishes every call 1.2 ms earlier (20 timed steps: +0.9 %, 160: +0.3 %). */
+    after(sL, ce[fmd_batch::EV_RDSH]);
+    launch_light(b, job, sL, true);
+  }
+  mark(9);
+  if (!serial_mode && b->concurrency < 2)
+  { // order the caller's stream after everything this call launched
+    note(hipStreamWaitEvent(stream, ce[fmd_batch::EV_AUD], 0));
+    note(hipStreamWaitEvent(stream, ce[fmd_batch::EV_RDS], 0));
+    note(hipStreamWaitEvent(stream, ce[fmd_batch::EV_INDONE], 0));
+    note(hipStreamWaitEvent(stream, ce[fmd_batch::EV_ROLL], 0));
+  }
+  note(hipGetLastError());
+  if (herr != hipSuccess)
+  { // part of the call is on the device, part is not: histories and channel state no longer line up
+    b->failed = true;
+    b->fail_msg = std::string("a call broke off while it was being submitted: ") + hipGetErrorString(herr);
+    return fail(FMD_ERR_DEVICE, b->fail_msg);
+  }
+  /* ---- the call is submitted: commit its index together with the positions ---- */
+  b->call_index = ci;
+  b->slot_call[es] = ci;
+  if (evset)
+    b->prof_calls++;
+
+  /* ---- advance the host-tracked positions ---- */
+  b->if_pos = pos + M * D - N;                      // DownConvert.cpp:132
+  b->lut_idx = (b->lut_idx + N) % d.table_size;     // FmDecode.cpp:81
+  b->rs_pos = new_rs_pos;                           // DownConvert.cpp:230-232
+  b->osc_re = osc_re;                               // DownConvert.cpp:440-441 (batch-wide, see osc_on)
+  b->osc_im = osc_im;
+  b->rds_lpf_g = (b->rds_lpf_g + R) % T_lpf;
+  b->mf_g = (b->mf_g + R) % T_mf;
+  b->alpf_g = (b->alpf_g + A) % T_alp;
+  b->hist_sel ^= 1;
+  b->lastM = M;
+  b->lastA = A;
+  b->lastR = R;
+  if (out_floats)
+    *out_floats = 2 * A;
+  return FMD_OK;
+}
+
+} // namespace

@@ -201,9 +201,12 @@ int fmd_gather_step(fmd_gather* g, fmd_batch* batch, int lag, unsigned channel_o
   }
   GNCCL(ncclGroupEnd());
   if (g->rank == 0)
-  { // rank 0's own outputs: a device copy, on the same stream
-    GHIP(hipMemcpyAsync(d_all_audio, d_audio, g->audio_floats * sizeof(float), hipMemcpyDeviceToDevice, g->side));
-    GHIP(hipMemcpyAsync(d_all_rds, d_rds, rds_ints * sizeof(int32_t), hipMemcpyDeviceToDevice, g->side));
+  { // rank 0's own outputs: a device copy, on the same stream -- unless the caller had them produced in place
+    // (d_audio == d_all_audio: 88 MB per step at 8192 channels that need not be read and written again)
+    if (d_all_audio != d_audio)
+      GHIP(hipMemcpyAsync(d_all_audio, d_audio, g->audio_floats * sizeof(float), hipMemcpyDeviceToDevice, g->side));
+    if (d_all_rds != d_rds)
+      GHIP(hipMemcpyAsync(d_all_rds, d_rds, rds_ints * sizeof(int32_t), hipMemcpyDeviceToDevice, g->side));
   }
   GHIP(hipEventRecord(g->t1[tslot], g->side));
   g->timed++;

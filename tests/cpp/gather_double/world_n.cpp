@@ -74,6 +74,7 @@ static int rank_main(int rank, int world, int steps, const uint8_t* id, bool exp
   std::vector<int32_t> rds(size_t(NBUF) * ROWS * 4), all_r(rank == 0 ? size_t(NBUF) * world * ROWS * 4 : 0);
   std::vector<float> stage_a(AFL);
   std::vector<int32_t> stage_r(size_t(ROWS) * 4);
+  const bool inplace = getenv("WORLD_N_INPLACE") != nullptr;
   long checked = 0;
   auto verify = [&](int step) { // rank 0: what every rank sent in `step`
     const int s = step % NBUF;
@@ -110,17 +111,20 @@ static int rank_main(int rank, int world, int steps, const uint8_t* id, bool exp
       stage_a[j] = audio_value(rank, i, j);
     for (size_t k = 0; k < size_t(ROWS) * 4; k++)
       stage_r[k] = rds_value(rank, i, k);
-    memset(&audio[size_t(s) * AFL], 0xEE, AFL * 4);
-    memset(&rds[size_t(s) * ROWS * 4], 0xEE, size_t(ROWS) * 16);
-    fake_hip_stream_busy(st, 1500);
-    CHECK(hipMemcpyAsync(&audio[size_t(s) * AFL], stage_a.data(), AFL * 4, 0, st) == 0);
-    CHECK(hipMemcpyAsync(&rds[size_t(s) * ROWS * 4], stage_r.data(), size_t(ROWS) * 16, 0, st) == 0);
+    // (WORLD_N_INPLACE: rank 0 has its outputs produced in its part of the receive buffers, like tools/node_bench)
+    float* const my_a = (rank == 0 && inplace) ? &all_a[size_t(s) * world * AFL] : &audio[size_t(s) * AFL];
+    int32_t* const my_r = (rank == 0 && inplace) ? &all_r[size_t(s) * world * ROWS * 4] : &rds[size_t(s) * ROWS * 4];
     if (rank == 0)
     { // poison the receive slot: stale data from NBUF steps ago must not pass for this step's
       memset(&all_a[size_t(s) * world * AFL], 0xFF, size_t(world) * AFL * 4);
       memset(&all_r[size_t(s) * world * ROWS * 4], 0xFF, size_t(world) * ROWS * 16);
     }
-    const int rc = fmd_gather_step(g, nullptr, 0, 0, &audio[size_t(s) * AFL], &rds[size_t(s) * ROWS * 4],
+    memset(my_a, 0xEE, AFL * 4);
+    memset(my_r, 0xEE, size_t(ROWS) * 16);
+    fake_hip_stream_busy(st, 1500);
+    CHECK(hipMemcpyAsync(my_a, stage_a.data(), AFL * 4, 0, st) == 0);
+    CHECK(hipMemcpyAsync(my_r, stage_r.data(), size_t(ROWS) * 16, 0, st) == 0);
+    const int rc = fmd_gather_step(g, nullptr, 0, 0, my_a, my_r,
                                    rank == 0 ? &all_a[size_t(s) * world * AFL] : nullptr,
                                    rank == 0 ? &all_r[size_t(s) * world * ROWS * 4] : nullptr, st);
     if (expect_failure && rank == 0)

@@ -41,6 +41,15 @@ def test_gather_step_with_real_peers_against_the_double(world_n, world, steps):
     assert line["rank_step_messages_checked"] == world * steps
 
 
+def test_rank0_outputs_produced_in_place(world_n):
+    """Rank 0's own audio / records written straight into its part of the receive buffers (what bench.py and
+    tools/node_bench do): the gather copies nothing for it and the peers' parts still land beside it."""
+    env = dict(os.environ, WORLD_N_INPLACE="1")
+    out = subprocess.run([world_n, "3", "40"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1])["rank_step_messages_checked"] == 120
+
+
 def test_a_failed_receive_reports_and_closes_its_group(world_n):
     env = dict(os.environ, FAKE_RCCL_FAIL_RECV="1")
     out = subprocess.run([world_n, "2", "1"], capture_output=True, text=True, timeout=120, env=env)

@@ -101,14 +101,18 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
   int submitted = -1, finalized = -1;
   unsigned nf = 0;
   std::vector<unsigned> nfs;
+  // rank 0 has its own outputs produced in place: slot s of its audio / record buffers is its part (the first) of
+  // slot s of the receive buffers, and the gather has nothing to copy for it
+  auto audio_of = [&](int s) { return rank == 0 ? all_a + size_t(s) * world * afl : audio + size_t(s) * afl; };
+  auto rds_of = [&](int s) { return rank == 0 ? all_r + size_t(s) * world * C * 4 : rds + size_t(s) * C * 4; };
   auto finalize = [&](int lag) { // outputs of step finalized + 1: on their way to rank 0
     const int i = ++finalized, s = i % int(NBUF);
-    CHECK(fmd_gather_step(g, b, lag, unsigned(rank) * C, audio + s * afl, rds + size_t(s) * C * 4,
+    CHECK(fmd_gather_step(g, b, lag, unsigned(rank) * C, audio_of(s), rds_of(s),
                           all_a ? all_a + size_t(s) * world * afl : nullptr, all_r ? all_r + size_t(s) * world * C * 4 : nullptr, st) >= 0);
   };
   auto step = [&](int i) {
     CHECK(fmd_gather_wait_lagged(g, NBUF - LAG - 1, st) == FMD_OK); // the gather that last read this slot's buffers
-    CHECK(fmd_batch_process_device(b, iq + size_t(i % int(RING)) * C * N * 2, N, N, audio + (i % int(NBUF)) * afl, stride, &nf, st) == FMD_OK);
+    CHECK(fmd_batch_process_device(b, iq + size_t(i % int(RING)) * C * N * 2, N, N, audio_of(i % int(NBUF)), stride, &nf, st) == FMD_OK);
     submitted = i;
     nfs.push_back(nf); // (audio floats per channel of step i: 2620 / 2622 at 2.4 MS/s)
     if (i - int(LAG) > finalized)
