@@ -276,6 +276,8 @@ def main():
     ap.add_argument("--channels", type=int, default=8192, help="channels per GPU")
     ap.add_argument("--ring", type=int, default=10, help="distinct input blocks resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lib", default=None,
+                    help="development aid: another build of libfmd_hip.so (A/B of compile-time constants)")
     ap.add_argument("--captures", type=int, default=1,
                     help="config3 only: G captures x 256 stations each in one batch (config 3 scaled out until it "
                          "fills the chip; fmd_batch_set_channels_per_capture)")
@@ -398,6 +400,8 @@ def main():
         raise SystemExit("--input u8 is implemented for the per-channel workloads")
     in_dtype = torch.uint8 if u8 else torch.float32
     pkg = load_package()
+    if args.lib:
+        pkg.LIB_PATH = os.path.abspath(args.lib)
     import importlib
     dg = importlib.import_module(pkg.__name__ + ".dist_gather")
     C = args.channels

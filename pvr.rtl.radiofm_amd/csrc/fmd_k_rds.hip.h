@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void k_ring_fir(const E* __restrict__ in, E* _
  * them take on their own.  Every output's accumulator starts at -0 (x + -0 = x for every x), the
  * order is the reference's.  A group that straddles a ring period is done as two groups. */
 #ifndef FMD_RG
-#define FMD_RG 4
+#define FMD_RG 8 // (4 until round 5: 8 outputs per thread read 4.5 rows per output instead of 8 -- 0.061 against 0.092 ms alone for the RDS low-pass, +1.7 % whole path; 12 and 16: no better)
 #endif
 constexpr int RG = FMD_RG;
 

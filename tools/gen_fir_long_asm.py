@@ -7,7 +7,7 @@ one sample (8 bytes) at a time, as the inline-asm bodies of
     fir_long_e1_asm    G = 2   two-region window, D = 2 * odd without the b128 form
     fir_long_e2_asm    G = 4   four-region window, D = 4 * odd (and higher powers of two)
 
-in pvr.rtl.radiofm_amd/csrc/fmd_kernels.hip.h (D = 2 * odd normally runs fir_long_b128_asm,
+in pvr.rtl.radiofm_amd/csrc/fmd_k_if.hip.h (D = 2 * odd normally runs fir_long_b128_asm,
 tools/gen_fir_long_b128_asm.py).
 
     python tools/gen_fir_long_asm.py G [b128]   (paste the output between `asm volatile(` and `);`)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generates the hand-scheduled long-filter tap loop of k_if_fir for the PLAIN window (E = 0) and an
 even decimation D = 2 * odd, reading TWO consecutive samples per lane with one ds_read_b128, as the
-inline-asm body of fir_long_b128_asm in pvr.rtl.radiofm_amd/csrc/fmd_kernels.hip.h.
+inline-asm body of fir_long_b128_asm in pvr.rtl.radiofm_amd/csrc/fmd_k_if.hip.h.
 
     python tools/gen_fir_long_b128_asm.py     (paste the output between `asm volatile(` and `);`)
 
