@@ -394,6 +394,9 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   const bool have_prev2 = ci > 2;
   hipEvent_t* pe2 = b->cev[(ci + fmd_batch::NSLOT - 2) % fmd_batch::NSLOT];
   const bool serial_mode = b->concurrency == 0 || b->profiling >= 2;
+  // (the gate: only where calls overlap on streams of their own queues and the post chain is one heavy stream)
+  const bool use_gate = !serial_mode && b->concurrency == 2 && !b->split_post && b->dbg_gate != 0 &&
+                        b->streams_sharing == 0 && b->heavy_flag.p != nullptr;
   hipStream_t sF = serial_mode ? stream : b->s_fir;
   hipStream_t sS = serial_mode ? stream : b->s_ser;
   hipStream_t sP = serial_mode ? stream : b->s_post;
@@ -500,7 +503,14 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     // (behind the RDS half only, i.e. beside the resampler and the audio low-pass: measured, the FIR then
     // takes 1.00 instead of 0.95 ms and the period does not move; again with the faster serial stage of
     // round 3's end, which has slack: FIR 1.09 instead of 0.98 ms, period the same 2.00-2.01 ms)
-    after(sF, pe2[fmd_batch::EV_HEAVY]);
+    // (by a word in device memory where that is possible: a hardware event between two queues costs ~110 us
+    // from the resampler's end to the FIR's start, every call -- k_gate_wait)
+    if (use_gate)
+      hipLaunchKernelGGL(fmd::k_gate_wait, dim3(1), dim3(64), 0, sF,
+                         (const unsigned*)(b->heavy_flag.p + (ci + fmd_batch::NSLOT - 2) % fmd_batch::NSLOT), ci - 2u,
+                         300000u);
+    else
+      after(sF, pe2[fmd_batch::EV_HEAVY]);
   }
   {
     // EV_FIR right behind the FIR kernel (the serial stage waits for nothing else); the level meter
@@ -969,6 +979,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     rds_heavy();
     signal(ce[(lpf_late || lpf_light) ? fmd_batch::EV_DEC : fmd_batch::EV_RDSH], sR);
     audio_heavy();
+    if (use_gate)
+      hipLaunchKernelGGL(fmd::k_flag_set, dim3(1), dim3(1), 0, sP, b->heavy_flag.p + es, ci);
     signal(ce[fmd_batch::EV_HEAVY], sP); // the next-but-one call's IF FIR may go
     if (mix_tail)
     {

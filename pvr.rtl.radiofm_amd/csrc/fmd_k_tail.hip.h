@@ -501,6 +501,26 @@ __global__ void k_delay(unsigned ticks)
     __builtin_amdgcn_s_sleep(4);
 }
 
+/* Ordering between two streams without a hardware event, where the order is only a matter of scheduling (the IF
+ * FIR of call k + 2 should not start before the heavy part of call k has ended: they would fight for the same
+ * CUs; no data passes between them).  A cross-queue event wait costs ~110 us between the end of one kernel and
+ * the start of the other (measured: docs/MEASUREMENTS.md, round 5); a word in device memory that the first
+ * stream sets (k_flag_set, one thread, behind the resampler) and one sleeping wave on the second stream polls
+ * (k_gate_wait, directly in front of the FIR) costs two same-stream kernel gaps (~13 us each).  Call indices
+ * only grow; the gate gives up after `limit` ticks of the 100 MHz clock -- it must never be what a call hangs on
+ * (two streams that share a hardware queue: the batch does not use the gate then). */
+__global__ void k_flag_set(unsigned* flag, unsigned value)
+{
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_gate_wait(const unsigned* flag, unsigned want, unsigned limit)
+{
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0 &&
+         __builtin_amdgcn_s_memrealtime() - t0 < limit)
+    __builtin_amdgcn_s_sleep(8);
+}
+
 __global__ void k_probe_nop(int* sink)
 {
   if (sink && threadIdx.x == 12345)
