@@ -494,6 +494,9 @@ __global__ __launch_bounds__(256) void k_ring_fir(const E* __restrict__ in, E* _
 #define FMD_RG 8 // (4 until round 5: 8 outputs per thread read 4.5 rows per output instead of 8 -- 0.061 against 0.092 ms alone for the RDS low-pass, +1.7 % whole path; 12 and 16: no better)
 #endif
 constexpr int RG = FMD_RG;
+#ifndef FMD_RING_UNROLL
+#define FMD_RING_UNROLL 8 // rows in flight per thread in ring_group's two long loops
+#endif
 
 __device__ __forceinline__ float rf_neg_zero(float*) { return -0.0f; }
 __device__ __forceinline__ float2 rf_neg_zero(float2*) { return make_float2(-0.0f, -0.0f); }
@@ -512,7 +515,7 @@ __device__ __forceinline__ void ring_group(const E* __restrict__ in, E* __restri
   const E* __restrict__ p1 = in + (size_t)((unsigned)T - 1 + i - (unsigned)a0) * CP + c; // time B
   const float* __restrict__ k1 = taps + a0;
   const int n1 = T - a0 - (RR - 1); // rows B .. i+RR-T, taken by every output: ages a0 + r + s
-#pragma unroll 8
+#pragma unroll FMD_RING_UNROLL
   for (int s = 0; s < n1; s++)
   {
     const E x = *p1;
@@ -540,7 +543,7 @@ __device__ __forceinline__ void ring_group(const E* __restrict__ in, E* __restri
     for (int r = RR - 1 - m; r < RR; r++)
       rf_acc(acc[r], taps[r - (RR - 1 - m)], x);
   }
-#pragma unroll 8
+#pragma unroll FMD_RING_UNROLL
   for (int s = 0; s < a0; s++) // rows i .. B+1, taken by every output: ages r + s
   {
     const E x = *p2;
