@@ -188,6 +188,7 @@ struct fmd_batch
   unsigned host_calls = 0;
   DevBuf<long long> serial_probe; // FMD_SERIAL_PROBE=1: per-workgroup timing of the serial stage
   DevBuf<unsigned> heavy_flag;    // [NSLOT]: call index whose heavy part has ended (k_flag_set / k_gate_wait)
+  int dbg_rs_first = 0;           // 1: resampler in front of the half-band chain, the chain beside the next IF FIR
   int dbg_gate = 0;               // 1: the IF FIR waits for the heavy part of two calls ago through that word
                                   // (the gap shrinks from 110 to 76 us, the period does not move: measured, off)
   DevBuf<float> fstate; // all float state arrays, CP each
@@ -1194,6 +1195,8 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
     b->dbg_level_in_fir = value != 0;
   else if (k == "light_split")
     b->dbg_light_split = value != 0;
+  else if (k == "rs_first")
+    b->dbg_rs_first = value != 0;
   else if (k == "gate")
     b->dbg_gate = value != 0;
   else if (k == "lpf_prio")

@@ -616,8 +616,9 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   const int post_delay_us = b->dbg_post_delay_us;
   // wave priorities of half-band chain (tens) and ring resampler (units) in the overlapped pipeline
   const unsigned heavy_prio = (!serial_mode && b->concurrency == 2) ? unsigned(b->dbg_heavy_prio) : 0u;
+  bool post_delay_done = false;
   auto post_delay = [&](hipStream_t s) {
-    if (post_delay_us > 0 && b->serial_exclusive && !serial_mode && b->concurrency == 2)
+    if (post_delay_us > 0 && b->serial_exclusive && !serial_mode && b->concurrency == 2 && !post_delay_done)
       hipLaunchKernelGGL(fmd::k_delay, dim3(1), dim3(64), 0, s, unsigned(post_delay_us) * 100u);
   };
 
@@ -976,12 +977,30 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       after(sP, pe2[fmd_batch::EV_RDSH]);
     if (lpf_late || lpf_light)
       rs_plan(sP); // off the path between the half-band chain and the resampler
+    const bool rs_first = lpf_light && b->dbg_rs_first != 0;
+    if (rs_first)
+    { // Experiment ("rs_first"): the resampler first, the next-but-one IF FIR released behind IT, and the half-band
+      // chain beside that FIR's start instead of beside the previous FIR's end (the two are independent: both
+      // only read br[q]).
+      after(sP, ce[fmd_batch::EV_SER]);
+      post_delay(sP);
+      post_delay_done = true;
+      audio_heavy();
+      if (use_gate)
+        hipLaunchKernelGGL(fmd::k_flag_set, dim3(1), dim3(1), 0, sP, b->heavy_flag.p + es, ci);
+      signal(ce[fmd_batch::EV_HEAVY], sP);
+      rds_heavy();
+      signal(ce[fmd_batch::EV_DEC], sR);
+    }
+    else
+    {
     rds_heavy();
     signal(ce[(lpf_late || lpf_light) ? fmd_batch::EV_DEC : fmd_batch::EV_RDSH], sR);
     audio_heavy();
     if (use_gate)
       hipLaunchKernelGGL(fmd::k_flag_set, dim3(1), dim3(1), 0, sP, b->heavy_flag.p + es, ci);
     signal(ce[fmd_batch::EV_HEAVY], sP); // the next-but-one call's IF FIR may go
+    }
     if (mix_tail)
     {
       mix_tail();
