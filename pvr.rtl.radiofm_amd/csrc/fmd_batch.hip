@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -252,13 +253,19 @@ struct fmd_batch
     int q = 0, es = 0, sq = 0;
     bool tail_after_alp = false; // the audio tail waits for EV_ALP (the audio low-pass behind EV_HEAVY)
     bool fuse_alp = false;       // audio low-pass inside the tail kernel (k_audio_lpf_tail29)
-    std::function<void()> before_tail; // the audio low-pass where it runs on the light stream, unfused
+    std::function<void()> before_tail; // (unused since the filters of the light part are launched from values)
     hipStream_t s_audio = nullptr;     // the audio half on a stream of its own (beside the RDS half), or null
+    hipStream_t sL = nullptr;          // the RDS half's stream (kept-back jobs carry it)
+    bool lpf_here = false;             // the two complex low-pass filters are part of the light part (lpf_light)
+    unsigned rds_lpf_g = 0;            // ring phase of the RDS low-pass at this call
     uint32_t call_index = 0;
     float* d_audio = nullptr;
     size_t audio_stride = 0;
     hipEvent_t tl0 = nullptr, tl1 = nullptr; // profiling level 1: the audio tail's own start / stop
   };
+  std::deque<LightJob> held_light;     // light parts kept back until the next call (light_hold)
+  int dbg_light_hold = 0;              // 1: a call's light part runs beside the NEXT heavy part, not the next-but-one FIR
+                                       // (FIR 0.60-0.61 of peak instead of 0.58-0.59, whole path -7.5 %: measured, off)
   bool split_post = false;
   bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
   enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_RDSH, EV_ALP, EV_DEC, EV_ROLL, EV_N };
@@ -512,6 +519,8 @@ template <class IN>
 int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
                     unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
                     hipEvent_t ev_start, hipEvent_t ev_stop);
+
+void release_held_light(fmd_batch* b, hipEvent_t gate); // fmd_batch_process.inc.hpp
 
 int do_reset(fmd_batch* b)
 {
@@ -1035,6 +1044,8 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
 
 void fmd_batch_destroy(fmd_batch* b)
 {
+  if (b)
+    b->held_light.clear(); // (a light part that was never waited for goes with the batch)
   delete b;
 }
 
@@ -1043,6 +1054,7 @@ int fmd_batch_reset(fmd_batch* b)
   if (!b)
     return fail(FMD_ERR_ARG, "null batch");
   HIPCHK(hipSetDevice(b->device));
+  release_held_light(b, nullptr);
   HIPCHK(hipDeviceSynchronize());
   if (do_reset(b))
     return fail(FMD_ERR_DEVICE, "state reset failed");
@@ -1108,6 +1120,8 @@ static int wait_impl(fmd_batch* b, int lag, void* stream_, bool take_lost)
     return fail(FMD_ERR_ARG, "fmd_batch_wait: bad argument (lag must be 0..4)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
+  if (lag == 0)
+    release_held_light(b, nullptr); // the newest call's light part, where it was kept back for the next call
   for (int q = 0; q < fmd_batch::NSLOT; q++)
     if (slot_eligible(b, q, lag))
     {
@@ -1166,6 +1180,7 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
   // Keys move work between streams and change kernel forms: nothing of an earlier call may still be
   // running when the next call takes the new route -- drain the device first.
   HIPCHK(hipSetDevice(b->device));
+  release_held_light(b, nullptr);
   HIPCHK(hipDeviceSynchronize());
   if (k == "resampler")
   {
@@ -1195,6 +1210,8 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
     b->dbg_level_in_fir = value != 0;
   else if (k == "light_split")
     b->dbg_light_split = value != 0;
+  else if (k == "light_hold")
+    b->dbg_light_hold = value != 0;
   else if (k == "rs_first")
     b->dbg_rs_first = value != 0;
   else if (k == "gate")
@@ -1286,6 +1303,7 @@ int fmd_batch_set_channels_per_capture(fmd_batch* b, unsigned channels_per_captu
   if (b->C % k)
     return fail(FMD_ERR_ARG, "fmd_batch_set_channels_per_capture: the channel count is not a multiple of it");
   HIPCHK(hipSetDevice(b->device));
+  release_held_light(b, nullptr);
   HIPCHK(hipDeviceSynchronize());
   b->cpc = k;
   return FMD_OK;
@@ -1296,6 +1314,7 @@ int fmd_batch_set_concurrency(fmd_batch* b, int mode)
   if (!b || mode < 0 || mode > 2)
     return fail(FMD_ERR_ARG, "fmd_batch_set_concurrency: mode must be 0, 1 or 2");
   HIPCHK(hipSetDevice(b->device));
+  release_held_light(b, nullptr);
   HIPCHK(hipDeviceSynchronize());
   b->concurrency = mode;
   return FMD_OK;
@@ -1314,6 +1333,8 @@ int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap,
     return fail(FMD_ERR_ARG, "fmd_batch_collect_rds: bad argument (lag must be 0..4)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
+  if (lag == 0)
+    release_held_light(b, nullptr);
   /* Two synchronisations whatever the number of queues: all counts in one copy, then the records of
    * the non-empty queues back to back.  Page-locked destinations: the copies are DMA transfers, not
    * staging kernels that would queue up behind the decoder's own. */
@@ -1411,6 +1432,8 @@ int fmd_batch_export_rds_device(fmd_batch* b, int32_t* d_records, unsigned cap, 
     return fail(FMD_ERR_ARG, "fmd_batch_export_rds_device: bad argument (lag must be 0..4)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
+  if (lag == 0)
+    release_held_light(b, nullptr);
   HIPCHK(hipMemsetAsync(d_records, 0, size_t(cap) * 4 * sizeof(int32_t), stream));
   unsigned* const cursor = b->export_cursor.p + (b->export_seq++ % fmd_batch::kExportCursors);
   HIPCHK(hipMemsetAsync(cursor, 0, sizeof(unsigned), stream));

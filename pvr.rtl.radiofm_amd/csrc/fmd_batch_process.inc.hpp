@@ -219,6 +219,26 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
   const unsigned T_mf = unsigned(d.rds_mf_taps.size());
   const dim3 rt(256);
   auto rgrid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
+  // a complex ring-buffer filter of the light part (RDS low-pass / audio low-pass) and its input's history roll
+  auto ring2 = [&](hipStream_t st, const float2* in, float2* in_next, float2* out, unsigned n, unsigned T,
+                   const float* taps, unsigned g0) {
+    if (b->dbg_ring4 && T >= unsigned(fmd::RG))
+      hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (n + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0, st,
+                         in, out, n, int(T), taps, g0, C, CP, 0u, unsigned(b->dbg_lpf_prio));
+    else
+      hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (n + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
+                         size_t(T - 1 + fmd::RF_TI) * 64 * sizeof(float2), st, in, out, n, int(T), taps, g0, C, CP, 0u);
+    hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T - 1), rt, 0, st, in, in_next, T - 1, n, CP);
+  };
+  if (j.lpf_here && record)
+  { // the RDS low-pass at the head of this stream, behind the decimator (process_device_impl: lpf_light)
+    if (hipStreamWaitEvent(s, b->cev[j.es][fmd_batch::EV_DEC], 0) != hipSuccess)
+      mark_failed(b, "hipStreamWaitEvent failed in front of the RDS low-pass of a call");
+    const unsigned T_lpf = unsigned(d.rds_lpf_taps.size());
+    ring2(s, b->rdsraw[j.q].p, b->rdsraw[j.q ^ 1].p, b->rlpf[j.q].p, j.R, T_lpf, b->rds_lpf_taps.p, j.rds_lpf_g);
+    if (hipEventRecord(b->cev[j.es][fmd_batch::EV_RDSH], s) != hipSuccess)
+      mark_failed(b, "hipEventRecord failed behind the RDS low-pass of a call");
+  }
   queue_is_free(b, j.es, s);
   {
     fmd::RdsConsts k{};
@@ -258,6 +278,11 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     s = j.s_audio; // the two halves side by side: two chains of lane-per-channel kernels, each shorter than a period
   if (record && hipStreamWaitEvent(s, b->cev[j.es][j.tail_after_alp ? fmd_batch::EV_ALP : fmd_batch::EV_HEAVY], 0) != hipSuccess)
     mark_failed(b, "hipStreamWaitEvent failed in front of the audio tail of a call");
+  if (j.lpf_here && record && !j.fuse_alp)
+  { // the audio low-pass in front of the tail that reads it
+    const unsigned T_alp = unsigned(d.lpf_taps.size());
+    ring2(s, b->rs[j.q].p, b->rs[j.q ^ 1].p, b->alp[j.q].p, j.A, T_alp, b->audio_taps.p, j.alpf_g);
+  }
   {
     fmd::AudioConsts k{};
     k.de_alpha = d.de_alpha;
@@ -290,6 +315,24 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
   }
   if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_AUD], s) != hipSuccess)
     mark_failed(b, "hipEventRecord failed behind the audio tail of a call");
+}
+
+/* Light parts that were kept back (light_hold): submit them now, each behind `gate` on both of its streams
+ * (null: at once -- a wait, a collect or a reset needs them on the device). */
+void release_held_light(fmd_batch* b, hipEvent_t gate)
+{
+  while (!b->held_light.empty())
+  {
+    const fmd_batch::LightJob j = b->held_light.front();
+    b->held_light.pop_front();
+    if (gate)
+    {
+      if (hipStreamWaitEvent(j.sL, gate, 0) != hipSuccess ||
+          (j.s_audio && hipStreamWaitEvent(j.s_audio, gate, 0) != hipSuccess))
+        mark_failed(b, "hipStreamWaitEvent failed in front of a kept-back light part");
+    }
+    launch_light(b, j, j.sL, true);
+  }
 }
 
 enum IqFormat
@@ -601,6 +644,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   }
   signal(ce[fmd_batch::EV_SER], sS);
   mark(2);
+  // the previous call's light part, kept back: behind THIS call's serial stage (see light_hold below)
+  release_held_light(b, ce[fmd_batch::EV_SER]);
 
   const dim3 rt(256);
   auto rgrid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
@@ -1024,15 +1069,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       signal(ce[fmd_batch::EV_ALP], sl);
     }
     fmd_batch::LightJob job;
-    if (lpf_light)
-    { // the RDS low-pass at the head of the light stream, behind the decimator; the audio one (where it is not
-      // part of the tail's kernel) in front of the tail, behind EV_HEAVY
-      after(sL, ce[fmd_batch::EV_DEC]);
-      rds_lpf_late();
-      signal(ce[fmd_batch::EV_RDSH], sL);
-      if (!fuse_alp)
-        job.before_tail = audio_lpf_late;
-    }
+    // lpf_light: the RDS low-pass at the head of the light part's RDS stream, behind the decimator; the audio one
+    // (where it is not part of the tail's kernel) in front of the tail, behind EV_HEAVY -- launch_light does
+    // both, from the job's values (so that the whole light part of a call can be submitted later: light_hold)
+    job.lpf_here = lpf_light;
+    job.rds_lpf_g = b->rds_lpf_g;
     job.fuse_alp = fuse_alp;
     job.alpf_g = b->alpf_g;
     if (light_split)
@@ -1058,8 +1099,21 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
      * stage had ended, so that it ran beside that call's heavy part and not beside a FIR; since its
      * kernels fetch their input a tile ahead they no longer stretch beside the bandwidth kernels, and
      * not keeping it back finishes every call 1.2 ms earlier (20 timed steps: +0.9 %, 160: +0.3 %). */
-    after(sL, ce[fmd_batch::EV_RDSH]);
-    launch_light(b, job, sL, true);
+    if (lpf_light && b->concurrency == 2 && b->dbg_light_hold != 0)
+    { /* Kept back (round 3's form, with two streams): the light part of this call is submitted with the NEXT
+       * call, behind that call's serial stage -- it then runs beside the next heavy part instead of beside the
+       * next-but-one IF FIR, whose window it otherwise shares from start to end.  Measured (docs/MEASUREMENTS.md,
+       * round 5): the FIR gains 0.02 of the HBM peak (0.60-0.61), the whole path loses 7.5 % -- the RDS PLL's
+       * table (16 KB of LDS on 32 CUs) and the light kernels' waves are in the whole-CU resampler's way.  Off. */
+      job.sL = sL;
+      b->held_light.push_back(job);
+    }
+    else
+    {
+      if (!lpf_light)
+        after(sL, ce[fmd_batch::EV_RDSH]);
+      launch_light(b, job, sL, true);
+    }
   }
   mark(9);
   if (!serial_mode && b->concurrency < 2)
