@@ -349,3 +349,13 @@ def test_audio_low_pass_forms_follow_each_other(oracle, fmsig):
             assert _bits_equal(a[c], refs[c].process_stream(iq[c])), (k, c, n)
         pos += n
     b.close()
+
+
+@pytest.mark.parametrize("lag", [1, 2])
+def test_light_part_kept_back_for_the_next_call(oracle, fmsig, lag):
+    """Opt-in "light_hold": the light part of a call (RDS low-pass, PLL, matched filter, bits; audio low-pass, tail,
+    status) is submitted with the NEXT call, behind that call's serial stage; waits and collects of the newest
+    call submit it first.  Same audio, status and groups, consumed one and two calls late, ragged sizes."""
+    pkg = load_package()
+    _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, 1024, [N, 30001, N, 8193, N, 12346, N, N],
+                    check=[0, 63, 512, 1023], u8=False, lag=lag, debug=(("light_hold", 1),))
