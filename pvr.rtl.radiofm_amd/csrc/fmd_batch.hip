@@ -256,6 +256,7 @@ struct fmd_batch
     std::function<void()> before_tail; // (unused since the filters of the light part are launched from values)
     hipStream_t s_audio = nullptr;     // the audio half on a stream of its own (beside the RDS half), or null
     hipStream_t sL = nullptr;          // the RDS half's stream (kept-back jobs carry it)
+    int part = 0;                      // 0 both halves, 1 the RDS half only, 2 the audio half only
     bool lpf_here = false;             // the two complex low-pass filters are part of the light part (lpf_light)
     unsigned rds_lpf_g = 0;            // ring phase of the RDS low-pass at this call
     uint32_t call_index = 0;
@@ -1210,8 +1211,8 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
     b->dbg_level_in_fir = value != 0;
   else if (k == "light_split")
     b->dbg_light_split = value != 0;
-  else if (k == "light_hold")
-    b->dbg_light_hold = value != 0;
+  else if (k == "light_hold") // 1 the whole light part, 2 its audio half only, 3 its RDS half only
+    b->dbg_light_hold = std::max(0, std::min(3, value));
   else if (k == "rs_first")
     b->dbg_rs_first = value != 0;
   else if (k == "gate")

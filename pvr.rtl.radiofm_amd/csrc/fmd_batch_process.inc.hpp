@@ -230,6 +230,8 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
                          size_t(T - 1 + fmd::RF_TI) * 64 * sizeof(float2), st, in, out, n, int(T), taps, g0, C, CP, 0u);
     hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T - 1), rt, 0, st, in, in_next, T - 1, n, CP);
   };
+  if (j.part != 2)
+  {
   if (j.lpf_here && record)
   { // the RDS low-pass at the head of this stream, behind the decimator (process_device_impl: lpf_light)
     if (hipStreamWaitEvent(s, b->cev[j.es][fmd_batch::EV_DEC], 0) != hipSuccess)
@@ -271,6 +273,9 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
   }
   if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_RDS], s) != hipSuccess)
     mark_failed(b, "hipEventRecord failed behind the RDS part of a call");
+  }
+  if (j.part == 1)
+    return; // (the audio half follows on its own: light_hold 2)
   // the RDS part above only needed the RDS half of the call's heavy part (EV_RDSH, waited for by the
   // caller); the audio tail needs the other half too
   const hipStream_t s_rds_part = s;
@@ -1106,6 +1111,18 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
        * round 5): the FIR gains 0.02 of the HBM peak (0.60-0.61), the whole path loses 7.5 % -- the RDS PLL's
        * table (16 KB of LDS on 32 CUs) and the light kernels' waves are in the whole-CU resampler's way.  Off. */
       job.sL = sL;
+      if (b->dbg_light_hold == 2 && light_split)
+      { // only the audio half is kept back (no LDS, 128 waves); the RDS half goes out now
+        job.part = 1;
+        launch_light(b, job, sL, true);
+        job.part = 2;
+      }
+      else if (b->dbg_light_hold == 3 && light_split)
+      { // only the RDS half is kept back
+        job.part = 2;
+        launch_light(b, job, sL, true);
+        job.part = 1;
+      }
       b->held_light.push_back(job);
     }
     else
