@@ -253,7 +253,6 @@ struct fmd_batch
     int q = 0, es = 0, sq = 0;
     bool tail_after_alp = false; // the audio tail waits for EV_ALP (the audio low-pass behind EV_HEAVY)
     bool fuse_alp = false;       // audio low-pass inside the tail kernel (k_audio_lpf_tail29)
-    std::function<void()> before_tail; // (unused since the filters of the light part are launched from values)
     hipStream_t s_audio = nullptr;     // the audio half on a stream of its own (beside the RDS half), or null
     hipStream_t sL = nullptr;          // the RDS half's stream (kept-back jobs carry it)
     int part = 0;                      // 0 both halves, 1 the RDS half only, 2 the audio half only

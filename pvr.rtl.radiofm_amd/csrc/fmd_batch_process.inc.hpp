@@ -296,8 +296,6 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     k.n_b2 = d.notch.b2;
     k.n_a1 = d.notch.a1;
     k.n_a2 = d.notch.a2;
-    if (j.before_tail)
-      j.before_tail();
     if (j.fuse_alp && j.tl0)
       hipExtLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3(CP / 64), dim3(64), 0u, s, j.tl0, j.tl1, 0u,
                             (const float2*)b->rs[j.q].p, b->rs[j.q ^ 1].p, j.A, j.alpf_g,
