@@ -647,7 +647,10 @@ __device__ __forceinline__ uint32_t rds_check_block(uint32_t& in_bits, uint32_t 
  *      imaginary part, written behind the T_mf-1 history rows the matched filter needs.
  *      Four waves (one per SIMD) share the 16 KB sine / cosine table of a workgroup: a quarter as many
  *      CUs carry one during the 0.2-0.5 ms the kernel runs, which matters to the whole-CU resampler. */
-constexpr int RP_WAVES = 4;
+#ifndef FMD_RP_WAVES
+#define FMD_RP_WAVES 4
+#endif
+constexpr int RP_WAVES = FMD_RP_WAVES; // channel groups (waves) of a workgroup that share one sine table in LDS
 __global__ __launch_bounds__(64 * RP_WAVES) void k_rds_pll(const float2* __restrict__ lpf, unsigned R, unsigned C,
                                                 unsigned CP, RdsConsts k, ChannelState st,
                                                 float* __restrict__ rpll, unsigned Hout,
