@@ -22,6 +22,9 @@ import time
 # The decoder runs three internal streams next to torch's; give HIP enough hardware queues that
 # they do not share one (must be set before the HIP runtime initialises).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# dmabuf IPC: what RCCL needs between processes on this pool (the driver exports it too; a launcher that did not
+# hand it down must not be what an N > 1 run fails on)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 
