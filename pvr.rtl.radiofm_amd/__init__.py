@@ -315,7 +315,7 @@ class Batch:
             n = iq_u8.size // 2
             stride = 0
         else:
-            iq_u8 = iq_u8.reshape(self.n_channels, -1)
+            iq_u8 = iq_u8.reshape(self.n_channels // getattr(self, "channels_per_capture", 1), -1)
             n = iq_u8.shape[1] // 2
             stride = n
         a_stride = self.max_audio_floats(n)

@@ -108,6 +108,30 @@ def test_config3_scaled_out_several_captures_in_one_batch(oracle, fmsig, device_
     b.close()
 
 
+def test_several_captures_of_rtl_sdr_bytes(oracle, fmsig):
+    """The same with byte input (fmd_batch_process_host_u8: one row of RTL-SDR byte pairs per capture, converted
+    inside the IF kernel like ReadAsyncCB, RTL_SDR_Source.cpp:207-211): 2 captures x 64 channels."""
+    pkg = load_package()
+    fs, D, G, k, T = 2.4e6, 11, 2, 64, 256
+    C = G * k
+    shifts = (np.arange(C, dtype=np.int32) % k) * 4 - 128
+    b = pkg.Batch(pkg.make_params(fs, 0.0, 48000.0, 15000.0, D, table_size=T), C, tuning_shifts=shifts,
+                  record_callbacks=False)
+    b.set_channels_per_capture(k)
+    check = [0, 16, 63, 64, 80, 127]
+    refs = {c: oracle.OracleDecoder(fs, 0.0, 48000.0, 15000.0, D, table_size=T, tuning_shift=int(shifts[c]))
+            for c in check}
+    ps = [fmsig.default_params(fs, f_offset=-600e3, noise_sigma=0.01, seed=70 + g, pi=0x6000 + g) for g in range(G)]
+    pos = 0
+    for blk, n in enumerate([N, 30002, N, 1000, N]):
+        cap = np.stack([fmsig.generate_u8(p, pos, n) for p in ps])  # [G][2 n] bytes
+        audio = b.process_host_u8(cap)
+        for c in check:
+            assert _bits_equal(audio[c], refs[c].process_stream_u8(cap[c // k])), (blk, c)
+        pos += n
+    b.close()
+
+
 def test_config5_long_fir_10msps(oracle, fmsig):
     """BASELINE config 5 geometry: 4096-tap cDownsampleFilter at 10 MS/s, D = 46."""
     pkg = load_package()

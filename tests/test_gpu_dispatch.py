@@ -320,7 +320,8 @@ def test_two_post_streams_overlapped_at_4096_channels(oracle, fmsig, debug):
                     check=[0, 63, 2047, 2048, 4095], u8=False, debug=debug)
 
 
-def test_fused_audio_tail_and_level_meter_inside_the_fir(oracle, fmsig):
+@pytest.mark.parametrize("u8", [False, True], ids=["f32", "u8"])
+def test_fused_audio_tail_and_level_meter_inside_the_fir(oracle, fmsig, u8):
     """Two opt-in forms (fmd_batch_debug_set "fuse_alp", "level_in_fir"): the 29-tap audio low-pass inside the
     audio tail's kernel (k_audio_lpf_tail29: cFirFilter::ProcessTwo's ring buffer in registers, FirFilter.cpp:387-413,
     whole rounds of 29 frames as straight-line code, the frames around them through the generic body) and
@@ -328,7 +329,7 @@ def test_fused_audio_tail_and_level_meter_inside_the_fir(oracle, fmsig):
     audio frames than taps, calls that start and end in the middle of a round, full blocks."""
     pkg = load_package()
     sizes = [N, 10007, 1001, 330, 65535, 150, 33001, N, 2000, 21120, N]
-    _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, 1024, sizes, check=[0, 63, 64, 511, 1023], u8=False,
+    _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, 1024, sizes, check=[0, 63, 64, 511, 1023], u8=u8,
                     debug=(("fuse_alp", 1), ("level_in_fir", 1)))
 
 
