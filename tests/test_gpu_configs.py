@@ -264,3 +264,56 @@ def test_config5_full_size_against_oracle(oracle, fmsig):
         assert sg.stereo_detected == so.stereo
         assert np.float32(sg.pilot_level) == np.float32(so.pilot_level)
     b.close()
+
+
+def test_seek_stops_on_the_next_stereo_station(oracle, fmsig):
+    """SURVEY 8(f)-4, the consumer of the getters: the tuner dialog's seek (cChannelSettings::Process,
+    /root/reference/src/ChannelSettings.cpp:96-147) steps the tuned frequency by 100 kHz, listens for 1.25 s
+    and stops when GetSignalStatus reports stereo (RadioReceiver.cpp:544-572).  One capture holds the whole
+    2.4 MHz around the tuner: a batch with one channel per 100 kHz step (cFineTuner table of 24 entries,
+    FmDecode.cpp:45-58) listens to all 24 steps at once -- the seek's answer from any start, in one dwell.  Checked
+    against the reference's way: an oracle decoder per step, each fed the same 1.25 s."""
+    pkg = load_package()
+    fs, D, T = 2.4e6, 11, 24
+    # three stereo stations and a mono one on the 100 kHz grid, the other steps empty
+    stations = [fmsig.default_params(fs, f_offset=-700e3, amp=0.2, noise_sigma=0.004, seed=81, pi=0x7001),
+                fmsig.default_params(fs, f_offset=-200e3, amp=0.2, noise_sigma=0.004, seed=82, pi=0x7002),
+                fmsig.default_params(fs, f_offset=500e3, amp=0.2, noise_sigma=0.004, seed=83, pi=0x7003),
+                fmsig.mono_params(fs, f_offset=100e3, amp=0.2, noise_sigma=0.004, seed=84)]
+    shifts = np.arange(T, dtype=np.int32) - 12           # tuned to -1.2 MHz ... +1.1 MHz in 100 kHz steps
+    b = pkg.Batch(pkg.make_params(fs, 0.0, 48000.0, 15000.0, D, table_size=T), T, tuning_shifts=shifts,
+                  record_callbacks=False)
+    refs = [oracle.OracleDecoder(fs, 0.0, 48000.0, 15000.0, D, table_size=T, tuning_shift=int(k)) for k in shifts]
+    blocks = int(np.ceil(1.25 * fs / N))                  # the dialog's dwell
+    for blk in range(blocks):
+        cap = np.zeros(2 * N, dtype=np.float32)
+        for p in stations:
+            cap += fmsig.generate_f32(p, blk * N, N)
+        b.process_host(cap.view(np.complex64), shared=True)
+        for r in refs:
+            r.process_stream(cap)
+    stereo = [bool(b.status(c).stereo_detected) for c in range(T)]
+    stereo_ref = [bool(r.status().stereo) for r in refs]
+    assert stereo == stereo_ref
+    # a station at offset f is brought to 0 by shift -f / 100 kHz: channel index 12 - f / 100 kHz.  The pilot PLL
+    # also locks one step beside a stereo station (the decoder's behaviour, the reference's seek stops there too);
+    # the mono station (11) and its neighbours are passed, the empty steps too
+    on = [c for c in range(T) if stereo[c]]
+    assert {7, 14, 19} <= set(on) <= {6, 7, 8, 13, 14, 15, 18, 19, 20} and not ({10, 11, 12} & set(on))
+
+    def seek(flags, start, step):  # cChannelSettings::Process: step until stereo (wrapping like its band limits)
+        c = start
+        for _ in range(T):
+            c = (c + step) % T
+            if flags[c]:
+                return c
+        return None
+    for start in range(T):
+        for step in (+1, -1):
+            assert seek(stereo, start, step) == seek(stereo_ref, start, step)
+    assert seek(stereo, 9, +1) in (13, 14) and seek(stereo, 12, -1) in (8, 7)
+    for c in (7, 14, 19):  # the getters the dialog shows (IF level, pilot) agree bit for bit with the reference path
+        so, sg = refs[c].status(), b.status(c)
+        assert np.float32(so.if_level) == np.float32(sg.interface_level)
+        assert np.float32(so.pilot_level) == np.float32(sg.pilot_level)
+    b.close()
