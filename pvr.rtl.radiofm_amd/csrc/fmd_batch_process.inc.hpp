@@ -87,7 +87,8 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
     {
       kfn3 = RO == 3 ? &fmd::k_if_fir_mt3<IN, 18, 2, 3> : &fmd::k_if_fir_mt3<IN, 12, 2, 2>;
       ntiles_l = (M + T3 - 1) / T3;
-      lds_l = (size_t(T3 - 1) * D + d.if_order + 4) * sizeof(float2);
+      // ("fir_lds_pad": experiment -- LDS the workgroup claims and does not use: fewer waves per CU)
+      lds_l = (size_t(T3 - 1) * D + d.if_order + 4) * sizeof(float2) + size_t(b->dbg_fir_lds_pad);
       nblocks = C * ((ntiles_l + 1) / 2);
       // the level meter inside the first tile's workgroup: its (N + 63) / 64 samples have to lie in that tile's
       // window, which ends in front of the tile's last output position pos + (nout - 1) D
@@ -440,6 +441,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   const bool have_prev2 = ci > 2;
   hipEvent_t* pe2 = b->cev[(ci + fmd_batch::NSLOT - 2) % fmd_batch::NSLOT];
   const bool serial_mode = b->concurrency == 0 || b->profiling >= 2;
+  /* "stage_mask" (fmd_batch_debug_set; results are WRONG with anything but 63): which parts of a call are
+   * launched at all -- 1 IF stage, 2 serial stage, 4 half-band chain, 8 resampler, 16 / 32 the light part's RDS /
+   * audio half.  Every event is still recorded, so the pipeline keeps its shape: tools/power_by_stage.py runs each
+   * part alone at full rate beside a power sampler (joules per call and part). */
+  const unsigned stage_mask = (!serial_mode && !b->split_post) ? unsigned(b->dbg_stage_mask) : 63u;
   // (the gate: only where calls overlap on streams of their own queues and the post chain is one heavy stream)
   const bool use_gate = !serial_mode && b->concurrency == 2 && !b->split_post && b->dbg_gate != 0 &&
                         b->streams_sharing == 0 && b->heavy_flag.p != nullptr;
@@ -566,7 +572,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       if (i == 1)
         signal(ce[fmd_batch::EV_FIR], sF);
     };
-    const int rc = fmt == IQ_U8
+    int rc = FMD_OK;
+    if (!(stage_mask & 1u))
+      markfn(1); // (energy experiment: this call leaves the IF stage out -- see "stage_mask")
+    else
+      rc = fmt == IQ_U8
                        ? launch_if_stage<fmd::InU8>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn,
                                                    evset ? evset[0] : nullptr, evset ? evset[1] : nullptr)
                        : launch_if_stage<fmd::InF32>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, markfn,
@@ -625,7 +635,9 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                        : (serial_claim ? &fmd::k_demod_serial<2, true, true> : &fmd::k_demod_serial<2, false, true>);
     auto kser1 = nomix ? &fmd::k_demod_serial<1, false, false> : &fmd::k_demod_serial<1, false, true>;
 
-    if (b->serial_exclusive && !serial_mode && evset && b->profiling == 1)
+    if (!(stage_mask & 2u))
+      ; // (energy experiment: no serial stage in this call)
+    else if (b->serial_exclusive && !serial_mode && evset && b->profiling == 1)
       // profiling level 1: the stage's own start and stop too (fmd_batch_debug_timeline)
       hipExtLaunchKernelGGL(kser2, dim3((groups + 1) / 2), dim3(256), 0u, sS, evset[2],
                             evset[3], 0u, (const float2*)b->demod[q].p, b->Mstride, M, C, CP, k, b->st,
@@ -1042,9 +1054,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     }
     else
     {
-    rds_heavy();
+    if (stage_mask & 4u)
+      rds_heavy();
     signal(ce[(lpf_late || lpf_light) ? fmd_batch::EV_DEC : fmd_batch::EV_RDSH], sR);
-    audio_heavy();
+    if (stage_mask & 8u)
+      audio_heavy();
     if (use_gate)
       hipLaunchKernelGGL(fmd::k_flag_set, dim3(1), dim3(1), 0, sP, b->heavy_flag.p + es, ci);
     signal(ce[fmd_batch::EV_HEAVY], sP); // the next-but-one call's IF FIR may go
@@ -1127,7 +1141,10 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     {
       if (!lpf_light)
         after(sL, ce[fmd_batch::EV_RDSH]);
-      launch_light(b, job, sL, true);
+      if ((stage_mask & 48u) != 48u) // (energy experiment: one half of the light part, or none)
+        job.part = (stage_mask & 16u) ? 1 : 2;
+      if (stage_mask & 48u)
+        launch_light(b, job, sL, true);
     }
   }
   mark(9);
