@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--channels", type=int, default=8192)
     ap.add_argument("--fir-variants", action="store_true")
+    ap.add_argument("--forms", action="store_true")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"])
     args = ap.parse_args()
     import numpy as np  # noqa: F401
@@ -140,6 +141,36 @@ def main():
             print("%-48s %.4f ms/call  %6.0f W  %4.0f MHz  %.3f J/call  (%.3f above idle)" % (
                 name, dt * 1e3, p, clk, p * dt, (p - p_idle) * dt))
             time.sleep(0.5)
+    if args.forms:  # the opt-in forms in joules: audio low-pass inside the tail, level meter inside the FIR
+        def measure(name, mask, keys):
+            for k_, v_ in keys.items():
+                b.debug_set(k_, v_)
+            b.debug_set("stage_mask", mask)
+            t0 = time.perf_counter()
+            run(40)
+            per = (time.perf_counter() - t0) / 40
+            calls = max(200, int(args.seconds / per))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(calls)
+            t1 = time.perf_counter()
+            dt = (t1 - t0) / calls
+            lo, hi = t0 + 0.25 * (t1 - t0), t1 - 0.1 * (t1 - t0)
+            ws = [(w, c) for t, w, c in smp.samples if lo <= t <= hi]
+            p = sum(w for w, _ in ws) / max(1, len(ws))
+            clk = sum(c for _, c in ws) / max(1, len(ws))
+            print("%-58s %.4f ms/call  %6.0f W  %4.0f MHz  %.3f J/call  (%.3f above idle)" % (
+                name, dt * 1e3, p, clk, p * dt, (p - p_idle) * dt))
+            time.sleep(0.5)
+        measure("audio half: low-pass kernel + tail (shipped)", 32, {"fuse_alp": 0})
+        measure("audio half: low-pass inside the tail (k_audio_lpf_tail29)", 32, {"fuse_alp": 1})
+        measure("audio half: low-pass kernel + tail (shipped), again", 32, {"fuse_alp": 0})
+        measure("IF stage: level meter in its own kernel (shipped)", 1, {"level_in_fir": 0})
+        measure("IF stage: level meter inside the FIR", 1, {"level_in_fir": 1})
+        measure("IF stage: level meter in its own kernel (shipped), again", 1, {"level_in_fir": 0})
+        measure("whole call, shipped", 63, {})
+        measure("whole call, both fusions", 63, {"fuse_alp": 1, "level_in_fir": 1})
+        measure("whole call, shipped, again", 63, {"fuse_alp": 0, "level_in_fir": 0})
     b.debug_set("stage_mask", 63)
     smp.stop = True
     print(json.dumps({"idle_watts": round(p_idle, 1), "channels": C, "rows": rows}))
