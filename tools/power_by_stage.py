@@ -168,7 +168,9 @@ def main():
         measure("IF stage: level meter in its own kernel (shipped)", 1, {"level_in_fir": 0})
         measure("IF stage: level meter inside the FIR", 1, {"level_in_fir": 1})
         measure("IF stage: level meter in its own kernel (shipped), again", 1, {"level_in_fir": 0})
-        measure("whole call, shipped", 63, {})
+        for pr in (3, 1, 0):
+            measure("whole call, audio low-pass inside the tail, priority %d" % pr, 63, {"fuse_alp": 1, "level_in_fir": 0, "alt_prio": pr})
+        measure("whole call, shipped", 63, {"fuse_alp": 0, "alt_prio": 3})
         measure("whole call, both fusions", 63, {"fuse_alp": 1, "level_in_fir": 1})
         measure("whole call, shipped, again", 63, {"fuse_alp": 0, "level_in_fir": 0})
     b.debug_set("stage_mask", 63)
