@@ -125,9 +125,15 @@ def test_full_size_verify_of_the_other_configs(workload, steps):
 def test_node_bench_cpp_world_of_one():
     """tools/node_bench: the timed loop of a rank in C++ (no Python in the process), here with a world of
     one -- the RCCL communicator is created from the id file, every step goes through fmd_gather_step."""
-    out = subprocess.run([os.path.join(ROOT, "tools", "node_bench"), "--gpus", "1", "--steps", "12", "--warmup", "4",
-                          "--channels", "2048"], capture_output=True, text=True, timeout=240)
+    cmd = [os.path.join(ROOT, "tools", "node_bench"), "--gpus", "1", "--steps", "12", "--warmup", "4", "--channels",
+           "2048", "--verify", "--watchdog", "90"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
+    if out.returncode != 0 and not out.stdout.strip():
+        # RCCL's bootstrap in a freshly forked process has stalled once in ~20 runs on this pool (no output at all,
+        # the rank's own watchdog ends it): that is the pool's, not the gather's -- one more try
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["audio_floats_per_channel_step"] in (2620, 2622)
     assert d["config"]["gather_ms_per_step_rank0"] > 0
+    assert d["rccl_ranks_seen"] == 1 and d["verify"]["ok"] and d["verify"]["per_rank_ok"] == [True]

@@ -4,7 +4,7 @@
  * over RCCL (include/fmd_gather.h).  The same loop as bench.py's (calls overlapped, outputs consumed
  * LAG steps late), same JSON keys; bench.py stays the driver's entry point.
  *
- *   tools/node_bench --gpus N [--steps K] [--warmup W] [--channels C] [--verify]
+ *   tools/node_bench --gpus N [--steps K] [--warmup W] [--channels C] [--watchdog seconds] [--verify]
  *
  * The parent forks the N ranks BEFORE anything touches HIP; rank 0 writes the communicator's id into a
  * file the others wait for.  Build: make -C pvr.rtl.radiofm_amd/csrc ../../tools/node_bench
@@ -260,6 +260,7 @@ int main(int argc, char** argv)
   int gpus = 1, K = 40, W = 8;
   unsigned C = 8192;
   bool verify = false;
+  unsigned watchdog = 900; // seconds after which a rank ends itself (a stalled RCCL bootstrap must not hang the node)
   for (int i = 1; i < argc; i++)
     if (std::string(argv[i]) == "--verify")
     { // a flag without a value: take it out of the key / value pairs
@@ -276,6 +277,7 @@ int main(int argc, char** argv)
     else if (k == "--steps") K = atoi(argv[i + 1]);
     else if (k == "--warmup") W = atoi(argv[i + 1]);
     else if (k == "--channels") C = unsigned(atoi(argv[i + 1]));
+    else if (k == "--watchdog") watchdog = unsigned(atoi(argv[i + 1]));
   }
   const std::string idfile = "/tmp/fmd_node_bench_" + std::to_string(getpid()) + ".id";
   setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); // dmabuf IPC: what RCCL needs on this pool
@@ -285,7 +287,10 @@ int main(int argc, char** argv)
   {
     const pid_t p = fork();
     if (p == 0)
+    {
+      alarm(watchdog);
       _exit(rank_main(r, gpus, K, W, C, idfile, verify));
+    }
     kids.push_back(p);
   }
   int worst = 0;
