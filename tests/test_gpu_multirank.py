@@ -67,13 +67,18 @@ def test_rccl_path_with_a_world_of_one():
     env.update(FMD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29544",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("FMD_BENCH_BACKEND", None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline",
-                          "--verify", "--channels", "256", "--steps", "30", "--warmup", "3", "--ring", "24",
-                          "--watchdog", "240"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline", "--verify",
+           "--channels", "256", "--steps", "30", "--warmup", "3", "--ring", "24", "--watchdog", "120"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
+    if out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]:
+        # (a stalled RCCL bootstrap, ended by bench.py's own watchdog: seen once in ~20 runs on this pool)
+        env["MASTER_PORT"] = "29543"
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert "RCCL" in d["config"]["gather"] and d["verify"]["ok"]
     assert d["config"]["rds_groups_in_timed_region"] > 0
+    assert d["rccl_ranks_seen"] == 1 and d["per_rank"][0]["rccl_rank"] == 0
 
 
 def test_bench_starts_its_own_ranks():
