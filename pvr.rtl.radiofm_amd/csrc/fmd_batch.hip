@@ -190,6 +190,7 @@ struct fmd_batch
   DevBuf<long long> serial_probe; // FMD_SERIAL_PROBE=1: per-workgroup timing of the serial stage
   DevBuf<unsigned> heavy_flag;    // [NSLOT]: call index whose heavy part has ended (k_flag_set / k_gate_wait)
   int dbg_fir_lds_pad = 0;        // experiment: bytes of LDS an IF FIR workgroup claims on top of its window
+  int dbg_light_pack = 1;         // channel groups (waves) per workgroup of the light part's lane-per-channel kernels
   int dbg_stage_mask = 63;        // energy experiment: parts of a call that are launched (63 = all; else wrong results)
   int dbg_rs_first = 0;           // 1: resampler in front of the half-band chain, the chain beside the next IF FIR
   int dbg_gate = 0;               // 1: the IF FIR waits for the heavy part of two calls ago through that word
@@ -1216,6 +1217,8 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
     b->dbg_light_hold = std::max(0, std::min(3, value));
   else if (k == "fir_lds_pad")
     b->dbg_fir_lds_pad = std::max(0, std::min(48 * 1024, value));
+  else if (k == "light_pack")
+    b->dbg_light_pack = std::max(1, std::min(4, value));
   else if (k == "stage_mask")
     b->dbg_stage_mask = value & 63;
   else if (k == "rs_first")

@@ -218,6 +218,7 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
   const fmd::Design& d = b->des;
   const unsigned C = b->C, CP = b->CP;
   const unsigned T_mf = unsigned(d.rds_mf_taps.size());
+  const unsigned LP = unsigned(std::max(1, std::min(4, b->dbg_light_pack))); // channel groups per workgroup
   const dim3 rt(256);
   auto rgrid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
   // a complex ring-buffer filter of the light part (RDS low-pass / audio low-pass) and its input's history roll
@@ -268,7 +269,7 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
                          b->rmf.p, j.R, int(T_mf), b->mf_taps2.p, j.mf_g, C, CP, 0u);
     hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, s, b->rpll.p, b->rpll.p, T_mf - 1, j.R,
                        CP);
-    hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, s, b->rmf.p, j.R, C, CP, k, b->st,
+    hipLaunchKernelGGL(fmd::k_rds_bits, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0, s, b->rmf.p, j.R, C, CP, k, b->st,
                        j.call_index, b->queue[j.es].p, b->qcount(j.es), b->queue_cap,
                        b->tap_sync.p, b->write_taps);
   }
@@ -298,20 +299,20 @@ void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, boo
     k.n_a1 = d.notch.a1;
     k.n_a2 = d.notch.a2;
     if (j.fuse_alp && j.tl0)
-      hipExtLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3(CP / 64), dim3(64), 0u, s, j.tl0, j.tl1, 0u,
+      hipExtLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0u, s, j.tl0, j.tl1, 0u,
                             (const float2*)b->rs[j.q].p, b->rs[j.q ^ 1].p, j.A, j.alpf_g,
                             (const float*)b->audio_taps.p, C, CP, k, b->st, j.d_audio, j.audio_stride,
                             unsigned(j.sq), j.call_index, unsigned(b->dbg_alt_prio));
     else if (j.fuse_alp)
-      hipLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3(CP / 64), dim3(64), 0, s, b->rs[j.q].p, b->rs[j.q ^ 1].p,
+      hipLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0, s, b->rs[j.q].p, b->rs[j.q ^ 1].p,
                          j.A, j.alpf_g, b->audio_taps.p, C, CP, k, b->st, j.d_audio, j.audio_stride,
                          unsigned(j.sq), j.call_index, unsigned(b->dbg_alt_prio));
     else if (j.tl0)
-      hipExtLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0u, s, j.tl0, j.tl1, 0u,
+      hipExtLaunchKernelGGL(fmd::k_audio_tail, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0u, s, j.tl0, j.tl1, 0u,
                             (const float2*)b->alp[j.q].p, j.A, C, CP, k, b->st, j.d_audio, j.audio_stride,
                             unsigned(j.sq), j.call_index);
     else
-      hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, s, b->alp[j.q].p, j.A, C, CP, k,
+      hipLaunchKernelGGL(fmd::k_audio_tail, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0, s, b->alp[j.q].p, j.A, C, CP, k,
                          b->st, j.d_audio, j.audio_stride, unsigned(j.sq), j.call_index);
     if (s != s_rds_part && hipStreamWaitEvent(s, b->cev[j.es][fmd_batch::EV_RDS], 0) != hipSuccess)
       mark_failed(b, "hipStreamWaitEvent failed in front of the status record of a call"); // its RDS state is the other half's
@@ -440,6 +441,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   // call k-2 used the same buffers; its events say when they are free again
   const bool have_prev2 = ci > 2;
   hipEvent_t* pe2 = b->cev[(ci + fmd_batch::NSLOT - 2) % fmd_batch::NSLOT];
+  const unsigned LP = unsigned(std::max(1, std::min(4, b->dbg_light_pack))); // light kernels: groups per workgroup
   const bool serial_mode = b->concurrency == 0 || b->profiling >= 2;
   /* "stage_mask" (fmd_batch_debug_set; results are WRONG with anything but 63): which parts of a call are
    * launched at all -- 1 IF stage, 2 serial stage, 4 half-band chain, 8 resampler, 16 / 32 the light part's RDS /
@@ -907,7 +909,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                            dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), sR,
                            b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C, CP, 0u);
       hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, sR, b->rpll.p, b->rpll.p, T_mf - 1, R, CP);
-      hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64), 0, sR, b->rmf.p, R, C, CP, k,
+      hipLaunchKernelGGL(fmd::k_rds_bits, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0, sR, b->rmf.p, R, C, CP, k,
                          b->st, ci, b->queue[es].p, b->qcount(es), b->queue_cap,
                          b->tap_sync.p, b->write_taps);
     }
@@ -995,11 +997,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       k.n_a1 = d.notch.a1;
       k.n_a2 = d.notch.a2;
       if (fuse_alp)
-        hipLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3(CP / 64), dim3(64), 0, sA, b->rs[q].p, b->rs[q ^ 1].p, A,
+        hipLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0, sA, b->rs[q].p, b->rs[q ^ 1].p, A,
                            b->alpf_g, b->audio_taps.p, C, CP, k, b->st, d_audio, audio_channel_stride, unsigned(sq), ci,
                            unsigned(b->dbg_alt_prio));
       else
-      hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64), 0, sA, b->alp[q].p, A, C, CP, k,
+      hipLaunchKernelGGL(fmd::k_audio_tail, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0, sA, b->alp[q].p, A, C, CP, k,
                          b->st, d_audio, audio_channel_stride, unsigned(sq), ci);
     }
   };

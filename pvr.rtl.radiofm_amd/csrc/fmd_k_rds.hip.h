@@ -716,14 +716,14 @@ __global__ __launch_bounds__(64 * RP_WAVES) void k_rds_pll(const float2* __restr
  *      a bit. */
 constexpr int RB_TILE = 32;
 
-__global__ __launch_bounds__(64) void k_rds_bits(const float* __restrict__ mf, unsigned R, unsigned C,
+__global__ __launch_bounds__(256) void k_rds_bits(const float* __restrict__ mf, unsigned R, unsigned C,
                                                  unsigned CP, RdsConsts k, ChannelState st,
                                                  uint32_t call_index, RdsGroupRec* __restrict__ queue,
                                                  unsigned* __restrict__ queue_count, unsigned queue_cap,
                                                  float* __restrict__ tap_sync, int write_taps)
 {
   __builtin_amdgcn_s_setprio(3);
-  const unsigned c = blockIdx.x * 64 + threadIdx.x;
+  const unsigned c = (blockIdx.x * blockDim.y + threadIdx.y) * 64 + threadIdx.x; // (blockDim.y groups: light_pack)
   if (c >= C)
     return;
   const uint32_t offs[8] = {0x3D8, 0x3D4, 0x25C, 0x258, 0x3D8, 0x3D4, 0x3CC, 0x258};

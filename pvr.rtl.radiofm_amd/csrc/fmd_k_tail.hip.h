@@ -23,7 +23,7 @@ constexpr int AT_STEPS = 16; // rows in flight per lane (32: slower inside the p
  * whole-CU resampler off every CU an audio tail was on, and the stores are not what bounds a
  * lane-per-channel recurrence.)  The status record goes to device memory; k_status_publish takes it
  * to the host. */
-__global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp, unsigned A,
+__global__ __launch_bounds__(256) void k_audio_tail(const float2* __restrict__ lp, unsigned A,
                                                    unsigned C, unsigned CP, AudioConsts k,
                                                    ChannelState st, float* __restrict__ audio,
                                                    size_t audio_stride, unsigned stereo_q,
@@ -31,7 +31,11 @@ __global__ __launch_bounds__(64) void k_audio_tail(const float2* __restrict__ lp
 {
   __builtin_amdgcn_s_setprio(3);
   const unsigned lane = threadIdx.x;
-  const unsigned c0 = blockIdx.x * 64 + lane;
+  // (blockDim.y channel groups per workgroup, a wave each, nothing shared: "light_pack" -- a CU that is awake for
+  // one wave draws as much as one that is busy, so the light part's waves go four to a CU: MEASUREMENTS, round 5)
+  const unsigned c0 = (blockIdx.x * blockDim.y + threadIdx.y) * 64 + lane;
+  if (c0 - lane >= CP)
+    return;
   const bool active = c0 < C;
   const unsigned c = active ? c0 : C - 1;
   float de_re = st.F(F_DE_RE)[c], de_im = st.F(F_DE_IM)[c];
@@ -299,7 +303,7 @@ struct AudioLpfTail
   }
 };
 
-__global__ __launch_bounds__(64) void k_audio_lpf_tail29(const float2* __restrict__ rs, float2* __restrict__ rs_next,
+__global__ __launch_bounds__(256) void k_audio_lpf_tail29(const float2* __restrict__ rs, float2* __restrict__ rs_next,
                                                          unsigned A, unsigned g0, const float* __restrict__ taps2,
                                                          unsigned C, unsigned CP, AudioConsts k, ChannelState st,
                                                          float* __restrict__ audio, size_t audio_stride,
@@ -308,7 +312,9 @@ __global__ __launch_bounds__(64) void k_audio_lpf_tail29(const float2* __restric
   constexpr int T = 29;
   wave_prio(prio);
   const unsigned lane = threadIdx.x;
-  const unsigned c0 = blockIdx.x * 64 + lane;
+  const unsigned c0 = (blockIdx.x * blockDim.y + threadIdx.y) * 64 + lane;
+  if (c0 - lane >= CP)
+    return;
   AudioLpfTail<T> s;
   s.active = c0 < C;
   const unsigned c = s.active ? c0 : C - 1;

@@ -162,6 +162,11 @@ def main():
             print("%-58s %.4f ms/call  %6.0f W  %4.0f MHz  %.3f J/call  (%.3f above idle)" % (
                 name, dt * 1e3, p, clk, p * dt, (p - p_idle) * dt))
             time.sleep(0.5)
+        for lp in (1, 2, 4):
+            measure("light part, RDS half, %d groups per workgroup" % lp, 16, {"light_pack": lp})
+            measure("light part, audio half, %d groups per workgroup" % lp, 32, {"light_pack": lp})
+            measure("whole call, %d groups per workgroup" % lp, 63, {"light_pack": lp})
+        b.debug_set("light_pack", 1)
         measure("audio half: low-pass kernel + tail (shipped)", 32, {"fuse_alp": 0})
         measure("audio half: low-pass inside the tail (k_audio_lpf_tail29)", 32, {"fuse_alp": 1})
         measure("audio half: low-pass kernel + tail (shipped), again", 32, {"fuse_alp": 0})
