@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--channels", type=int, default=8192)
     ap.add_argument("--fir-variants", action="store_true")
     ap.add_argument("--forms", action="store_true")
+    ap.add_argument("--alt-forms", action="store_true")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"])
     args = ap.parse_args()
     import numpy as np  # noqa: F401
@@ -178,6 +179,37 @@ def main():
         measure("whole call, shipped", 63, {"fuse_alp": 0, "alt_prio": 3})
         measure("whole call, both fusions", 63, {"fuse_alp": 1, "level_in_fir": 1})
         measure("whole call, shipped, again", 63, {"fuse_alp": 0, "level_in_fir": 0})
+    if args.alt_forms:  # the other forms of the heavy kernels and of the serial stage, in joules
+        def measure2(name, mask, keys, undo):
+            for k_, v_ in keys.items():
+                b.debug_set(k_, v_)
+            b.debug_set("stage_mask", mask)
+            t0 = time.perf_counter()
+            run(40)
+            per = (time.perf_counter() - t0) / 40
+            calls = max(200, int(args.seconds / per))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(calls)
+            t1 = time.perf_counter()
+            dt = (t1 - t0) / calls
+            lo, hi = t0 + 0.25 * (t1 - t0), t1 - 0.1 * (t1 - t0)
+            ws = [(w, c) for t, w, c in smp.samples if lo <= t <= hi]
+            p = sum(w for w, _ in ws) / max(1, len(ws))
+            clk = sum(c for _, c in ws) / max(1, len(ws))
+            print("%-58s %.4f ms/call  %6.0f W  %4.0f MHz  %.3f J/call  (%.3f above idle)" % (
+                name, dt * 1e3, p, clk, p * dt, (p - p_idle) * dt))
+            for k_, v_ in undo.items():
+                b.debug_set(k_, v_)
+            time.sleep(0.5)
+        measure2("resampler: LDS ring, 8 waves x 2 outputs (shipped)", 8, {}, {})
+        measure2("resampler: LDS ring, 4 waves x 4 outputs", 8, {"rsr_form": 1}, {"rsr_form": 0})
+        measure2("resampler: window per wave (round 3)", 8, {"resampler": 0}, {"resampler": -1})
+        measure2("half-band chain: one kernel (shipped)", 4, {}, {})
+        measure2("half-bands: a launch per stage (round 3)", 4, {"halfband_chain": 0}, {"halfband_chain": -1})
+        measure2("serial stage: whole CUs (shipped)", 2, {}, {})
+        measure2("serial stage: whole CUs, waves claim their SIMD", 2, {"serial_claim": 1}, {"serial_claim": 0})
+        measure2("serial stage: shared form", 2, {"serial_exclusive": 0}, {"serial_exclusive": 1})
     b.debug_set("stage_mask", 63)
     smp.stop = True
     print(json.dumps({"idle_watts": round(p_idle, 1), "channels": C, "rows": rows}))
