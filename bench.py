@@ -880,7 +880,11 @@ def main():
         # PMC needs its own rocprofv3 passes, it cannot be collected inside this run)
         # the file is keyed by the kernel form: two tiles per workgroup (k_if_fir_mt) is what runs when
         # calls overlap beside the whole-CU serial stage, one tile (k_if_fir) otherwise
-        form = "k_if_fir_mt" if (args.concurrency == 2 and 1024 <= (C + 63) // 64 * 64 <= 8192
+        # (above 8192 channels the batch runs as sub-batches of equal size: fmd_batch_create)
+        n_sub = (C + 8191) // 8192
+        c_sub = C if n_sub == 1 else min(C, ((C + n_sub - 1) // n_sub + 127) // 128 * 128)
+        out["roofline"]["launches_per_call"] = n_sub
+        form = "k_if_fir_mt" if (args.concurrency == 2 and 1024 <= (c_sub + 63) // 64 * 64 <= 8192
                                  and args.workload == "config4" and args.fir_reduction == 0) else "k_if_fir"
         # (two outputs per lane, k_if_fir_mt3, unless a --debug-set fir_ro says otherwise; the traffic file
         # keeps the older key)

@@ -57,6 +57,7 @@ extern "C" {
  * values 64 (FmDecode.cpp:249) and 8*downsample (FmDecode.cpp:262). */
 #define FMD_FIR_SEQUENTIAL 0
 #define FMD_FIR_SHUFFLE_PARITY_WAIVED 0x101
+#define FMD_FIR_FMA_PARITY_WAIVED 0x102
 typedef struct fmd_params
 {
   double sample_rate_if;
@@ -74,7 +75,13 @@ typedef struct fmd_params
    * a different order of float additions.  Measured on BASELINE config 2 (6 s): audio 1.2e-5 RMS from
    * the reference (worst block 3.5e-5) -- ABOVE the 1e-5 RMS the contract allows -- and 3x slower, so
    * whoever asks for it says in the value itself that parity is waived; a plain 1 is refused.
-   * Headline window layout only (odd downsample, power-of-two tuner table), other geometries ignore it. */
+   * Headline window layout only (odd downsample, power-of-two tuner table), other geometries ignore it.
+   * FMD_FIR_FMA_PARITY_WAIVED: the reference's tap order, every multiply-add fused (v_pk_fma_f32: one rounding
+   * per tap instead of two) in the IF FIR and in the two fractional resamplers (DownConvert.cpp:117-121,
+   * 203-232) -- what an x86 build of the reference with -march=native does to the same loops (BASELINE.md
+   * section 2: "output bits change").  Not bit-identical, so it too has to be asked for by name (a plain 2 is
+   * refused); it exists to put a price on bit-exactness (docs/MEASUREMENTS.md: audio RMS distance, joules per
+   * call, MS/s).  Reference geometry only (88 taps, downsample 11); refused elsewhere. */
   int fir_reduction;
 } fmd_params;
 

@@ -127,7 +127,7 @@ struct fmd_batch
   // k_resample_ring (large batches): outputs per wave (0 = this geometry does not fit the CU's LDS),
   // ring batches, batches per group in the tap table, row offset; plan buffers; -1 auto / 0 off / 1 on
   int rsr_R = 0, rsr_NW = 0;
-  unsigned rsr_nbr = 0, rsr_nbm = 0, rsr_exp = 0, rsr_pace = 0;
+  unsigned rsr_nbr = 0, rsr_nbm = 0;
   int rsr_rb = 0;
   DevBuf<float> rsr_tab;
   DevBuf<int> rsr_head, rsr_steps;
@@ -165,36 +165,19 @@ struct fmd_batch
   int dbg_nomix = 1;
   // development switches (fmd_batch_debug_set; the library reads no environment variable)
   int dbg_fir_nt = 0;          // tiles per IF FIR workgroup (0: the library decides)
-  int dbg_fir_b128 = 1;        // long filters: 16-byte window reads where the layout allows
   int dbg_serial_claim = 0;    // whole-CU serial stage: every role wave claims its SIMD's register file
-  int dbg_post_delay_us = 20;  // the post chain starts this long behind the serial stage's end
   int dbg_hb4 = 1, dbg_ring4 = 1; // 0: the generic half-band / ring-FIR kernels where the unrolled ones would run
-  int dbg_prof_dump = 0;
   int dbg_fir_ro = 2;          // outputs per lane of the headline IF FIR form: 1 k_if_fir_mt, 2 / 3 k_if_fir_mt3
                                // (2: 288 600 MS/s and the FIR 0.975 ms inside the pipeline; 3: 287 500 and 1.00)
-  int dbg_heavy_prio = 2;      // s_setprio of k_halfband_chain's (tens) and k_resample_ring's (units) waves
-  int dbg_rsr_wgs = 0;         // workgroups of k_resample_ring (0: the library decides)
-  int dbg_lpf_late = -1;       // where the post chain's low-pass filters run: -1 the library decides, 0 heavy
-                               // stream, 1 a stream of their own, 2 the light stream (in front of their readers)
-  int dbg_level_in_fir = 0;    // 1: RMSLevelApprox inside k_if_fir_mt3's first workgroup of a channel (0: k_if_level)
-  int dbg_light_split = 1;     // the light part's audio half on its own stream, beside the RDS half
-  int dbg_lpf_prio = 0;        // wave priority of the two complex low-pass filters (k_ring_fir4<float2>)
-  int dbg_alt_prio = 3;        // wave priority of k_audio_lpf_tail29
-  int dbg_fuse_alp = 0;        // 1: 29-tap audio low-pass inside the audio tail's kernel (k_audio_lpf_tail29): 0.15 GB
-                               // per call less, bit-identical, but no faster as a whole and the IF FIR beside it
-                               // slower (0.57 against 0.59 of the HBM peak): measured, left off
+  int dbg_lpf_late = -1;       // stream layout of an overlapped call (process_device_impl): -1 the library decides,
+                               // 0 low-pass filters on the heavy stream, 1 on a stream of their own, 2 at the
+                               // heads of the light part's two streams
   // where a host-buffer call's time goes (fmd_batch_debug_host_ms): copy in, submission, wait + copy
   // out, RDS collection + group decoder callbacks; sums since the last query
   double host_ms[4] = {0, 0, 0, 0};
   unsigned host_calls = 0;
   DevBuf<long long> serial_probe; // FMD_SERIAL_PROBE=1: per-workgroup timing of the serial stage
-  DevBuf<unsigned> heavy_flag;    // [NSLOT]: call index whose heavy part has ended (k_flag_set / k_gate_wait)
-  int dbg_fir_lds_pad = 0;        // experiment: bytes of LDS an IF FIR workgroup claims on top of its window
-  int dbg_light_pack = 1;         // channel groups (waves) per workgroup of the light part's lane-per-channel kernels
   int dbg_stage_mask = 63;        // energy experiment: parts of a call that are launched (63 = all; else wrong results)
-  int dbg_rs_first = 0;           // 1: resampler in front of the half-band chain, the chain beside the next IF FIR
-  int dbg_gate = 0;               // 1: the IF FIR waits for the heavy part of two calls ago through that word
-                                  // (the gap shrinks from 110 to 76 us, the period does not move: measured, off)
   DevBuf<float> fstate; // all float state arrays, CP each
   DevBuf<int> istate;
   DevBuf<uint16_t> r_data;
@@ -248,27 +231,37 @@ struct fmd_batch
   //                  fmd_batch_collect_rds; lets call k+1's FIR overlap call k's serial stages
   int concurrency = 1;
   hipStream_t s_fir = nullptr, s_ser = nullptr, s_post = nullptr, s_rds = nullptr, s_lpf = nullptr;
-  // What the light part of a call's post chain (RDS PLL, matched filter, bit recovery, audio tail)
-  // needs to know about its call: see launch_light.
+  // What the light part of a call's post chain (RDS PLL, matched filter, bit recovery, audio tail) needs to know
+  // about its call: see launch_light_rds / launch_light_audio.
   struct LightJob
   {
     unsigned R = 0, A = 0, mf_g = 0, alpf_g = 0;
-    int q = 0, es = 0, sq = 0;
-    bool tail_after_alp = false; // the audio tail waits for EV_ALP (the audio low-pass behind EV_HEAVY)
-    bool fuse_alp = false;       // audio low-pass inside the tail kernel (k_audio_lpf_tail29)
-    hipStream_t s_audio = nullptr;     // the audio half on a stream of its own (beside the RDS half), or null
-    hipStream_t sL = nullptr;          // the RDS half's stream (kept-back jobs carry it)
-    int part = 0;                      // 0 both halves, 1 the RDS half only, 2 the audio half only
-    bool lpf_here = false;             // the two complex low-pass filters are part of the light part (lpf_light)
     unsigned rds_lpf_g = 0;            // ring phase of the RDS low-pass at this call
+    int q = 0, es = 0, sq = 0;
+    bool events = true;                // false: everything on the caller's stream, no event is recorded or waited for
+    bool lpf_here = false;             // the two complex low-pass filters are part of the light part (layout 2)
+    int audio_after = -1;              // event of the call the audio half waits for on its stream (-1: stream order)
+    bool status_after_rds = false;     // the two halves are on different streams: the status record waits for EV_RDS
+    hipEvent_t prev_aud = nullptr;     // ... and the bit recovery for the previous call's status record
     uint32_t call_index = 0;
     float* d_audio = nullptr;
     size_t audio_stride = 0;
     hipEvent_t tl0 = nullptr, tl1 = nullptr; // profiling level 1: the audio tail's own start / stop
   };
-  std::deque<LightJob> held_light;     // light parts kept back until the next call (light_hold)
-  int dbg_light_hold = 0;              // 1: a call's light part runs beside the NEXT heavy part, not the next-but-one FIR
-                                       // (FIR 0.60-0.61 of peak instead of 0.58-0.59, whole path -7.5 %: measured, off)
+  /* More channels than the whole-CU pipeline is built for (kSubBatchChannels = 64 CUs' worth of serial stage): the
+   * batch the caller holds is a SHELL over ceil(C / 8192) sub-batches of equal size, each a complete batch of its own
+   * (buffers, channel state, RDS queues, status snapshot), all on the shell's five streams.  A call is submitted
+   * sub-batch by sub-batch, so that on the streams the sub-batch calls form ONE sequence of 8192-channel calls --
+   * FIR(k, s + 1) behind heavy(k, s - 1), serial stages back to back -- i.e. the pipeline DESIGN.md section 2
+   * describes, at its rate, whatever C is (channels are independent: FmDecode.h:201-212).  The shell owns the
+   * streams, the caller-facing bookkeeping (group decoders, host staging, export cursor) and nothing on the device. */
+  std::vector<std::unique_ptr<fmd_batch>> subs;
+  std::vector<unsigned> sub_ch0;   // first channel of every sub-batch, and C behind the last
+  bool owns_streams = true;        // false: a sub-batch, the streams are its shell's
+  hipEvent_t vheavy[2] = {nullptr, nullptr}; // shell: EV_HEAVY of the last two sub-batch calls of the common sequence
+  // sub-batch: EV_HEAVY of the sub-batch call two back in the common sequence -- this call's IF FIR stays behind it
+  // (process_device_impl); else null
+  hipEvent_t sched_prev2 = nullptr;
   bool split_post = false;
   bool serial_exclusive = false; // serial stage owns whole CUs (small batches, see the launch)
   enum { EV_IN, EV_FIR, EV_INDONE, EV_SER, EV_AUD, EV_RDS, EV_HEAVY, EV_RDSH, EV_ALP, EV_DEC, EV_ROLL, EV_N };
@@ -298,6 +291,7 @@ struct fmd_batch
   {
     (void)hipSetDevice(device);
     (void)hipDeviceSynchronize();
+    subs.clear(); // (sub-batches first: the streams they run on are this object's)
     lut.release();
     hist[0].release();
     hist[1].release();
@@ -347,7 +341,6 @@ struct fmd_batch
     sctab256.release();
     pidx.release();
     serial_probe.release();
-    heavy_flag.release();
     fstate.release();
     istate.release();
     r_data.release();
@@ -364,18 +357,13 @@ struct fmd_batch
     if (h_recs)
       (void)hipHostFree(h_recs);
     if (cev_ready)
-    {
       for (auto& row : cev)
         for (auto& e : row)
           (void)hipEventDestroy(e);
-      (void)hipStreamDestroy(s_fir);
-      (void)hipStreamDestroy(s_ser);
-      (void)hipStreamDestroy(s_post);
-      if (s_rds)
-        (void)hipStreamDestroy(s_rds);
-      if (s_lpf)
-        (void)hipStreamDestroy(s_lpf);
-    }
+    if (owns_streams)
+      for (hipStream_t st : {s_fir, s_ser, s_post, s_rds, s_lpf})
+        if (st)
+          (void)hipStreamDestroy(st);
     h_iq.release();
     h_audio.release();
     if (h_err)
@@ -392,6 +380,28 @@ namespace
 {
 
 constexpr unsigned kMaxProfCalls = 512;
+// channels of one batch with buffers of its own: 64 CUs' worth of the whole-CU serial stage (128 channels per CU)
+constexpr unsigned kSubBatchChannels = 8192;
+
+inline bool is_shell(const fmd_batch* b)
+{
+  return !b->subs.empty();
+}
+
+/* the sub-batch that owns a channel, and the channel's index there (a plain batch: itself) */
+inline fmd_batch* owner_of(fmd_batch* b, unsigned channel, unsigned* local)
+{
+  if (!is_shell(b))
+  {
+    *local = channel;
+    return b;
+  }
+  size_t s = 0;
+  while (s + 1 < b->subs.size() && channel >= b->sub_ch0[s + 1])
+    s++;
+  *local = channel - b->sub_ch0[s];
+  return b->subs[s].get();
+}
 
 int upload(void* dst, const void* src, size_t bytes)
 {
@@ -468,6 +478,16 @@ void mark_failed(fmd_batch* b, const char* what)
 /* Turns the device-side error word, and an earlier broken-off call, into an error code. */
 int check_device_errors(fmd_batch* b)
 {
+  if (!b->subs.empty())
+  { // a shell: its sub-batches' words; one that failed fails the whole batch
+    for (auto& sb : b->subs)
+      if (check_device_errors(sb.get()) != FMD_OK && !b->failed)
+      {
+        b->failed = true;
+        b->fail_msg = sb->fail_msg;
+      }
+    return b->failed ? fail(FMD_ERR_DEVICE, b->fail_msg) : FMD_OK;
+  }
   const unsigned e = b->h_err ? __atomic_load_n(&b->h_err[0], __ATOMIC_ACQUIRE) : 0u;
   if (e && !b->failed)
   {
@@ -486,6 +506,14 @@ int check_device_errors(fmd_batch* b)
  * cleared (atomically: a kernel setting the flag again at that moment is seen by the next query). */
 int take_lost_groups(fmd_batch* b)
 {
+  if (!b->subs.empty())
+  {
+    int rc = FMD_OK;
+    for (auto& sb : b->subs)
+      if (take_lost_groups(sb.get()) != FMD_OK)
+        rc = FMD_WARN_RDS_LOST;
+    return rc;
+  }
   // one exchange: a kernel that ORs the flag in between a load and a store would have its loss wiped
   if (!b->h_err || !__atomic_exchange_n(&b->h_err[1], 0u, __ATOMIC_ACQ_REL))
     return FMD_OK;
@@ -523,10 +551,20 @@ int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, un
                     unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
                     hipEvent_t ev_start, hipEvent_t ev_stop);
 
-void release_held_light(fmd_batch* b, hipEvent_t gate); // fmd_batch_process.inc.hpp
-
 int do_reset(fmd_batch* b)
 {
+  if (!b->subs.empty())
+  {
+    for (auto& sb : b->subs)
+      if (do_reset(sb.get()))
+        return -1;
+    for (auto& g : b->gdec)
+      if (g)
+        g->reset();
+    b->failed = false;
+    b->fail_msg.clear();
+    return 0;
+  }
   const size_t CP = b->CP;
   using namespace fmd;
   const ChannelState& s = b->st;
@@ -723,19 +761,41 @@ const char* fmd_stage_name(unsigned idx)
   return idx < ST_COUNT ? kStageNames[idx] : "";
 }
 
-int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* tuning_shifts,
-                     int device, const fmd_callbacks* cb, void* user, fmd_batch** out)
-{
-  if (!params || !out || n_channels == 0)
-    return fail(FMD_ERR_ARG, "fmd_batch_create: null argument or zero channels");
-  *out = nullptr;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(FMD_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
-  if (device < 0 || device >= ndev)
-    return fail(FMD_ERR_ARG, "fmd_batch_create: device ordinal out of range");
-  HIPCHK(hipSetDevice(device));
+} // extern "C"
 
+namespace
+{
+
+/* The internal streams of a batch: the FIR feeds the pipeline and is the bandwidth-bound kernel -- dispatch it
+ * first; the post chain has slack every call and goes last. */
+int create_streams(fmd_batch* b)
+{
+  int lo = 0, hi = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi)); // lo = least, hi = greatest priority
+  // (the two heavy chains side by side on a fifth stream: measured slower in rounds 1-3, removed.)  The
+  // fifth stream carries the post chain's two low-pass filters or the light part's audio half: see the stream
+  // layouts in process_device_impl
+  const int nstreams = 5;
+  // (the light chain's stream at the high priority too: measured twice, no difference; the heavy part's,
+  // which since round 4 is on the loop that closes the period: 279 100 against 279 200 MS/s; with the
+  // low-pass filters' as well: -1.6 %)
+  const int prio[5] = {hi, hi, lo, lo, lo};
+  hipStream_t st4[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (pick_independent_streams(nstreams, prio, st4, &b->streams_sharing) != 0)
+    return fail(FMD_ERR_DEVICE, "could not create the internal streams");
+  b->s_fir = st4[0];
+  b->s_ser = st4[1];
+  b->s_post = st4[2];
+  b->s_rds = st4[3];
+  b->s_lpf = st4[4];
+  return FMD_OK;
+}
+
+/* One batch with buffers and state of its own: what fmd_batch_create returns up to kSubBatchChannels channels, and
+ * every sub-batch of a larger one (shell != null: on the shell's streams). */
+int create_one(const fmd_params* params, unsigned n_channels, const int* tuning_shifts, int device,
+               const fmd_callbacks* cb, void* user, fmd_batch* shell, fmd_batch** out)
+{
   std::unique_ptr<fmd_batch> b(new fmd_batch);
   b->device = device;
   b->params.sample_rate_if = params->sample_rate_if;
@@ -746,11 +806,15 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   b->params.us_version = params->us_version != 0;
   b->params.table_size = params->table_size;
   b->params.if_filter_order = params->if_filter_order;
-  if (params->fir_reduction != FMD_FIR_SEQUENTIAL && params->fir_reduction != FMD_FIR_SHUFFLE_PARITY_WAIVED)
-    return fail(FMD_ERR_ARG, "fmd_batch_create: fir_reduction must be 0 (sequential, the parity mode) or "
+  if (params->fir_reduction != FMD_FIR_SEQUENTIAL && params->fir_reduction != FMD_FIR_SHUFFLE_PARITY_WAIVED &&
+      params->fir_reduction != FMD_FIR_FMA_PARITY_WAIVED)
+    return fail(FMD_ERR_ARG, "fmd_batch_create: fir_reduction must be 0 (sequential, the parity mode), "
+                             "FMD_FIR_FMA_PARITY_WAIVED (fused multiply-add in the reference's tap order) or "
                              "FMD_FIR_SHUFFLE_PARITY_WAIVED (shuffle-reduced: 1.2e-5 RMS from the reference, "
                              "outside the 1e-5 contract)");
-  b->params.fir_reduction = params->fir_reduction == FMD_FIR_SHUFFLE_PARITY_WAIVED ? 1 : 0;
+  b->params.fir_reduction = params->fir_reduction == FMD_FIR_SHUFFLE_PARITY_WAIVED ? 1
+                            : params->fir_reduction == FMD_FIR_FMA_PARITY_WAIVED   ? 2
+                                                                                   : 0;
   try
   {
     b->des = fmd::make_design(b->params);
@@ -887,7 +951,6 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   bad |= b->rpll.alloc(size_t(T_mf - 1 + b->Rmax) * CP);
   bad |= b->rmf.alloc(size_t(b->Rmax) * CP);
   bad |= b->tap_sync.alloc(size_t(b->Rmax) * CP);
-  bad |= b->heavy_flag.alloc(fmd_batch::NSLOT);
   bad |= b->rs[0].alloc(size_t(T_alp - 1 + b->Amax) * CP);
   bad |= b->rs[1].alloc(size_t(T_alp - 1 + b->Amax) * CP);
   bad |= b->alp[0].alloc(size_t(b->Amax) * CP);
@@ -982,39 +1045,28 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     return fail(FMD_ERR_DEVICE, "state reset failed");
 
   b->gdec.resize(C);
-  { // the FIR feeds the pipeline and is the bandwidth-bound kernel: dispatch it first; the
-    // post chain has slack every call and goes last
-    int lo = 0, hi = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi)); // lo = least, hi = greatest priority
-    // (the two heavy chains side by side on a fifth stream: measured slower in rounds 1-3, removed.)  The
-    // fifth stream carries the post chain's two low-pass filters: see lpf_late in process_device_impl
-    const int nstreams = 5;
-    // (the light chain's stream at the high priority too: measured twice, no difference; the heavy part's,
-    // which since round 4 is on the loop that closes the period: 279 100 against 279 200 MS/s; with the
-    // low-pass filters' as well: -1.6 %)
-    const int prio[5] = {hi, hi, lo, lo, lo};
-    hipStream_t st4[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (pick_independent_streams(nstreams, prio, st4, &b->streams_sharing) != 0)
-      return fail(FMD_ERR_DEVICE, "could not create the internal streams");
-    b->s_fir = st4[0];
-    b->s_ser = st4[1];
-    b->s_post = st4[2];
-    b->s_rds = st4[3];
-    b->s_lpf = st4[4];
-    // RDS chain and audio chain behind the serial stage are independent.  With more channels than
-    // the chip holds serial-stage workgroups (256 CUs x 64 channels) the batch is throughput-bound
-    // and they run side by side on two streams (+10 % at 24 576, +12 % at 32 768 channels); below
-    // that the extra concurrent kernels only stretch the latency-bound serial stage (-4 % at
-    // 8192), so they share one stream ("split_post" of fmd_batch_debug_set overrides).
-    // A batch of one or two wavefronts (the single decoder of cFmDecoder: RadioReceiver.cpp:515-538) is
-    // pure latency: its RDS chain (0.35 ms of lane-serial kernels) and its audio chain (0.19 ms) behind the
-    // serial stage run side by side as well -- 2.17 -> 1.9 ms per call of one channel.
-    b->split_post = b->CP > 16384 || b->CP <= 128;
-    // The serial stage takes whole CUs (one role wave per SIMD) while that costs at most a quarter of the chip (<= 8192
-    // channels = 64 CUs; +4.4 % at 8192 channels) and the batch is big enough for the bandwidth
-    // kernels to notice their neighbours at all ("serial_exclusive" of fmd_batch_debug_set overrides).
-    b->serial_exclusive = b->CP <= 8192 && b->CP >= 1024;
+  if (shell)
+  {
+    b->owns_streams = false;
+    b->s_fir = shell->s_fir;
+    b->s_ser = shell->s_ser;
+    b->s_post = shell->s_post;
+    b->s_rds = shell->s_rds;
+    b->s_lpf = shell->s_lpf;
+    b->streams_sharing = shell->streams_sharing;
   }
+  else if (int rc = create_streams(b.get()))
+    return rc;
+  // RDS chain and audio chain behind the serial stage are independent, but side by side their kernels only
+  // stretch the latency-bound serial stage (-4 % at 8192 channels), so they share one stream -- except in a batch
+  // of one or two wavefronts (the single decoder of cFmDecoder: RadioReceiver.cpp:515-538), which is pure
+  // latency: its RDS chain (0.35 ms of lane-serial kernels) and its audio chain (0.19 ms) run side by side,
+  // 2.17 -> 1.9 ms per call of one channel ("split_post" of fmd_batch_debug_set overrides).
+  b->split_post = b->CP <= 128;
+  // The serial stage takes whole CUs (one role wave per SIMD; at most 64 CUs = a quarter of the chip at
+  // kSubBatchChannels; +4.4 % there) where the batch is big enough for the bandwidth kernels to notice their
+  // neighbours at all ("serial_exclusive" of fmd_batch_debug_set overrides).
+  b->serial_exclusive = b->CP <= kSubBatchChannels && b->CP >= 1024;
   for (auto& row : b->cev)
     for (auto& e : row)
       HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1032,7 +1084,7 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
     if (rc != FMD_OK)
       return rc;
   }
-  if (b->streams_sharing > 0)
+  if (b->streams_sharing > 0 && !shell)
     // not an error: the batch works, its chains just queue behind each other where they were meant to overlap.
     // The text stays in fmd_last_error() (the call still returns FMD_OK); fmd_batch_streams_sharing_queue() has
     // the number.  HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the HOST sets the
@@ -1045,10 +1097,84 @@ int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* t
   return FMD_OK;
 }
 
+} // namespace
+
+extern "C" {
+
+int fmd_batch_create(const fmd_params* params, unsigned n_channels, const int* tuning_shifts,
+                     int device, const fmd_callbacks* cb, void* user, fmd_batch** out)
+{
+  if (!params || !out || n_channels == 0)
+    return fail(FMD_ERR_ARG, "fmd_batch_create: null argument or zero channels");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(FMD_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev)
+    return fail(FMD_ERR_ARG, "fmd_batch_create: device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  // (and no more channels than keep a sub-batch's row buffers below 4 GB -- create_one; only low decimations)
+  unsigned sub_cap = kSubBatchChannels;
+  {
+    const size_t Dd = std::max(1u, params->downsample);
+    const size_t mstride = ((FMD_MAX_BLOCK + Dd - 1) / Dd + 1 + 15) & ~size_t(15);
+    const size_t fit = ((size_t(1) << 32) - 8192) / (mstride * sizeof(float2)) / 128 * 128;
+    sub_cap = unsigned(std::max<size_t>(128, std::min<size_t>(sub_cap, fit)));
+  }
+  if (n_channels <= sub_cap)
+    return create_one(params, n_channels, tuning_shifts, device, cb, user, nullptr, out);
+
+  /* A shell over sub-batches (see fmd_batch::subs): equal sizes, multiples of 128 channels (a CU's worth of
+   * serial stage), so that every sub-batch call is the same load. */
+  std::unique_ptr<fmd_batch> b(new fmd_batch);
+  b->device = device;
+  if (int rc = create_streams(b.get()))
+    return rc;
+  const unsigned S = (n_channels + sub_cap - 1) / sub_cap;
+  const unsigned per = ((n_channels + S - 1) / S + 127u) & ~127u;
+  for (unsigned ch0 = 0; ch0 < n_channels; ch0 += per)
+  {
+    fmd_batch* sub = nullptr;
+    const unsigned n = std::min(per, n_channels - ch0);
+    // (callbacks: the shell runs the group decoders, with the caller's channel numbers)
+    if (int rc = create_one(params, n, tuning_shifts ? tuning_shifts + ch0 : nullptr, device, nullptr, nullptr,
+                            b.get(), &sub))
+      return rc;
+    sub->concurrency = 2; // the sub-batch calls of one call overlap; the shell orders the caller's stream (mode 1)
+    b->subs.emplace_back(sub);
+    b->sub_ch0.push_back(ch0);
+  }
+  b->sub_ch0.push_back(n_channels);
+  const fmd_batch* s0 = b->subs[0].get();
+  b->params = s0->params;
+  b->des = s0->des;
+  b->min_samples = s0->min_samples;
+  b->n_cus = s0->n_cus;
+  b->Mmax = s0->Mmax;
+  b->Mstride = s0->Mstride;
+  b->Amax = s0->Amax;
+  b->C = n_channels;
+  b->CP = (n_channels + 63u) & ~63u;
+  for (const auto& sb : b->subs)
+    b->shifts.insert(b->shifts.end(), sb->shifts.begin(), sb->shifts.end());
+  if (cb)
+    b->cb = *cb;
+  b->user = user;
+  b->gdec.resize(n_channels);
+  if (b->export_cursor.alloc(fmd_batch::kExportCursors))
+    return fail(FMD_ERR_DEVICE, "device allocation failed");
+  HIPCHK(hipDeviceSynchronize());
+  if (b->streams_sharing > 0)
+    (void)fail(FMD_OK, std::to_string(b->streams_sharing) +
+                           " of the batch's 5 internal streams share a hardware queue with another stream of this "
+                           "process: overlapped calls will be slower than measured (host: GPU_MAX_HW_QUEUES=8 "
+                           "before the HIP runtime initialises)");
+  *out = b.release();
+  return FMD_OK;
+}
+
 void fmd_batch_destroy(fmd_batch* b)
 {
-  if (b)
-    b->held_light.clear(); // (a light part that was never waited for goes with the batch)
   delete b;
 }
 
@@ -1057,7 +1183,6 @@ int fmd_batch_reset(fmd_batch* b)
   if (!b)
     return fail(FMD_ERR_ARG, "null batch");
   HIPCHK(hipSetDevice(b->device));
-  release_held_light(b, nullptr);
   HIPCHK(hipDeviceSynchronize());
   if (do_reset(b))
     return fail(FMD_ERR_DEVICE, "state reset failed");
@@ -1090,24 +1215,72 @@ unsigned fmd_batch_max_audio_floats(const fmd_batch* b, unsigned samples)
 
 } // extern "C"
 
-#include "fmd_batch_process.inc.hpp" // launch_if_stage*, launch_light, process_device_impl
+#include "fmd_batch_if.inc.hpp"      // launch_if_stage: the IF stage's kernel forms
+#include "fmd_batch_process.inc.hpp" // process_device_impl: one call on the batch's streams
 
 extern "C" {
+
+static int wait_impl(fmd_batch* b, int lag, void* stream_, bool take_lost);
+
+/* One call of any batch: a plain one directly; a shell's as one call of every sub-batch, in channel order, on the
+ * same streams (fmd_batch::subs). */
+static int process_any(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_channel_stride, unsigned samples,
+                       float* d_audio, size_t audio_channel_stride, unsigned* out_floats, void* stream)
+{
+  if (!b || b->subs.empty())
+    return process_device_impl(b, d_iq, fmt, iq_channel_stride, samples, d_audio, audio_channel_stride, out_floats,
+                               stream);
+  if (!d_iq || !d_audio)
+    return fail(FMD_ERR_ARG, "fmd_batch_process_device: null argument");
+  if (int rc = check_device_errors(b))
+    return rc;
+  const size_t esz = fmt == IQ_U8 ? 2 : 8; // bytes per IQ sample
+  unsigned nf = 0;
+  for (size_t k = 0; k < b->subs.size(); k++)
+  {
+    fmd_batch* sb = b->subs[k].get();
+    const unsigned ch0 = b->sub_ch0[k];
+    sb->sched_prev2 = b->vheavy[1];
+    const char* iq = static_cast<const char*>(d_iq) + size_t(ch0 / b->cpc) * iq_channel_stride * esz;
+    const int rc = process_device_impl(sb, iq, fmt, iq_channel_stride, samples,
+                                       d_audio + size_t(ch0) * audio_channel_stride, audio_channel_stride, &nf, stream);
+    if (rc != FMD_OK)
+    { // the first sub-batch refuses what every one of them would refuse (same geometry, same positions): nothing
+      // has been submitted.  Later: part of the call is on the device -- the batch is unusable until reset.
+      if (k > 0)
+      {
+        b->failed = true;
+        b->fail_msg = std::string("a call broke off between two sub-batches: ") + g_err;
+      }
+      return rc;
+    }
+    b->vheavy[1] = b->vheavy[0];
+    b->vheavy[0] = sb->cev[sb->call_index % fmd_batch::NSLOT][fmd_batch::EV_HEAVY];
+  }
+  b->call_index = b->subs[0]->call_index;
+  b->lastM = b->subs[0]->lastM;
+  b->lastA = b->subs[0]->lastA;
+  b->lastR = b->subs[0]->lastR;
+  if (out_floats)
+    *out_floats = nf;
+  if (b->concurrency == 1) // the caller's stream is ordered after every call (the sub-batches run in mode 2)
+    return wait_impl(b, 0, stream, false);
+  return FMD_OK;
+}
 
 int fmd_batch_process_device(fmd_batch* b, const float* d_iq, size_t iq_channel_stride,
                              unsigned samples, float* d_audio, size_t audio_channel_stride,
                              unsigned* out_floats, void* stream)
 {
-  return process_device_impl(b, d_iq, IQ_F32, iq_channel_stride, samples, d_audio, audio_channel_stride,
-                             out_floats, stream);
+  return process_any(b, d_iq, IQ_F32, iq_channel_stride, samples, d_audio, audio_channel_stride, out_floats, stream);
 }
 
 int fmd_batch_process_device_u8(fmd_batch* b, const uint8_t* d_iq_u8, size_t iq_channel_stride,
                                 unsigned samples, float* d_audio, size_t audio_channel_stride,
                                 unsigned* out_floats, void* stream)
 {
-  return process_device_impl(b, d_iq_u8, IQ_U8, iq_channel_stride, samples, d_audio,
-                             audio_channel_stride, out_floats, stream);
+  return process_any(b, d_iq_u8, IQ_U8, iq_channel_stride, samples, d_audio, audio_channel_stride, out_floats,
+                     stream);
 }
 
 /* slots whose call is at least `lag` calls old (lag 0 = every call submitted so far) */
@@ -1123,8 +1296,18 @@ static int wait_impl(fmd_batch* b, int lag, void* stream_, bool take_lost)
     return fail(FMD_ERR_ARG, "fmd_batch_wait: bad argument (lag must be 0..4)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
-  if (lag == 0)
-    release_held_light(b, nullptr); // the newest call's light part, where it was kept back for the next call
+  if (is_shell(b))
+  {
+    for (auto& sb : b->subs)
+    {
+      const int rc = wait_impl(sb.get(), lag, stream_, false);
+      if (rc < 0)
+        return check_device_errors(b); // (marks the shell failed too)
+    }
+    if (int rc = check_device_errors(b))
+      return rc;
+    return take_lost ? take_lost_groups(b) : FMD_OK;
+  }
   for (int q = 0; q < fmd_batch::NSLOT; q++)
     if (slot_eligible(b, q, lag))
     {
@@ -1158,6 +1341,8 @@ int fmd_batch_debug_set_spin_limit(fmd_batch* b, unsigned limit)
     return fail(FMD_ERR_ARG, "null batch");
   b->spin_limit = limit;
   b->st.spin_limit = limit;
+  for (auto& sb : b->subs)
+    fmd_batch_debug_set_spin_limit(sb.get(), limit);
   return FMD_OK;
 }
 
@@ -1183,8 +1368,14 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
   // Keys move work between streams and change kernel forms: nothing of an earlier call may still be
   // running when the next call takes the new route -- drain the device first.
   HIPCHK(hipSetDevice(b->device));
-  release_held_light(b, nullptr);
   HIPCHK(hipDeviceSynchronize());
+  if (is_shell(b))
+  { // every sub-batch takes the key
+    for (auto& sb : b->subs)
+      if (int rc = fmd_batch_debug_set(sb.get(), key, value))
+        return rc;
+    return FMD_OK;
+  }
   if (k == "resampler")
   {
     if (value > 0 && b->rsr_R == 0)
@@ -1193,52 +1384,22 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
   }
   else if (k == "fir_nt")
     b->dbg_fir_nt = std::max(0, value);
-  else if (k == "fir_b128")
-    b->dbg_fir_b128 = value != 0;
   else if (k == "serial_claim")
     b->dbg_serial_claim = value != 0;
   else if (k == "serial_exclusive")
     b->serial_exclusive = value != 0;
   else if (k == "split_post")
     b->split_post = value != 0;
-  else if (k == "post_delay_us")
-    b->dbg_post_delay_us = std::max(0, value);
   else if (k == "hb4")
     b->dbg_hb4 = value != 0;
   else if (k == "ring4")
     b->dbg_ring4 = value != 0;
   else if (k == "lpf_late")
     b->dbg_lpf_late = value < 0 ? -1 : std::min(value, 2);
-  else if (k == "level_in_fir")
-    b->dbg_level_in_fir = value != 0;
-  else if (k == "light_split")
-    b->dbg_light_split = value != 0;
-  else if (k == "light_hold") // 1 the whole light part, 2 its audio half only, 3 its RDS half only
-    b->dbg_light_hold = std::max(0, std::min(3, value));
-  else if (k == "fir_lds_pad")
-    b->dbg_fir_lds_pad = std::max(0, std::min(48 * 1024, value));
-  else if (k == "light_pack")
-    b->dbg_light_pack = std::max(1, std::min(4, value));
   else if (k == "stage_mask")
     b->dbg_stage_mask = value & 63;
-  else if (k == "rs_first")
-    b->dbg_rs_first = value != 0;
-  else if (k == "gate")
-    b->dbg_gate = value != 0;
-  else if (k == "lpf_prio")
-    b->dbg_lpf_prio = std::max(0, std::min(3, value));
-  else if (k == "alt_prio")
-    b->dbg_alt_prio = std::max(0, std::min(3, value));
-  else if (k == "fuse_alp")
-    b->dbg_fuse_alp = value != 0;
-  else if (k == "prof_dump")
-    b->dbg_prof_dump = value != 0;
   else if (k == "fir_ro")
     b->dbg_fir_ro = (value == 2 || value == 3) ? value : 1;
-  else if (k == "heavy_prio")
-    b->dbg_heavy_prio = std::max(0, std::min(33, value));
-  else if (k == "rsr_wgs")
-    b->dbg_rsr_wgs = std::max(0, value);
   else if (k == "serial_probe")
   { // per-workgroup timing of the serial stage's last 8 launches (fmd_batch_debug_serial_probe)
     HIPCHK(hipSetDevice(b->device));
@@ -1264,36 +1425,6 @@ int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)
     for (int f = std::max(0, std::min(2, value)); f < 3 && !ok; f++)
       ok = rsr_configure(b, f);
   }
-  else if (k == "cu_partition")
-  { /* Experiment: the serial stage and the light chain on `value` CUs of their own (CU-mask bit i is a
-     * CU of XCC i % 8: the first `value` bits are value / 8 CUs of every XCC), IF FIR and the heavy
-     * chain on all the others -- nothing of the light chain then holds LDS where the ring resampler's
-     * whole-CU workgroups go.  Replaces the four internal streams; only while no call is in flight. */
-    HIPCHK(hipSetDevice(b->device));
-    HIPCHK(hipDeviceSynchronize());
-    if (value <= 0 || value >= b->n_cus || value % 8)
-      return fail(FMD_ERR_ARG, "cu_partition: a multiple of 8 below the CU count");
-    const int words = (b->n_cus + 31) / 32;
-    std::vector<uint32_t> ma(size_t(words), 0u), mb(size_t(words), 0u);
-    for (int i = 0; i < b->n_cus; i++)
-      (i < value ? ma : mb)[size_t(i / 32)] |= 1u << (i % 32);
-    hipStream_t ns[4] = {nullptr, nullptr, nullptr, nullptr};
-    const uint32_t* masks[4] = {mb.data(), ma.data(), mb.data(), ma.data()}; // fir, serial, heavy, light
-    for (int i = 0; i < 4; i++)
-      HIPCHK(hipExtStreamCreateWithCUMask(&ns[i], uint32_t(words), masks[i]));
-    (void)hipStreamDestroy(b->s_fir);
-    (void)hipStreamDestroy(b->s_ser);
-    (void)hipStreamDestroy(b->s_post);
-    (void)hipStreamDestroy(b->s_rds);
-    b->s_fir = ns[0];
-    b->s_ser = ns[1];
-    b->s_post = ns[2];
-    b->s_rds = ns[3];
-  }
-  else if (k == "rsr_pace") // k_resample_ring's tap warmer: 64-cycle sleeps per batch
-    b->rsr_pace = unsigned(std::max(0, value));
-  else if (k == "rsr_exp") // timing experiments of k_resample_ring (results are wrong with them)
-    b->rsr_exp = unsigned(value);
   else
     return fail(FMD_ERR_ARG, "fmd_batch_debug_set: unknown key '" + k + "'");
   return FMD_OK;
@@ -1311,10 +1442,16 @@ int fmd_batch_set_channels_per_capture(fmd_batch* b, unsigned channels_per_captu
   const unsigned k = channels_per_capture ? channels_per_capture : 1u;
   if (b->C % k)
     return fail(FMD_ERR_ARG, "fmd_batch_set_channels_per_capture: the channel count is not a multiple of it");
+  for (size_t i = 0; i < b->subs.size(); i++) // a capture's channels must not straddle two sub-batches
+    if (b->sub_ch0[i] % k || b->subs[i]->C % k)
+      return fail(FMD_ERR_ARG, "fmd_batch_set_channels_per_capture: with " + std::to_string(b->C) +
+                                   " channels the batch runs as sub-batches of " + std::to_string(b->subs[0]->C) +
+                                   ", which is not a multiple of it");
   HIPCHK(hipSetDevice(b->device));
-  release_held_light(b, nullptr);
   HIPCHK(hipDeviceSynchronize());
   b->cpc = k;
+  for (auto& sb : b->subs)
+    sb->cpc = k;
   return FMD_OK;
 }
 
@@ -1323,9 +1460,10 @@ int fmd_batch_set_concurrency(fmd_batch* b, int mode)
   if (!b || mode < 0 || mode > 2)
     return fail(FMD_ERR_ARG, "fmd_batch_set_concurrency: mode must be 0, 1 or 2");
   HIPCHK(hipSetDevice(b->device));
-  release_held_light(b, nullptr);
   HIPCHK(hipDeviceSynchronize());
   b->concurrency = mode;
+  for (auto& sb : b->subs) // (their calls overlap inside one call of the shell; mode 1 is the shell's to keep)
+    sb->concurrency = mode == 0 ? 0 : 2;
   return FMD_OK;
 }
 
@@ -1335,6 +1473,65 @@ static bool slot_to_drain(const fmd_batch* b, int q, int lag)
   return slot_eligible(b, q, lag) && b->drained_call[q] != b->slot_call[q];
 }
 
+/* Draining the RDS queues of one batch with buffers of its own, in the three steps between which the caller
+ * synchronises the stream once for ALL the batches it drains (a shell: its sub-batches). */
+struct QueueDrain
+{
+  fmd_batch* b = nullptr;
+  unsigned ch0 = 0; // what the caller adds to the records' channel numbers
+  int todo[fmd_batch::NSLOT] = {}, ntodo = 0;
+  unsigned cnt[fmd_batch::NSLOT] = {};
+  size_t total = 0;
+};
+
+static int drain_counts(QueueDrain& d, int lag, hipStream_t stream)
+{
+  fmd_batch* b = d.b;
+  for (int q = 0; q < fmd_batch::NSLOT; q++)
+    if (slot_to_drain(b, q, lag)) // never used / already drained / its call may still be appending
+    {
+      HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_RDS], 0));
+      d.todo[d.ntodo++] = q;
+    }
+  if (d.ntodo)
+    HIPCHK(hipMemcpyAsync(b->h_counts, b->queue_counts.p, fmd_batch::NSLOT * sizeof(unsigned), hipMemcpyDeviceToHost,
+                          stream));
+  return FMD_OK;
+}
+
+static int drain_records(QueueDrain& d, hipStream_t stream)
+{ // (the counts have arrived)
+  fmd_batch* b = d.b;
+  for (int i = 0; i < d.ntodo; i++)
+  {
+    d.cnt[i] = std::min(b->h_counts[d.todo[i]], b->queue_cap); // overflow: the oldest queue_cap groups are kept
+    d.total += d.cnt[i];
+  }
+  if (d.total > b->h_recs_cap)
+  {
+    if (b->h_recs)
+      (void)hipHostFree(b->h_recs);
+    b->h_recs = nullptr;
+    b->h_recs_cap = 0;
+    const size_t want = std::max<size_t>(d.total, size_t(2) * b->C + 1024);
+    if (hipHostMalloc(reinterpret_cast<void**>(&b->h_recs), want * sizeof(fmd::RdsGroupRec), hipHostMallocDefault) !=
+        hipSuccess)
+      return fail(FMD_ERR_DEVICE, "fmd_batch_collect_rds: page-locked staging allocation failed");
+    b->h_recs_cap = want;
+  }
+  size_t at = 0;
+  for (int i = 0; i < d.ntodo; i++)
+    if (d.cnt[i])
+    {
+      const int q = d.todo[i];
+      HIPCHK(hipMemcpyAsync(b->h_recs + at, b->queue[q].p, size_t(d.cnt[i]) * sizeof(fmd::RdsGroupRec),
+                            hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipMemsetAsync(b->qcount(q), 0, sizeof(unsigned), stream));
+      at += d.cnt[i];
+    }
+  return FMD_OK;
+}
+
 int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap, int run_group_decoder,
                                  int lag, void* stream_)
 {
@@ -1342,60 +1539,43 @@ int fmd_batch_collect_rds_lagged(fmd_batch* b, fmd_rds_group* out, unsigned cap,
     return fail(FMD_ERR_ARG, "fmd_batch_collect_rds: bad argument (lag must be 0..4)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(b->device));
-  if (lag == 0)
-    release_held_light(b, nullptr);
-  /* Two synchronisations whatever the number of queues: all counts in one copy, then the records of
-   * the non-empty queues back to back.  Page-locked destinations: the copies are DMA transfers, not
-   * staging kernels that would queue up behind the decoder's own. */
-  int todo[fmd_batch::NSLOT], ntodo = 0;
-  for (int q = 0; q < fmd_batch::NSLOT; q++)
-    if (slot_to_drain(b, q, lag)) // never used / already drained / its call may still be appending
-    {
-      HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_RDS], 0));
-      todo[ntodo++] = q;
-    }
-  std::vector<fmd::RdsGroupRec> recs;
-  if (ntodo)
+  /* Two synchronisations whatever the number of queues (and of sub-batches): all counts in one copy per batch,
+   * then the records of the non-empty queues back to back.  Page-locked destinations: the copies are DMA
+   * transfers, not staging kernels that would queue up behind the decoder's own. */
+  std::vector<QueueDrain> drains(is_shell(b) ? b->subs.size() : 1);
+  for (size_t k = 0; k < drains.size(); k++)
   {
-    HIPCHK(hipMemcpyAsync(b->h_counts, b->queue_counts.p, fmd_batch::NSLOT * sizeof(unsigned),
-                          hipMemcpyDeviceToHost, stream));
+    drains[k].b = is_shell(b) ? b->subs[k].get() : b;
+    drains[k].ch0 = is_shell(b) ? b->sub_ch0[k] : 0u;
+  }
+  bool any = false, any_recs = false;
+  for (auto& d : drains)
+  {
+    if (int rc = drain_counts(d, lag, stream))
+      return rc;
+    any = any || d.ntodo > 0;
+  }
+  std::vector<fmd::RdsGroupRec> recs;
+  if (any)
+  {
     HIPCHK(hipStreamSynchronize(stream));
-    size_t total = 0;
-    unsigned cnt[fmd_batch::NSLOT];
-    for (int i = 0; i < ntodo; i++)
+    for (auto& d : drains)
     {
-      cnt[i] = std::min(b->h_counts[todo[i]], b->queue_cap); // overflow: the oldest queue_cap groups are kept
-      total += cnt[i];
+      if (int rc = drain_records(d, stream))
+        return rc;
+      any_recs = any_recs || d.total > 0;
     }
-    if (total > b->h_recs_cap)
-    {
-      if (b->h_recs)
-        (void)hipHostFree(b->h_recs);
-      b->h_recs = nullptr;
-      b->h_recs_cap = 0;
-      const size_t want = std::max<size_t>(total, size_t(2) * b->C + 1024);
-      if (hipHostMalloc(reinterpret_cast<void**>(&b->h_recs), want * sizeof(fmd::RdsGroupRec),
-                        hipHostMallocDefault) != hipSuccess)
-        return fail(FMD_ERR_DEVICE, "fmd_batch_collect_rds: page-locked staging allocation failed");
-      b->h_recs_cap = want;
-    }
-    size_t at = 0;
-    for (int i = 0; i < ntodo; i++)
-    {
-      const int q = todo[i];
-      if (cnt[i])
-      {
-        HIPCHK(hipMemcpyAsync(b->h_recs + at, b->queue[q].p, size_t(cnt[i]) * sizeof(fmd::RdsGroupRec),
-                              hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemsetAsync(b->qcount(q), 0, sizeof(unsigned), stream));
-        at += cnt[i];
-      }
-    }
-    if (total)
+    if (any_recs)
       HIPCHK(hipStreamSynchronize(stream));
-    for (int i = 0; i < ntodo; i++)
-      b->drained_call[todo[i]] = b->slot_call[todo[i]];
-    recs.assign(b->h_recs, b->h_recs + total);
+    for (auto& d : drains)
+    {
+      for (int i = 0; i < d.ntodo; i++)
+        d.b->drained_call[d.todo[i]] = d.b->slot_call[d.todo[i]];
+      const size_t at = recs.size();
+      recs.insert(recs.end(), d.b->h_recs, d.b->h_recs + d.total);
+      for (size_t i = at; i < recs.size(); i++)
+        recs[i].channel += d.ch0;
+    }
   }
   if (int rc = check_device_errors(b)) // the stream was synchronised above: covers the drained calls
     return rc;
@@ -1434,18 +1614,10 @@ int fmd_batch_collect_rds(fmd_batch* b, fmd_rds_group* out, unsigned cap, int ru
   return fmd_batch_collect_rds_lagged(b, out, cap, run_group_decoder, 0, stream_);
 }
 
-int fmd_batch_export_rds_device(fmd_batch* b, int32_t* d_records, unsigned cap, unsigned channel_offset,
-                                int lag, void* stream_)
+/* The queues of one batch with buffers of its own, appended to the caller's record buffer at *cursor. */
+static int export_queues(fmd_batch* b, int32_t* d_records, unsigned cap, unsigned channel_offset, int lag,
+                         hipStream_t stream, unsigned* cursor)
 {
-  if (!b || !d_records || cap == 0 || lag < 0 || lag > 4)
-    return fail(FMD_ERR_ARG, "fmd_batch_export_rds_device: bad argument (lag must be 0..4)");
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  HIPCHK(hipSetDevice(b->device));
-  if (lag == 0)
-    release_held_light(b, nullptr);
-  HIPCHK(hipMemsetAsync(d_records, 0, size_t(cap) * 4 * sizeof(int32_t), stream));
-  unsigned* const cursor = b->export_cursor.p + (b->export_seq++ % fmd_batch::kExportCursors);
-  HIPCHK(hipMemsetAsync(cursor, 0, sizeof(unsigned), stream));
   for (int q = 0; q < fmd_batch::NSLOT; q++)
   {
     if (!slot_to_drain(b, q, lag))
@@ -1457,6 +1629,27 @@ int fmd_batch_export_rds_device(fmd_batch* b, int32_t* d_records, unsigned cap, 
     b->drained_pending[q] = true;
     b->drained_call[q] = b->slot_call[q];
   }
+  return FMD_OK;
+}
+
+int fmd_batch_export_rds_device(fmd_batch* b, int32_t* d_records, unsigned cap, unsigned channel_offset,
+                                int lag, void* stream_)
+{
+  if (!b || !d_records || cap == 0 || lag < 0 || lag > 4)
+    return fail(FMD_ERR_ARG, "fmd_batch_export_rds_device: bad argument (lag must be 0..4)");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipMemsetAsync(d_records, 0, size_t(cap) * 4 * sizeof(int32_t), stream));
+  unsigned* const cursor = b->export_cursor.p + (b->export_seq++ % fmd_batch::kExportCursors);
+  HIPCHK(hipMemsetAsync(cursor, 0, sizeof(unsigned), stream));
+  if (is_shell(b))
+  {
+    for (size_t k = 0; k < b->subs.size(); k++)
+      if (int rc = export_queues(b->subs[k].get(), d_records, cap, channel_offset + b->sub_ch0[k], lag, stream, cursor))
+        return rc;
+  }
+  else if (int rc = export_queues(b, d_records, cap, channel_offset, lag, stream, cursor))
+    return rc;
   HIPCHK(hipGetLastError());
   if (int rc = check_device_errors(b))
     return rc;
@@ -1503,8 +1696,7 @@ static int process_host_impl(fmd_batch* b, const void* iq, IqFormat fmt, size_t 
   b->host_ms[0] += ms_since(tp);
   tp = clk::now();
   unsigned nf = 0;
-  int rc = process_device_impl(b, b->h_iq.p, fmt, dev_iq_stride, samples, b->h_audio.p, a_stride, &nf,
-                               nullptr);
+  int rc = process_any(b, b->h_iq.p, fmt, dev_iq_stride, samples, b->h_audio.p, a_stride, &nf, nullptr);
   if (rc != FMD_OK)
     return rc;
   if (C > 1 && nf > audio_channel_stride)
@@ -1552,8 +1744,9 @@ int fmd_batch_get_status(fmd_batch* b, unsigned channel, fmd_status* stt)
 {
   if (!b || !stt || channel >= b->C)
     return fail(FMD_ERR_ARG, "fmd_batch_get_status: bad argument");
-  unsigned w[fmd::HS_WORDS];
-  if (!host_status_read(b, channel, w))
+  unsigned w[fmd::HS_WORDS], lc = 0;
+  const fmd_batch* ob = owner_of(b, channel, &lc); // (a shell: the sub-batch's snapshot)
+  if (!host_status_read(ob, lc, w))
     return fail(FMD_ERR_DEVICE, "fmd_batch_get_status: the status snapshot is being written and never completes");
   auto f = [&](int i) {
     float v;
@@ -1575,8 +1768,9 @@ int fmd_batch_get_audio_level(fmd_batch* b, unsigned channel, fmd_audio_level* o
 {
   if (!b || !out || channel >= b->C)
     return fail(FMD_ERR_ARG, "fmd_batch_get_audio_level: bad argument");
-  unsigned w[fmd::HS_WORDS];
-  if (!host_status_read(b, channel, w))
+  unsigned w[fmd::HS_WORDS], lc = 0;
+  const fmd_batch* ob = owner_of(b, channel, &lc); // (a shell: the sub-batch's snapshot)
+  if (!host_status_read(ob, lc, w))
     return fail(FMD_ERR_DEVICE, "fmd_batch_get_audio_level: the status snapshot never completes");
   memcpy(&out->mean, &w[fmd::HS_AUDIO_MEAN], 4);
   memcpy(&out->rms, &w[fmd::HS_AUDIO_RMS], 4);
@@ -1588,8 +1782,9 @@ int fmd_batch_status_call_index(fmd_batch* b, unsigned channel, uint32_t* call_i
 {
   if (!b || !call_index || channel >= b->C)
     return fail(FMD_ERR_ARG, "fmd_batch_status_call_index: bad argument");
-  unsigned w[fmd::HS_WORDS];
-  if (!host_status_read(b, channel, w))
+  unsigned w[fmd::HS_WORDS], lc = 0;
+  const fmd_batch* ob = owner_of(b, channel, &lc); // (a shell: the sub-batch's snapshot)
+  if (!host_status_read(ob, lc, w))
     return fail(FMD_ERR_DEVICE, "fmd_batch_status_call_index: the status snapshot never completes");
   *call_index = (w[fmd::HS_SEQ_END] & 0x80000000u) ? 0u : w[fmd::HS_SEQ_END];
   return FMD_OK;
@@ -1599,6 +1794,12 @@ int fmd_batch_get_tap(fmd_batch* b, int tap, unsigned channel, float* out, unsig
 {
   if (!b || !out || channel >= b->C)
     return fail(FMD_ERR_ARG, "fmd_batch_get_tap: bad argument");
+  if (is_shell(b))
+  {
+    unsigned lc = 0;
+    fmd_batch* ob = owner_of(b, channel, &lc);
+    return fmd_batch_get_tap(ob, tap, lc, out, cap_floats);
+  }
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
   const size_t CP = b->CP;
@@ -1720,6 +1921,8 @@ int fmd_batch_set_debug_taps(fmd_batch* b, int enable)
   if (!b)
     return fail(FMD_ERR_ARG, "null batch");
   b->write_taps = enable != 0;
+  for (auto& sb : b->subs)
+    sb->write_taps = b->write_taps;
   return FMD_OK;
 }
 
@@ -1734,6 +1937,11 @@ int fmd_batch_set_profiling(fmd_batch* b, int level)
   HIPCHK(hipDeviceSynchronize());
   b->profiling = level < 0 ? 0 : (level > 2 ? 2 : level);
   b->prof_calls = 0; // restart the averaging window
+  for (auto& sb : b->subs)
+  {
+    sb->profiling = b->profiling;
+    sb->prof_calls = 0;
+  }
   return FMD_OK;
 }
 
@@ -1741,23 +1949,28 @@ int fmd_batch_get_stage_ms(fmd_batch* b, float* out, unsigned cap)
 {
   if (!b || !out)
     return fail(FMD_ERR_ARG, "bad argument");
+  if (is_shell(b))
+  { // per call of the shell: the sub-batch calls' times added up (one launch of every stage per sub-batch)
+    std::vector<float> sum(ST_COUNT, 0.0f), one(ST_COUNT);
+    int calls = 0;
+    for (auto& sb : b->subs)
+    {
+      const int n = fmd_batch_get_stage_ms(sb.get(), one.data(), ST_COUNT);
+      if (n < 0)
+        return n;
+      calls = n;
+      for (int i = 0; i < ST_COUNT; i++)
+        sum[size_t(i)] = (one[size_t(i)] < 0 || sum[size_t(i)] < 0) ? -1.0f : sum[size_t(i)] + one[size_t(i)];
+    }
+    for (unsigned i = 0; i < cap && i < unsigned(ST_COUNT); i++)
+      out[i] = sum[i];
+    return calls;
+  }
   if (!b->profiling || b->prof_calls == 0)
     return fail(FMD_ERR_STATE, "profiling not enabled or no call made since it was enabled");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
   const int nst = b->profiling >= 2 ? ST_COUNT : 1;
-  if (b->dbg_prof_dump) // dev aid: the IF FIR's duration call by call
-  {
-    fprintf(stderr, "prof_dump: if_fir ms per call:");
-    for (unsigned c = 0; c < b->prof_calls; c++)
-    {
-      float ms = 0;
-      hipEvent_t* es = &b->ev[size_t(c) * (ST_COUNT + 1)];
-      if (hipEventElapsedTime(&ms, es[0], es[1]) == hipSuccess)
-        fprintf(stderr, " %.3f", ms);
-    }
-    fprintf(stderr, "\n");
-  }
   for (int i = 0; i < ST_COUNT; i++)
   {
     double sum = 0;
@@ -1884,6 +2097,8 @@ int fmd_batch_debug_timeline(fmd_batch* b, float* out, unsigned cap_calls)
 {
   if (!b || !out)
     return fail(FMD_ERR_ARG, "fmd_batch_debug_timeline: null argument");
+  if (is_shell(b)) // (the first sub-batch's calls: every S-th of the common sequence)
+    return fmd_batch_debug_timeline(b->subs[0].get(), out, cap_calls);
   if (b->profiling != 1 || b->prof_calls == 0 || !b->serial_exclusive || b->concurrency != 2)
     return 0;
   HIPCHK(hipSetDevice(b->device));
@@ -1909,6 +2124,8 @@ int fmd_batch_debug_serial_probe(fmd_batch* b, long long* out, unsigned cap_work
 {
   if (!b || !out)
     return fail(FMD_ERR_ARG, "fmd_batch_debug_serial_probe: null argument");
+  if (is_shell(b))
+    return fmd_batch_debug_serial_probe(b->subs[0].get(), out, cap_workgroups);
   if (!b->serial_probe.p)
     return 0;
   const unsigned wgs = std::min<unsigned>(cap_workgroups, unsigned(b->serial_probe.n / 3));

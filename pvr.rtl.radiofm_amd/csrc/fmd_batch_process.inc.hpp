@@ -1,202 +1,76 @@
 /*
  * fmd_batch_process.inc.hpp -- one call of a batch: the position plan the host replays (DownConvert.cpp:112-132,
- * 203-232; FirFilter.cpp:346), the choice of kernel forms, and the launches of all stages on the batch's internal
- * streams with the events that tie them (process_device_impl); the IF stage's launch helpers and the light part's.
- * Included by fmd_batch.hip (one translation unit: it uses that file's fmd_batch struct and helpers).
+ * 203-232; FirFilter.cpp:346), the choice of kernel forms behind the IF stage, and the launches of all stages on the
+ * batch's internal streams with the events that tie them (process_device_impl); the light part's launch helpers.
+ * Included by fmd_batch.hip behind fmd_batch_if.inc.hpp (one translation unit: it uses that file's fmd_batch
+ * struct and helpers).
  */
 namespace
 {
 
-/* The IF FIR kernel is instantiated for a few load depths (two-sample loads in flight per lane);
- * the launch takes the smallest one that stages a tile's window in a single round trip. */
-template <class IN>
-using FirFn = void (*)(const typename IN::elem*, size_t, unsigned, const float2*, float2*, const float2*,
-                       unsigned, unsigned, const float*, unsigned, unsigned, unsigned, unsigned, float2*,
-                       unsigned, unsigned, unsigned, unsigned);
-
-template <class IN>
-using FirFn3 = void (*)(const typename IN::elem*, size_t, unsigned, const float2*, float2*, const float2*,
-                        unsigned, unsigned, const float*, unsigned, unsigned, unsigned, unsigned, float2*,
-                        unsigned, unsigned, unsigned, unsigned, float*);
-
-template <class IN, int TILE, int E, bool RB128 = false>
-int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
-                      unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
-                      hipEvent_t ev_start, hipEvent_t ev_stop)
+/* The kernels' constant blocks, from the design (constructor maths: FmDecode.cpp:237-314, RDSProcess.cpp:60-90). */
+fmd::DemodConsts demod_consts(const fmd::Design& d)
 {
-  const fmd::Design& d = b->des;
-  const unsigned C = b->C, D = d.D, T = d.table_size;
-  const unsigned ntiles = (M + TILE - 1) / TILE;
-  // 2^E regions of ((TILE-1)*D + order + slack) >> E slots each (see k_if_fir)
-  // (+ 1: the regions of the 16-byte-read form are rounded up to an even size)
-  const size_t region = ((size_t(TILE - 1) * D + d.if_order + 2u * (1u << E) + 2u) >> E) + 2u;
-  // long filter: one workgroup per CU, hand-scheduled tap loop for every window layout (k_if_fir
-  // LONGASM: plain window read 16 bytes at a time for D = 2 * odd, 8 bytes at a time for odd D, and
-  // the two- and four-region windows)
-  const bool longasm = TILE == 256 && d.if_order >= 512;
-  // + 32 slots in front of the window for the tap loops' dummy last prefetch (k_if_fir WIN_PAD)
-  const size_t lds = (region << E) * sizeof(float2) + (longasm ? 32 * sizeof(float2) : 0);
-  if (lds > 160 * 1024)
-    return fail(FMD_ERR_ARG, "IF filter window does not fit in LDS");
-  if (b->if_dry_run) // fmd_batch_create: only whether this geometry can be launched at all
-    return FMD_OK;
-  // fast staging: the tuner table is a power of two that divides a tile's sample span, so a lane
-  // needs the same two table entries for every load (all reference configurations: T = 64)
-  const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
-  // loads per lane needed to stage one tile in a single round trip (two samples per load)
-  const unsigned rounds = unsigned(((size_t(TILE - 1) * D + d.if_order + 2) / 2 + TILE - 1) / TILE);
-  FirFn<IN> kfn = &fmd::k_if_fir<IN, TILE, 1, false, E>;
-  if (pow2)
-    kfn = rounds <= 2 ? &fmd::k_if_fir<IN, TILE, 2, true, E>
-        : rounds <= 4 ? &fmd::k_if_fir<IN, TILE, 4, true, E>
-        : rounds <= 6 ? &fmd::k_if_fir<IN, TILE, 6, true, E>
-        : rounds <= 7 ? &fmd::k_if_fir<IN, TILE, 7, true, E>
-                      : &fmd::k_if_fir<IN, TILE, 8, true, E>;
-  if (pow2 && longasm)
-    kfn = &fmd::k_if_fir<IN, TILE, 8, true, E, TILE == 256, false, TILE == 256 && RB128 && (E >= 1)>;
-  // opt-in shuffle-reduced tap sum (not bit-exact): headline window layout only
-  const bool shfl = b->params.fir_reduction == 1 && TILE == 64 && E == 0 && pow2 && rounds <= 8;
-  if (shfl)
-    kfn = &fmd::k_if_fir<IN, TILE, 8, true, E, false, TILE == 64 && E == 0>;
-  // several tiles per workgroup with the next tile's loads in flight during the tap loop
-  // (k_if_fir_mt): the headline geometry only.  Two tiles: 0.94-0.95 ms inside the pipeline against
-  // 0.98-1.00 (one tile per workgroup) on the same box, the same alone; 3, 4, 8 tiles: no better
-  // than one ("fir_nt" of fmd_batch_debug_set overrides, 1 = k_if_fir).
-  // With the chip to itself (calls not overlapped) one tile per workgroup is the faster form (0.77
-  // against 0.83 ms), and in the throughput-bound regime (> 8192 channels) the faster FIR only
-  // takes from the kernels beside it (32 768 channels: 228 against 236 GS/s): two tiles only beside
-  // the whole-CU serial stage.
-  const int fir_nt = b->dbg_fir_nt ? b->dbg_fir_nt : (b->concurrency == 2 && b->serial_exclusive ? 2 : 1);
-  unsigned nblocks = C * ntiles, ntiles_l = ntiles;
-  size_t lds_l = lds;
-  FirFn3<IN> kfn3 = nullptr; // k_if_fir_mt3 (one more argument: where the level meter goes)
-  bool level_in_fir = false;
-  if (TILE == 64 && E == 0 && pow2 && rounds == 7 && fir_nt > 1 && !shfl)
-  {
-    const unsigned nt = fir_nt >= 8 ? 8u : fir_nt >= 4 ? 4u : fir_nt == 3 ? 3u : 2u;
-    kfn = nt == 8 ? &fmd::k_if_fir_mt<IN, 7, 8>
-        : nt == 4 ? &fmd::k_if_fir_mt<IN, 7, 4>
-        : nt == 3 ? &fmd::k_if_fir_mt<IN, 7, 3>
-                  : &fmd::k_if_fir_mt<IN, 7, 2>;
-    nblocks = C * ((ntiles + nt - 1) / nt);
-    // two (three) outputs per lane (k_if_fir_mt3): every sample is read from LDS once for up to two (three) taps
-    const unsigned RO = unsigned(b->dbg_fir_ro), T3 = 64 * RO;
-    const unsigned rounds3 = unsigned(((size_t(T3 - 1) * D + d.if_order + 2) / 2 + 63) / 64);
-    if (RO > 1 && nt == 2 && d.if_order == 88 && D == 11 && (size_t(T3) * D) % T == 0 &&
-        rounds3 <= (RO == 3 ? 18u : 12u))
-    {
-      kfn3 = RO == 3 ? &fmd::k_if_fir_mt3<IN, 18, 2, 3> : &fmd::k_if_fir_mt3<IN, 12, 2, 2>;
-      ntiles_l = (M + T3 - 1) / T3;
-      // ("fir_lds_pad": experiment -- LDS the workgroup claims and does not use: fewer waves per CU)
-      lds_l = (size_t(T3 - 1) * D + d.if_order + 4) * sizeof(float2) + size_t(b->dbg_fir_lds_pad);
-      nblocks = C * ((ntiles_l + 1) / 2);
-      // the level meter inside the first tile's workgroup: its (N + 63) / 64 samples have to lie in that tile's
-      // window, which ends in front of the tile's last output position pos + (nout - 1) D
-      const unsigned nout0 = std::min(T3, M);
-      level_in_fir = b->dbg_level_in_fir != 0 && (N + 63u) / 64u <= pos + (nout0 - 1u) * D;
-    }
-  }
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const typename IN::elem* x = static_cast<const typename IN::elem*>(d_iq);
-  mark(0);
-  // profiled calls: the two events take the kernel's own start and stop (hipExtLaunchKernelGGL),
-  // not the stream's state around it (a recorded event also counts the dispatch gap behind it)
-  float* const lvl = level_in_fir ? b->st.F(fmd::F_IF_LEVEL) : static_cast<float*>(nullptr);
-  if (kfn3 && ev_start)
-    hipExtLaunchKernelGGL(kfn3, dim3(nblocks), dim3(TILE), unsigned(lds_l), sF, ev_start, ev_stop, 0u, x,
-                          iq_channel_stride, N, (const float2*)b->hist[b->hist_sel].p,
-                          (float2*)b->hist[b->hist_sel ^ 1].p, (const float2*)b->lut.p, T, b->lut_idx,
-                          (const float*)b->if_coeff.p, d.if_order, D, pos, M, (float2*)b->demod[q].p,
-                          b->Mstride, ntiles_l, (C % 8 == 0) ? 1u : 0u, b->cpc, lvl);
-  else if (kfn3)
-    hipLaunchKernelGGL(kfn3, dim3(nblocks), dim3(TILE), lds_l, sF, x, iq_channel_stride, N,
-                       b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, T, b->lut_idx,
-                       b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles_l,
-                       (C % 8 == 0) ? 1u : 0u, b->cpc, lvl);
-  else if (ev_start)
-    hipExtLaunchKernelGGL(kfn, dim3(nblocks), dim3(TILE), unsigned(lds_l), sF, ev_start, ev_stop, 0u, x,
-                          iq_channel_stride, N, (const float2*)b->hist[b->hist_sel].p,
-                          (float2*)b->hist[b->hist_sel ^ 1].p, (const float2*)b->lut.p, T, b->lut_idx,
-                          (const float*)b->if_coeff.p, d.if_order, D, pos, M, (float2*)b->demod[q].p,
-                          b->Mstride, ntiles_l, (C % 8 == 0) ? 1u : 0u, b->cpc);
+  fmd::DemodConsts k{};
+  k.pll_alpha = d.pll_alpha;
+  k.pll_beta = d.pll_beta;
+  k.nco_hl = d.nco_hl;
+  k.nco_ll = d.nco_ll;
+  k.demod_gain = d.demod_gain;
+  k.p_minfreq = d.p_minfreq;
+  k.p_maxfreq = d.p_maxfreq;
+  k.p_b0 = d.p_b0;
+  k.p_a1 = d.p_a1;
+  k.p_a2 = d.p_a2;
+  k.p_lf_b0 = d.p_lf_b0;
+  k.p_lf_b1 = d.p_lf_b1;
+  k.p_minsignal = d.p_minsignal;
+  k.p_lock_delay = d.p_lock_delay;
+  k.osc_cos = d.rds_osc_cos;
+  k.osc_sin = d.rds_osc_sin;
+  return k;
+}
+
+fmd::RdsConsts rds_consts(const fmd::Design& d)
+{
+  fmd::RdsConsts k{};
+  k.pll_alpha = d.rds_pll_alpha;
+  k.pll_beta = d.rds_pll_beta;
+  k.nco_hl = d.rds_nco_hl;
+  k.nco_ll = d.rds_nco_ll;
+  k.bs_b0 = d.bitsync.b0;
+  k.bs_b1 = d.bitsync.b1;
+  k.bs_b2 = d.bitsync.b2;
+  k.bs_a1 = d.bitsync.a1;
+  k.bs_a2 = d.bitsync.a2;
+  k.mf_taps = int(d.rds_mf_taps.size());
+  return k;
+}
+
+fmd::AudioConsts audio_consts(const fmd::Design& d)
+{
+  fmd::AudioConsts k{};
+  k.de_alpha = d.de_alpha;
+  k.n_b0 = d.notch.b0;
+  k.n_b1 = d.notch.b1;
+  k.n_b2 = d.notch.b2;
+  k.n_a1 = d.notch.a1;
+  k.n_a2 = d.notch.a2;
+  return k;
+}
+
+/* One of the post chain's two complex ring-buffer filters (cFirFilter::Process / ProcessTwo: RDS 75-tap low-pass,
+ * audio 29-tap low-pass) on stream st; g0 = the ring phase at the call's first sample. */
+void launch_ring2(fmd_batch* b, hipStream_t st, const float2* in, float2* out, unsigned n, unsigned T,
+                  const float* taps, unsigned g0)
+{
+  const unsigned C = b->C, CP = b->CP;
+  if (b->dbg_ring4 && T >= unsigned(fmd::RG))
+    hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (n + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
+                       st, in, out, n, int(T), taps, g0, C, CP, 0u, 0u);
   else
-    hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(TILE), lds_l, sF, x, iq_channel_stride, N,
-                       b->hist[b->hist_sel].p, b->hist[b->hist_sel ^ 1].p, b->lut.p, T, b->lut_idx,
-                       b->if_coeff.p, d.if_order, D, pos, M, b->demod[q].p, b->Mstride, ntiles_l,
-                       (C % 8 == 0) ? 1u : 0u, b->cpc);
-  mark(1);
-  if (!level_in_fir)
-    hipLaunchKernelGGL(fmd::k_if_level<IN>, dim3(C), dim3(64), 0, sF, x, iq_channel_stride, N, b->lut.p, T,
-                       b->lut_idx, b->st, b->cpc);
-  return FMD_OK;
-}
-
-/* Window layout by the power-of-two factor of D (k_if_fir): D odd -> plain, D = 2 * odd and
- * 4 * odd -> de-interleaved into 2 / 4 regions; higher powers of two keep 4 regions (their
- * lane stride stays even: fewer conflicts, not none). */
-template <class IN, int TILE>
-int launch_if_stage_e(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
-                      unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
-                      hipEvent_t ev_start, hipEvent_t ev_stop)
-{
-  const unsigned D = b->des.D;
-  if (D % 2 != 0)
-    return launch_if_stage_t<IN, TILE, 0>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
-  if (D % 4 != 0)
-  { // D = 2 * odd.  Long filters: plain window read two samples at a time (fir_long_b128_asm: the b128
-    // lane groups are conflict-free at this stride); otherwise the two-region window.  "fir_b128" = 0
-    // keeps the two-region form for long filters too (fir_long_e1_asm).
-    const int b128 = b->dbg_fir_b128;
-    const unsigned T = b->des.table_size;
-    const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
-    if (b128 && TILE == 256 && b->des.if_order >= 512 && pow2)
-      return launch_if_stage_t<IN, TILE, 0>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
-    return launch_if_stage_t<IN, TILE, 1>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
-  }
-  { // D = 4 * odd and above.  Long filters: one region fewer than the power of two in D asks for, so
-    // that the lane stride inside a region stays EVEN and two adjacent positions come with one
-    // 16-byte read (fir_long_e1_b128_asm / fir_long_e2_b128_asm); FMD_FIR_B128=0 keeps the 8-byte reads
-    // of the four-region window (fir_long_e2_asm).  Short filters: four regions (odd stride for 4 * odd).
-    const int b128 = b->dbg_fir_b128;
-    const unsigned T = b->des.table_size;
-    const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
-    if (b128 && TILE == 256 && b->des.if_order >= 512 && pow2)
-    {
-      if (D % 8 != 0)
-        return launch_if_stage_t<IN, TILE, 1, true>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start,
-                                                    ev_stop);
-      return launch_if_stage_t<IN, TILE, 2, true>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start,
-                                                  ev_stop);
-    }
-  }
-  return launch_if_stage_t<IN, TILE, 2>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
-}
-
-/* Outputs per workgroup.  Small workgroups suffer least from the serial stage: its two role waves
- * issue with priority on two SIMDs of half the CUs, a bandwidth wave sharing such a SIMD runs at a
- * fraction of its speed, and a multi-wave workgroup waits for its slowest wave.  One wave per
- * workgroup (measured, 8192 channels, in the pipeline): 0.89 ms against 0.98 ms for four waves,
- * alone 0.77 against 0.78.  Long filters keep 256 outputs per workgroup so the `order`-sample
- * halo is amortised and the window fits LDS a useful number of times. */
-template <class IN>
-int launch_if_stage(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, unsigned N, unsigned pos,
-                    unsigned M, int q, hipStream_t sF, const std::function<void(int)>& mark,
-                      hipEvent_t ev_start, hipEvent_t ev_stop)
-{
-  const fmd::Design& d = b->des;
-  const unsigned T = d.table_size;
-  auto fits = [&](unsigned tile) {
-    const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * tile && (size_t(tile) * d.D) % T == 0;
-    const size_t lds = (size_t(tile - 1) * d.D + d.if_order + 4) * sizeof(float2);
-    return pow2 && d.if_order <= 4u * tile * d.D / 8u && lds <= 16 * 1024; // halo <= half the tile span
-  };
-  if (fits(64))
-    return launch_if_stage_e<IN, 64>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
-  if (fits(128))
-    return launch_if_stage_e<IN, 128>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
-  return launch_if_stage_e<IN, 256>(b, d_iq, iq_channel_stride, N, pos, M, q, sF, mark, ev_start, ev_stop);
+    hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (n + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
+                       size_t(T - 1 + fmd::RF_TI) * 64 * sizeof(float2), st, in, out, n, int(T), taps, g0, C, CP, 0u);
 }
 
 /* A call appends its RDS groups to queue[es]; if the queue's previous contents were handed to an
@@ -211,133 +85,79 @@ void queue_is_free(fmd_batch* b, int es, hipStream_t s)
   }
 }
 
-/* The light part of one call's post chain on stream s: cRDSRxSignalProcessor's PLL, matched filter
- * and bit recovery, then the audio tail; records the call's EV_RDS / EV_AUD. */
-void launch_light(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s, bool record)
-{ // (s by value: the audio half may move to j.s_audio)
+/* The light part of a call's post chain, lane-per-channel kernels on CP / 64 workgroups, in two halves.
+ * RDS half on stream s: (layout 2: the 75-tap low-pass behind the decimator's event,) cRDSRxSignalProcessor's
+ * PLL, matched filter and bit recovery; records EV_RDS. */
+void launch_light_rds(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s)
+{
   const fmd::Design& d = b->des;
   const unsigned C = b->C, CP = b->CP;
   const unsigned T_mf = unsigned(d.rds_mf_taps.size());
-  const unsigned LP = unsigned(std::max(1, std::min(4, b->dbg_light_pack))); // channel groups per workgroup
   const dim3 rt(256);
   auto rgrid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
-  // a complex ring-buffer filter of the light part (RDS low-pass / audio low-pass) and its input's history roll
-  auto ring2 = [&](hipStream_t st, const float2* in, float2* in_next, float2* out, unsigned n, unsigned T,
-                   const float* taps, unsigned g0) {
-    if (b->dbg_ring4 && T >= unsigned(fmd::RG))
-      hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (n + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0, st,
-                         in, out, n, int(T), taps, g0, C, CP, 0u, unsigned(b->dbg_lpf_prio));
-    else
-      hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (n + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
-                         size_t(T - 1 + fmd::RF_TI) * 64 * sizeof(float2), st, in, out, n, int(T), taps, g0, C, CP, 0u);
-    hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T - 1), rt, 0, st, in, in_next, T - 1, n, CP);
-  };
-  if (j.part != 2)
-  {
-  if (j.lpf_here && record)
-  { // the RDS low-pass at the head of this stream, behind the decimator (process_device_impl: lpf_light)
+  if (j.lpf_here)
+  { // the RDS low-pass at the head of this stream, behind the decimator
     if (hipStreamWaitEvent(s, b->cev[j.es][fmd_batch::EV_DEC], 0) != hipSuccess)
       mark_failed(b, "hipStreamWaitEvent failed in front of the RDS low-pass of a call");
     const unsigned T_lpf = unsigned(d.rds_lpf_taps.size());
-    ring2(s, b->rdsraw[j.q].p, b->rdsraw[j.q ^ 1].p, b->rlpf[j.q].p, j.R, T_lpf, b->rds_lpf_taps.p, j.rds_lpf_g);
+    launch_ring2(b, s, b->rdsraw[j.q].p, b->rlpf[j.q].p, j.R, T_lpf, b->rds_lpf_taps.p, j.rds_lpf_g);
+    hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, s, b->rdsraw[j.q].p, b->rdsraw[j.q ^ 1].p,
+                       T_lpf - 1, j.R, CP);
     if (hipEventRecord(b->cev[j.es][fmd_batch::EV_RDSH], s) != hipSuccess)
       mark_failed(b, "hipEventRecord failed behind the RDS low-pass of a call");
   }
   queue_is_free(b, j.es, s);
-  {
-    fmd::RdsConsts k{};
-    k.pll_alpha = d.rds_pll_alpha;
-    k.pll_beta = d.rds_pll_beta;
-    k.nco_hl = d.rds_nco_hl;
-    k.nco_ll = d.rds_nco_ll;
-    k.bs_b0 = d.bitsync.b0;
-    k.bs_b1 = d.bitsync.b1;
-    k.bs_b2 = d.bitsync.b2;
-    k.bs_a1 = d.bitsync.a1;
-    k.bs_a2 = d.bitsync.a2;
-    k.mf_taps = int(T_mf);
-    const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
-    hipLaunchKernelGGL(fmd::k_rds_pll, dim3((CP / 64 + fmd::RP_WAVES - 1) / fmd::RP_WAVES), dim3(64, fmd::RP_WAVES), 0, s, b->rlpf[j.q].p, j.R, C, CP, k, b->st,
-                       b->rpll.p, T_mf - 1, b->sctab.p, sct);
-    if (T_mf >= unsigned(fmd::RG))
-      hipLaunchKernelGGL(fmd::k_ring_fir4<float>, dim3(CP / 64, (j.R + 4 * fmd::RG - 1) / (4 * fmd::RG)),
-                         dim3(64, 4), 0, s, b->rpll.p, b->rmf.p, j.R, int(T_mf), b->mf_taps2.p, j.mf_g, C, CP,
-                         0u, 3u);
-    else
-      hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (j.R + fmd::RF_TI - 1) / fmd::RF_TI),
-                         dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), s, b->rpll.p,
-                         b->rmf.p, j.R, int(T_mf), b->mf_taps2.p, j.mf_g, C, CP, 0u);
-    hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, s, b->rpll.p, b->rpll.p, T_mf - 1, j.R,
-                       CP);
-    hipLaunchKernelGGL(fmd::k_rds_bits, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0, s, b->rmf.p, j.R, C, CP, k, b->st,
-                       j.call_index, b->queue[j.es].p, b->qcount(j.es), b->queue_cap,
-                       b->tap_sync.p, b->write_taps);
-  }
-  if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_RDS], s) != hipSuccess)
+  const fmd::RdsConsts k = rds_consts(d);
+  const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
+  hipLaunchKernelGGL(fmd::k_rds_pll, dim3((CP / 64 + fmd::RP_WAVES - 1) / fmd::RP_WAVES), dim3(64, fmd::RP_WAVES), 0,
+                     s, b->rlpf[j.q].p, j.R, C, CP, k, b->st, b->rpll.p, T_mf - 1, b->sctab.p, sct);
+  if (T_mf >= unsigned(fmd::RG))
+    hipLaunchKernelGGL(fmd::k_ring_fir4<float>, dim3(CP / 64, (j.R + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4),
+                       0, s, b->rpll.p, b->rmf.p, j.R, int(T_mf), b->mf_taps2.p, j.mf_g, C, CP, 0u, 3u);
+  else
+    hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (j.R + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
+                       size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), s, b->rpll.p, b->rmf.p, j.R, int(T_mf),
+                       b->mf_taps2.p, j.mf_g, C, CP, 0u);
+  hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, s, b->rpll.p, b->rpll.p, T_mf - 1, j.R, CP);
+  // Two light streams: the PREVIOUS call's status record (on the audio half's stream) copies the RDS state this
+  // kernel is about to overwrite -- it goes first (its call's audio half ended a period ago: never a wait in practice)
+  if (j.prev_aud && hipStreamWaitEvent(s, j.prev_aud, 0) != hipSuccess)
+    mark_failed(b, "hipStreamWaitEvent failed in front of the bit recovery of a call");
+  hipLaunchKernelGGL(fmd::k_rds_bits, dim3(CP / 64), dim3(64, 1), 0, s, b->rmf.p, j.R, C, CP, k, b->st,
+                     j.call_index, b->queue[j.es].p, b->qcount(j.es), b->queue_cap, b->tap_sync.p, b->write_taps);
+  if (j.events && hipEventRecord(b->cev[j.es][fmd_batch::EV_RDS], s) != hipSuccess)
     mark_failed(b, "hipEventRecord failed behind the RDS part of a call");
-  }
-  if (j.part == 1)
-    return; // (the audio half follows on its own: light_hold 2)
-  // the RDS part above only needed the RDS half of the call's heavy part (EV_RDSH, waited for by the
-  // caller); the audio tail needs the other half too
-  const hipStream_t s_rds_part = s;
-  if (j.s_audio && record)
-    s = j.s_audio; // the two halves side by side: two chains of lane-per-channel kernels, each shorter than a period
-  if (record && hipStreamWaitEvent(s, b->cev[j.es][j.tail_after_alp ? fmd_batch::EV_ALP : fmd_batch::EV_HEAVY], 0) != hipSuccess)
-    mark_failed(b, "hipStreamWaitEvent failed in front of the audio tail of a call");
-  if (j.lpf_here && record && !j.fuse_alp)
-  { // the audio low-pass in front of the tail that reads it
-    const unsigned T_alp = unsigned(d.lpf_taps.size());
-    ring2(s, b->rs[j.q].p, b->rs[j.q ^ 1].p, b->alp[j.q].p, j.A, T_alp, b->audio_taps.p, j.alpf_g);
-  }
-  {
-    fmd::AudioConsts k{};
-    k.de_alpha = d.de_alpha;
-    k.n_b0 = d.notch.b0;
-    k.n_b1 = d.notch.b1;
-    k.n_b2 = d.notch.b2;
-    k.n_a1 = d.notch.a1;
-    k.n_a2 = d.notch.a2;
-    if (j.fuse_alp && j.tl0)
-      hipExtLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0u, s, j.tl0, j.tl1, 0u,
-                            (const float2*)b->rs[j.q].p, b->rs[j.q ^ 1].p, j.A, j.alpf_g,
-                            (const float*)b->audio_taps.p, C, CP, k, b->st, j.d_audio, j.audio_stride,
-                            unsigned(j.sq), j.call_index, unsigned(b->dbg_alt_prio));
-    else if (j.fuse_alp)
-      hipLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0, s, b->rs[j.q].p, b->rs[j.q ^ 1].p,
-                         j.A, j.alpf_g, b->audio_taps.p, C, CP, k, b->st, j.d_audio, j.audio_stride,
-                         unsigned(j.sq), j.call_index, unsigned(b->dbg_alt_prio));
-    else if (j.tl0)
-      hipExtLaunchKernelGGL(fmd::k_audio_tail, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0u, s, j.tl0, j.tl1, 0u,
-                            (const float2*)b->alp[j.q].p, j.A, C, CP, k, b->st, j.d_audio, j.audio_stride,
-                            unsigned(j.sq), j.call_index);
-    else
-      hipLaunchKernelGGL(fmd::k_audio_tail, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0, s, b->alp[j.q].p, j.A, C, CP, k,
-                         b->st, j.d_audio, j.audio_stride, unsigned(j.sq), j.call_index);
-    if (s != s_rds_part && hipStreamWaitEvent(s, b->cev[j.es][fmd_batch::EV_RDS], 0) != hipSuccess)
-      mark_failed(b, "hipStreamWaitEvent failed in front of the status record of a call"); // its RDS state is the other half's
-    hipLaunchKernelGGL(fmd::k_status_publish, dim3((C + 255) / 256), dim3(256), 0, s, b->st, C, j.call_index);
-  }
-  if (record && hipEventRecord(b->cev[j.es][fmd_batch::EV_AUD], s) != hipSuccess)
-    mark_failed(b, "hipEventRecord failed behind the audio tail of a call");
 }
 
-/* Light parts that were kept back (light_hold): submit them now, each behind `gate` on both of its streams
- * (null: at once -- a wait, a collect or a reset needs them on the device). */
-void release_held_light(fmd_batch* b, hipEvent_t gate)
+/* Audio half on stream s, behind event `audio_after` of the call where it has one: (layout 2: the 29-tap low-pass,)
+ * de-emphasis, notch, L/R matrix, audio meter; then -- behind the RDS half -- the status record; records EV_AUD. */
+void launch_light_audio(fmd_batch* b, const fmd_batch::LightJob& j, hipStream_t s)
 {
-  while (!b->held_light.empty())
-  {
-    const fmd_batch::LightJob j = b->held_light.front();
-    b->held_light.pop_front();
-    if (gate)
-    {
-      if (hipStreamWaitEvent(j.sL, gate, 0) != hipSuccess ||
-          (j.s_audio && hipStreamWaitEvent(j.s_audio, gate, 0) != hipSuccess))
-        mark_failed(b, "hipStreamWaitEvent failed in front of a kept-back light part");
-    }
-    launch_light(b, j, j.sL, true);
+  const fmd::Design& d = b->des;
+  const unsigned C = b->C, CP = b->CP;
+  if (j.events && j.audio_after >= 0 && hipStreamWaitEvent(s, b->cev[j.es][j.audio_after], 0) != hipSuccess)
+    mark_failed(b, "hipStreamWaitEvent failed in front of the audio tail of a call");
+  if (j.lpf_here)
+  { // the audio low-pass in front of the tail that reads it
+    const unsigned T_alp = unsigned(d.lpf_taps.size());
+    launch_ring2(b, s, b->rs[j.q].p, b->alp[j.q].p, j.A, T_alp, b->audio_taps.p, j.alpf_g);
+    hipLaunchKernelGGL(fmd::k_roll<float2>, dim3((CP + 255) / 256, std::max(1u, std::min(T_alp - 1, 64u))), dim3(256),
+                       0, s, b->rs[j.q].p, b->rs[j.q ^ 1].p, T_alp - 1, j.A, CP);
   }
+  const fmd::AudioConsts k = audio_consts(d);
+  if (j.tl0) // profiling level 1: the tail's own start and stop
+    hipExtLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64, 1), 0u, s, j.tl0, j.tl1, 0u,
+                          (const float2*)b->alp[j.q].p, j.A, C, CP, k, b->st, j.d_audio, j.audio_stride,
+                          unsigned(j.sq), j.call_index);
+  else
+    hipLaunchKernelGGL(fmd::k_audio_tail, dim3(CP / 64), dim3(64, 1), 0, s, b->alp[j.q].p, j.A, C, CP, k, b->st,
+                       j.d_audio, j.audio_stride, unsigned(j.sq), j.call_index);
+  // the record's RDS state is the other half's (same stream: stream order)
+  if (j.events && j.status_after_rds && hipStreamWaitEvent(s, b->cev[j.es][fmd_batch::EV_RDS], 0) != hipSuccess)
+    mark_failed(b, "hipStreamWaitEvent failed in front of the status record of a call");
+  hipLaunchKernelGGL(fmd::k_status_publish, dim3((C + 255) / 256), dim3(256), 0, s, b->st, C, j.call_index);
+  if (j.events && hipEventRecord(b->cev[j.es][fmd_batch::EV_AUD], s) != hipSuccess)
+    mark_failed(b, "hipEventRecord failed behind the audio tail of a call");
 }
 
 enum IqFormat
@@ -441,16 +261,12 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   // call k-2 used the same buffers; its events say when they are free again
   const bool have_prev2 = ci > 2;
   hipEvent_t* pe2 = b->cev[(ci + fmd_batch::NSLOT - 2) % fmd_batch::NSLOT];
-  const unsigned LP = unsigned(std::max(1, std::min(4, b->dbg_light_pack))); // light kernels: groups per workgroup
   const bool serial_mode = b->concurrency == 0 || b->profiling >= 2;
   /* "stage_mask" (fmd_batch_debug_set; results are WRONG with anything but 63): which parts of a call are
    * launched at all -- 1 IF stage, 2 serial stage, 4 half-band chain, 8 resampler, 16 / 32 the light part's RDS /
    * audio half.  Every event is still recorded, so the pipeline keeps its shape: tools/power_by_stage.py runs each
    * part alone at full rate beside a power sampler (joules per call and part). */
   const unsigned stage_mask = (!serial_mode && !b->split_post) ? unsigned(b->dbg_stage_mask) : 63u;
-  // (the gate: only where calls overlap on streams of their own queues and the post chain is one heavy stream)
-  const bool use_gate = !serial_mode && b->concurrency == 2 && !b->split_post && b->dbg_gate != 0 &&
-                        b->streams_sharing == 0 && b->heavy_flag.p != nullptr;
   hipStream_t sF = serial_mode ? stream : b->s_fir;
   hipStream_t sS = serial_mode ? stream : b->s_ser;
   hipStream_t sP = serial_mode ? stream : b->s_post;
@@ -557,15 +373,14 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     // (behind the RDS half only, i.e. beside the resampler and the audio low-pass: measured, the FIR then
     // takes 1.00 instead of 0.95 ms and the period does not move; again with the faster serial stage of
     // round 3's end, which has slack: FIR 1.09 instead of 0.98 ms, period the same 2.00-2.01 ms)
-    // (by a word in device memory where that is possible: a hardware event between two queues costs ~110 us
-    // from the resampler's end to the FIR's start, every call -- k_gate_wait)
-    if (use_gate)
-      hipLaunchKernelGGL(fmd::k_gate_wait, dim3(1), dim3(64), 0, sF,
-                         (const unsigned*)(b->heavy_flag.p + (ci + fmd_batch::NSLOT - 2) % fmd_batch::NSLOT), ci - 2u,
-                         300000u);
-    else
-      after(sF, pe2[fmd_batch::EV_HEAVY]);
+    // (a hardware event between two queues costs ~110 us from the resampler's end to the FIR's start, every
+    // call; a word in device memory in its place: 76 us, and the period did not move -- round 5, removed)
+    after(sF, pe2[fmd_batch::EV_HEAVY]);
   }
+  // a batch that is one of several sub-batches sharing these streams (fmd_batch_create above 8192 channels): the
+  // FIR also stays behind the heavy part of the sub-batch call two back in the common sequence
+  if (b->sched_prev2 && !serial_mode)
+    after(sF, b->sched_prev2);
   {
     // EV_FIR right behind the FIR kernel (the serial stage waits for nothing else); the level meter
     // behind it also reads the input: EV_INDONE is what tells the caller its buffer is free
@@ -602,23 +417,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     after(sS, pe2[fmd_batch::EV_ROLL]);
   after(sS, ce[fmd_batch::EV_FIR]);
   {
-    fmd::DemodConsts k{};
-    k.pll_alpha = d.pll_alpha;
-    k.pll_beta = d.pll_beta;
-    k.nco_hl = d.nco_hl;
-    k.nco_ll = d.nco_ll;
-    k.demod_gain = d.demod_gain;
-    k.p_minfreq = d.p_minfreq;
-    k.p_maxfreq = d.p_maxfreq;
-    k.p_b0 = d.p_b0;
-    k.p_a1 = d.p_a1;
-    k.p_a2 = d.p_a2;
-    k.p_lf_b0 = d.p_lf_b0;
-    k.p_lf_b1 = d.p_lf_b1;
-    k.p_minsignal = d.p_minsignal;
-    k.p_lock_delay = d.p_lock_delay;
-    k.osc_cos = d.rds_osc_cos;
-    k.osc_sin = d.rds_osc_sin;
+    const fmd::DemodConsts k = demod_consts(d);
     // Up to 8192 channels the batch is latency-bound by this stage and needs at most 64 CUs for
     // it: two channel groups per workgroup, one role wave per SIMD of a CU (k_demod_serial).
     // Larger batches need the CUs for throughput and keep the shared form.
@@ -661,8 +460,6 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   }
   signal(ce[fmd_batch::EV_SER], sS);
   mark(2);
-  // the previous call's light part, kept back: behind THIS call's serial stage (see light_hold below)
-  release_held_light(b, ce[fmd_batch::EV_SER]);
 
   const dim3 rt(256);
   auto rgrid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
@@ -673,15 +470,13 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
    * post chain is dispatched first it fills every CU and the serial stage starts only once those
    * workgroups have drained (measured: 136 us after its predecessor ended, every call).  So the
    * post chain and the light part start behind a single wave that idles for a few microseconds:
-   * the serial stage is dispatched first (30-50 us after its predecessor, period 2.50 -> 2.42 ms).
-   * "post_delay_us" of fmd_batch_debug_set overrides (0 = off). */
-  const int post_delay_us = b->dbg_post_delay_us;
-  // wave priorities of half-band chain (tens) and ring resampler (units) in the overlapped pipeline
-  const unsigned heavy_prio = (!serial_mode && b->concurrency == 2) ? unsigned(b->dbg_heavy_prio) : 0u;
-  bool post_delay_done = false;
+   * the serial stage is dispatched first (30-50 us after its predecessor, period 2.50 -> 2.42 ms). */
+  constexpr unsigned kPostDelayUs = 20;
+  // wave priority of the ring resampler in the overlapped pipeline (the half-band chain's stays 0)
+  const unsigned rsr_prio = (!serial_mode && b->concurrency == 2) ? 2u : 0u;
   auto post_delay = [&](hipStream_t s) {
-    if (post_delay_us > 0 && b->serial_exclusive && !serial_mode && b->concurrency == 2 && !post_delay_done)
-      hipLaunchKernelGGL(fmd::k_delay, dim3(1), dim3(64), 0, s, unsigned(post_delay_us) * 100u);
+    if (b->serial_exclusive && !serial_mode && b->concurrency == 2)
+      hipLaunchKernelGGL(fmd::k_delay, dim3(1), dim3(64), 0, s, kPostDelayUs * 100u);
   };
 
   /* The post chain in four pieces.  "Heavy" = bandwidth / LDS bound and filling the chip; "light" =
@@ -705,30 +500,30 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     nrolls = 0;
     roll_hmax = 1;
   };
-  /* Default overlapped mode: the two low-pass filters of the post chain (0.1 ms each at 8192 channels, a few
-   * hundred small workgroups) run on a stream of their own, each behind the kernel that feeds it (EV_DEC: the
-   * decimator; EV_HEAVY: the resampler).  On the heavy stream they stood between the half-band chain and the
-   * resampler and in front of the next IF FIR -- 0.2 ms of every period with most of the 192 CUs idle; and
-   * behind EV_HEAVY on that stream they were in the next call's way (the IF FIR, at the high priority, kept
-   * them from running beside it: they ran when it had ended, in front of the half-band chain).  Their
-   * inputs (rdsraw, rs) are buffered by call parity so that the next call's decimator / resampler need not
-   * wait for them.  The light part waits for its low-pass (EV_RDSH behind the RDS one, EV_ALP behind the
-   * audio one). */
-  /* Only where the two loops of the pipeline are balanced (short IF filters): with a long IF filter the FIR
-   * alone sets the period and the fifth stream only gets in its way (config 5: 3.41 ms per call with it,
-   * 3.16 without -- its head waits for events in a hardware queue the FIR's stream shares). */
-  /* Round 5: the audio low-pass lives inside the audio tail's kernel (fuse_alp: 29 taps, every reference
-   * configuration), and the RDS low-pass runs at the head of the LIGHT stream, behind the decimator's event and in
-   * front of the RDS PLL that reads it (lpf_light): no fifth stream, nothing of either filter beside the next IF FIR
-   * but what the light part itself does.  "lpf_late" = 0 / 1 brings the heavy-stream / own-stream forms back. */
-  const bool fuse_alp = T_alp == 29 && b->dbg_fuse_alp != 0;
-  const bool lpf_late = !serial_mode && !b->split_post && b->s_lpf && b->dbg_lpf_late == 1;
-  const bool lpf_light = !serial_mode && !b->split_post && (b->dbg_lpf_late < 0 || b->dbg_lpf_late == 2);
+  /* Where the post chain's two complex low-pass filters (RDS 75 taps, audio 29 taps: ~0.05 ms each alone at 8192
+   * channels, a few hundred small workgroups) and the light part run -- the stream layout of an overlapped call
+   * ("lpf_late" of fmd_batch_debug_set overrides the choice):
+   *   0  both filters on the heavy stream (the RDS one between half-band chain and resampler, the audio one behind
+   *      the resampler), the light part on one stream behind them.  Long IF filters (> 512 taps): there the IF
+   *      FIR alone sets the period and more streams only get in its way (config 5, round 6, one box: 86 500 MS/s
+   *      against 80 800 with layout 2; the streams' heads wait for events in hardware queues the FIR's shares).
+   *   1  the filters on a stream of their own (s_lpf), each behind the kernel that feeds it (EV_DEC: the
+   *      decimator; EV_HEAVY: the resampler), the light part on one stream: round 4's layout -- the IF FIR at
+   *      0.62-0.65 of the HBM peak inside the pipeline, the whole path 4 % slower than layout 2.
+   *   2  no filter on the heavy stream or beside the next IF FIR's start: the RDS low-pass at the head of the light
+   *      part's RDS half (s_rds, behind EV_DEC), the audio low-pass at the head of its audio half on s_lpf (behind
+   *      EV_HEAVY) -- two chains of lane-per-channel kernels side by side, each shorter than a period.  Default
+   *      for short IF filters: +2.3 % at the driver's flags over layout 1.
+   * The filters' inputs (rdsraw, rs) are buffered by call parity, so the next call's decimator / resampler need
+   * not wait for them. */
+  const int layout = (serial_mode || b->split_post) ? 0
+                     : b->dbg_lpf_late >= 0         ? b->dbg_lpf_late
+                     : d.if_order <= 512            ? 2
+                                                    : 0;
+  const bool lpf_late = layout == 1, lpf_light = layout == 2;
   std::function<void()> rds_lpf_late, audio_lpf_late, mix_tail;
-  // ... and the light part's audio half (the tail's kernel) on the stream the filters had, beside its RDS half
-  const bool light_split = lpf_light && b->s_lpf && b->dbg_light_split != 0;
-  hipStream_t sLPr = lpf_late ? b->s_lpf : lpf_light ? sL : sR;
-  hipStream_t sLPa = (lpf_late || light_split) ? b->s_lpf : lpf_light ? sL : sA;
+  hipStream_t sLPr = lpf_late ? b->s_lpf : sR;
+  hipStream_t sLPa = lpf_late ? b->s_lpf : sA;
   // the resampler's form and its plan kernel (tap tables of this call's phases: no input but the positions)
   const unsigned per_step = unsigned(std::max(b->rsr_NW * b->rsr_R, 1));
   const unsigned rs_steps = (A + per_step - 1) / per_step;
@@ -779,12 +574,12 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
                               (const float2*)b->hbbuf[0].p, (const float2*)b->hbbuf[1].p, b->rdsraw[q].p, T_lpf - 1,
                               b->hbf_tail1.p, b->hbf_tail2.p, b->hbcoef[0], b->hbcoef[1], b->hbcoef[2],
                               (const fmd::HbStep*)pl->steps.p, (const int*)pl->seg_first.p, hb_in[0], n0, n1, C, CP,
-                              osc, (heavy_prio / 10u) % 10u);
+                              osc, 0u);
       else
         hipLaunchKernelGGL(kern, dim3(groups, pl->S), dim3(64, 4), 0, sR, in0, (const float2*)b->hbbuf[0].p,
                            (const float2*)b->hbbuf[1].p, b->rdsraw[q].p, T_lpf - 1, b->hbf_tail1.p, b->hbf_tail2.p,
                            b->hbcoef[0], b->hbcoef[1], b->hbcoef[2], (const fmd::HbStep*)pl->steps.p,
-                           (const int*)pl->seg_first.p, hb_in[0], n0, n1, C, CP, osc, (heavy_prio / 10u) % 10u);
+                           (const int*)pl->seg_first.p, hb_in[0], n0, n1, C, CP, osc, 0u);
       if (nomix) // the next call's stage-0 history, should it take a launch per stage (it reads mixed rows)
         mix_tail = [&, L0H]() {
           hipLaunchKernelGGL(fmd::k_mix_tail, rgrid(L0H), rt, 0, sR,
@@ -849,27 +644,25 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       }
     }
     mark(3);
-    auto lpf = [&]() {
-    const int ring4 = b->dbg_ring4;
-    if (ring4 && T_lpf >= unsigned(fmd::RG))
-      hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
-                         sLPr, b->rdsraw[q].p, b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C,
-                         CP, 0u, unsigned(b->dbg_lpf_prio));
-    else
-    hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
-                       size_t(T_lpf - 1 + fmd::RF_TI) * 64 * sizeof(float2), sLPr, b->rdsraw[q].p,
-                       b->rlpf[q].p, R, int(T_lpf), b->rds_lpf_taps.p, b->rds_lpf_g, C, CP, 0u);
-    if (hb_all_normal)
-    {
-      roll_later(b->rdsraw[q].p, b->rdsraw[q ^ 1].p, T_lpf - 1, R);
-      roll_flush(sLPr);
+    if (lpf_light) // the low-pass is the light part's (launch_light_rds); the decimator's rolls wait for the
+    {              // resampler's: one launch behind EV_HEAVY (k_roll_set takes four)
+      if (nrolls > 3)
+        roll_flush(sR);
+      return;
     }
-    else
-      hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, sLPr, b->rdsraw[q].p, b->rdsraw[q ^ 1].p, T_lpf - 1, R, CP);
+    auto lpf = [&]() {
+      launch_ring2(b, sLPr, b->rdsraw[q].p, b->rlpf[q].p, R, T_lpf, b->rds_lpf_taps.p, b->rds_lpf_g);
+      if (hb_all_normal)
+      {
+        roll_later(b->rdsraw[q].p, b->rdsraw[q ^ 1].p, T_lpf - 1, R);
+        roll_flush(sLPr);
+      }
+      else
+        hipLaunchKernelGGL(fmd::k_roll<float2>, rgrid(T_lpf - 1), rt, 0, sLPr, b->rdsraw[q].p, b->rdsraw[q ^ 1].p,
+                           T_lpf - 1, R, CP);
     };
-    if (lpf_late || lpf_light)
-    { // the low-pass later (see above); what the decimator left to roll waits for the resampler's roll: one
-      // launch behind EV_HEAVY (k_roll_set takes four)
+    if (lpf_late)
+    { // the low-pass later, on its own stream (see above)
       if (nrolls > 3)
         roll_flush(sR);
       rds_lpf_late = lpf;
@@ -883,37 +676,6 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     lpf();
     mark(4);
   };
-  auto rds_light = [&]() {
-    queue_is_free(b, es, sR);
-    {
-      fmd::RdsConsts k{};
-      k.pll_alpha = d.rds_pll_alpha;
-      k.pll_beta = d.rds_pll_beta;
-      k.nco_hl = d.rds_nco_hl;
-      k.nco_ll = d.rds_nco_ll;
-      k.bs_b0 = d.bitsync.b0;
-      k.bs_b1 = d.bitsync.b1;
-      k.bs_b2 = d.bitsync.b2;
-      k.bs_a1 = d.bitsync.a1;
-      k.bs_a2 = d.bitsync.a2;
-      k.mf_taps = int(T_mf);
-      const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
-      hipLaunchKernelGGL(fmd::k_rds_pll, dim3((CP / 64 + fmd::RP_WAVES - 1) / fmd::RP_WAVES), dim3(64, fmd::RP_WAVES), 0, sR, b->rlpf[q].p, R, C, CP, k,
-                         b->st, b->rpll.p, T_mf - 1, b->sctab.p, sct);
-      if (T_mf >= unsigned(fmd::RG))
-        hipLaunchKernelGGL(fmd::k_ring_fir4<float>, dim3(CP / 64, (R + 4 * fmd::RG - 1) / (4 * fmd::RG)),
-                           dim3(64, 4), 0, sR, b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C,
-                           CP, 0u, 3u);
-      else
-        hipLaunchKernelGGL(fmd::k_ring_fir<float>, dim3(CP / 64, (R + fmd::RF_TI - 1) / fmd::RF_TI),
-                           dim3(64, 4), size_t(T_mf - 1 + fmd::RF_TI) * 64 * sizeof(float), sR,
-                           b->rpll.p, b->rmf.p, R, int(T_mf), b->mf_taps2.p, b->mf_g, C, CP, 0u);
-      hipLaunchKernelGGL(fmd::k_roll<float>, rgrid(T_mf - 1), rt, 0, sR, b->rpll.p, b->rpll.p, T_mf - 1, R, CP);
-      hipLaunchKernelGGL(fmd::k_rds_bits, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0, sR, b->rmf.p, R, C, CP, k,
-                         b->st, ci, b->queue[es].p, b->qcount(es), b->queue_cap,
-                         b->tap_sync.p, b->write_taps);
-    }
-  };
   auto audio_heavy = [&]() {
 
     /* ---- audio branch  (stream A): resamplers, 15 kHz LPF, de-emphasis / notch / matrix ---- */
@@ -925,12 +687,12 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     if (ring)
     {
       // one workgroup (a whole CU's LDS) for every CU the serial stage leaves free: one round, with an equal
-      // run of (group, step) units each, >= 8 steps ("rsr_wgs" of fmd_batch_debug_set overrides the count;
-      // 160 / 176 / 184 / 192 of 192: 267 800 / 278 700 / 280 000 / 282 300 MS/s whole path on one box)
+      // run of (group, step) units each, >= 8 steps (measured with 160 / 176 / 184 / 192 of 192: 267 800 /
+      // 278 700 / 280 000 / 282 300 MS/s whole path on one box)
       const unsigned groups = CP / 64;
       const unsigned ncu = unsigned(b->n_cus) - ((b->serial_exclusive && !serial_mode) ? (groups + 1) / 2 : 0u);
       const unsigned units = groups * rs_steps;
-      unsigned W = b->dbg_rsr_wgs > 0 ? unsigned(b->dbg_rsr_wgs) : std::max(1u, ncu);
+      unsigned W = std::max(1u, ncu);
       W = std::max(1u, std::min(W, units / 8u));
       const unsigned per_wg = (units + W - 1) / W;
       W = (units + per_wg - 1) / per_wg;
@@ -941,11 +703,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
           hipExtLaunchKernelGGL(kern, dim3(W), dim3(64, b->rsr_NW + 1), lds, sA, evset[8], evset[9], 0u,
                                 (const float2*)b->brp(q), Hbb, b->rsr_rb, d.rs_order, (const float*)b->rsr_tab.p,
                                 b->rsr_nbm, (const int*)b->rsr_head.p, (const int*)b->rsr_steps.p, rs_steps, per_wg,
-                                b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, b->rsr_exp | ((heavy_prio % 10u) << 8), b->rsr_pace);
+                                b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, rsr_prio);
         else
         hipLaunchKernelGGL(kern, dim3(W), dim3(64, b->rsr_NW + 1), lds, sA, b->brp(q), Hbb, b->rsr_rb,
                            d.rs_order, b->rsr_tab.p, b->rsr_nbm, b->rsr_head.p, b->rsr_steps.p, rs_steps, per_wg,
-                           b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, b->rsr_exp | ((heavy_prio % 10u) << 8), b->rsr_pace);
+                           b->rsr_nbr, A, b->rs[q].p, T_alp - 1, C, CP, rsr_prio);
       };
       if (b->rsr_R == 4)
         go(&fmd::k_resample_ring<4, 4>);
@@ -964,22 +726,14 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     }
     roll_later(b->brp(q), b->brp(q ^ 1), Hbb, M); // with the low-pass's own roll, at the chain's end
     mark(6);
+    if (lpf_light) // the low-pass is the light part's (launch_light_audio); the baseband rows' roll: below
+      return;
     auto lpf = [&]() {
-    if (!fuse_alp)
-    { // (fused: the tail's kernel filters, and keeps the delay line's rows itself)
-    const int ring4a = b->dbg_ring4;
-    if (ring4a && T_alp >= unsigned(fmd::RG))
-      hipLaunchKernelGGL(fmd::k_ring_fir4<float2>, dim3(CP / 64, (A + 4 * fmd::RG - 1) / (4 * fmd::RG)), dim3(64, 4), 0,
-                         sLPa, b->rs[q].p, b->alp[q].p, A, int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u, unsigned(b->dbg_lpf_prio));
-    else
-    hipLaunchKernelGGL(fmd::k_ring_fir<float2>, dim3(CP / 64, (A + fmd::RF_TI - 1) / fmd::RF_TI), dim3(64, 4),
-                       size_t(T_alp - 1 + fmd::RF_TI) * 64 * sizeof(float2), sLPa, b->rs[q].p, b->alp[q].p, A,
-                       int(T_alp), b->audio_taps.p, b->alpf_g, C, CP, 0u);
-    roll_later(b->rs[q].p, b->rs[q ^ 1].p, T_alp - 1, A);
-    }
-    roll_flush(sLPa);
+      launch_ring2(b, sLPa, b->rs[q].p, b->alp[q].p, A, T_alp, b->audio_taps.p, b->alpf_g);
+      roll_later(b->rs[q].p, b->rs[q ^ 1].p, T_alp - 1, A);
+      roll_flush(sLPa);
     };
-    if (lpf_late || lpf_light)
+    if (lpf_late)
     { // the low-pass (and its own roll) later; the baseband rows' history behind EV_HEAVY (below)
       audio_lpf_late = lpf;
       return;
@@ -987,41 +741,38 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     lpf();
     mark(7);
   };
-  auto audio_light = [&]() {
-    {
-      fmd::AudioConsts k{};
-      k.de_alpha = d.de_alpha;
-      k.n_b0 = d.notch.b0;
-      k.n_b1 = d.notch.b1;
-      k.n_b2 = d.notch.b2;
-      k.n_a1 = d.notch.a1;
-      k.n_a2 = d.notch.a2;
-      if (fuse_alp)
-        hipLaunchKernelGGL(fmd::k_audio_lpf_tail29, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0, sA, b->rs[q].p, b->rs[q ^ 1].p, A,
-                           b->alpf_g, b->audio_taps.p, C, CP, k, b->st, d_audio, audio_channel_stride, unsigned(sq), ci,
-                           unsigned(b->dbg_alt_prio));
-      else
-      hipLaunchKernelGGL(fmd::k_audio_tail, dim3((CP / 64 + LP - 1) / LP), dim3(64, LP), 0, sA, b->alp[q].p, A, C, CP, k,
-                         b->st, d_audio, audio_channel_stride, unsigned(sq), ci);
-    }
-  };
+  // the light part's two halves (launch_light_rds / launch_light_audio), from the call's values
+  fmd_batch::LightJob job;
+  job.events = !serial_mode;
+  job.lpf_here = lpf_light;
+  job.rds_lpf_g = b->rds_lpf_g;
+  job.alpf_g = b->alpf_g;
+  job.R = R;
+  job.A = A;
+  job.mf_g = b->mf_g;
+  job.q = q;
+  job.es = es;
+  job.sq = sq;
+  job.call_index = ci;
+  job.d_audio = d_audio;
+  job.audio_stride = audio_channel_stride;
   if (serial_mode || b->split_post)
   { // stage order of the reference (what the per-stage profile is keyed to), or two streams
     rds_heavy();
-    rds_light();
-    signal(ce[fmd_batch::EV_RDS], sR);
+    if (sA != sR && !serial_mode && ci > 1) // call k-1's status record copies the RDS state this call's bit recovery writes
+      job.prev_aud = b->cev[(ci + fmd_batch::NSLOT - 1) % fmd_batch::NSLOT][fmd_batch::EV_AUD];
+    launch_light_rds(b, job, sR); // (records EV_RDS)
     mark(5);
     audio_heavy();
-    audio_light();
+    job.audio_after = -1; // behind its resampler and low-pass in stream order
+    job.status_after_rds = sA != sR;
+    launch_light_audio(b, job, sA); // (records EV_AUD)
     mark(8);
-    after(sA, ce[fmd_batch::EV_RDS]); // the record's RDS state is the other chain's
-    hipLaunchKernelGGL(fmd::k_status_publish, dim3((C + 255) / 256), dim3(256), 0, sA, b->st, C, ci);
-    signal(ce[fmd_batch::EV_AUD], sA);
     signal(ce[fmd_batch::EV_HEAVY], sA);
     signal(ce[fmd_batch::EV_ROLL], sA);
   }
   else
-  { // Both heavy parts first on the post stream, the light parts behind them on a stream of their
+  { // Both heavy parts first on the post stream, the light parts behind them on streams of their
     // own: the next call's FIR runs beside the light parts, and the next call's heavy parts do
     // not queue behind them (rlpf / alp, the buffers between a heavy and a light part, are
     // double-buffered by call parity; their readers of two calls ago are long done).
@@ -1039,38 +790,18 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       after(sP, pe2[fmd_batch::EV_RDSH]);
     if (lpf_late || lpf_light)
       rs_plan(sP); // off the path between the half-band chain and the resampler
-    const bool rs_first = lpf_light && b->dbg_rs_first != 0;
-    if (rs_first)
-    { // Experiment ("rs_first"): the resampler first, the next-but-one IF FIR released behind IT, and the half-band
-      // chain beside that FIR's start instead of beside the previous FIR's end (the two are independent: both
-      // only read br[q]).
-      after(sP, ce[fmd_batch::EV_SER]);
-      post_delay(sP);
-      post_delay_done = true;
-      audio_heavy();
-      if (use_gate)
-        hipLaunchKernelGGL(fmd::k_flag_set, dim3(1), dim3(1), 0, sP, b->heavy_flag.p + es, ci);
-      signal(ce[fmd_batch::EV_HEAVY], sP);
-      rds_heavy();
-      signal(ce[fmd_batch::EV_DEC], sR);
-    }
-    else
-    {
     if (stage_mask & 4u)
       rds_heavy();
     signal(ce[(lpf_late || lpf_light) ? fmd_batch::EV_DEC : fmd_batch::EV_RDSH], sR);
     if (stage_mask & 8u)
       audio_heavy();
-    if (use_gate)
-      hipLaunchKernelGGL(fmd::k_flag_set, dim3(1), dim3(1), 0, sP, b->heavy_flag.p + es, ci);
     signal(ce[fmd_batch::EV_HEAVY], sP); // the next-but-one call's IF FIR may go
-    }
     if (mix_tail)
     {
       mix_tail();
       mix_tail = nullptr;
     }
-    roll_flush(sP); // (lpf_late: the history rolls of both heavy parts in one launch)
+    roll_flush(sP); // (layouts 1, 2: the history rolls of both heavy parts in one launch)
     signal(ce[fmd_batch::EV_ROLL], sP);
     if (lpf_late)
     { // the two low-pass filters on their own stream
@@ -1087,67 +818,33 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       audio_lpf_late();
       signal(ce[fmd_batch::EV_ALP], sl);
     }
-    fmd_batch::LightJob job;
-    // lpf_light: the RDS low-pass at the head of the light part's RDS stream, behind the decimator; the audio one
-    // (where it is not part of the tail's kernel) in front of the tail, behind EV_HEAVY -- launch_light does
-    // both, from the job's values (so that the whole light part of a call can be submitted later: light_hold)
-    job.lpf_here = lpf_light;
-    job.rds_lpf_g = b->rds_lpf_g;
-    job.fuse_alp = fuse_alp;
-    job.alpf_g = b->alpf_g;
-    if (light_split)
-      job.s_audio = b->s_lpf;
-    job.R = R;
-    job.A = A;
-    job.mf_g = b->mf_g;
-    job.q = q;
-    job.es = es;
-    job.sq = sq;
-    job.call_index = ci;
-    job.d_audio = d_audio;
-    job.audio_stride = audio_channel_stride;
-    job.tail_after_alp = lpf_late;
     if (evset && b->profiling == 1)
     {
       job.tl0 = evset[4];
       job.tl1 = evset[5];
     }
-    /* The light part goes out at once, on its own stream: its RDS half behind the RDS half of the
-     * heavy part (it runs beside the resampler and the audio low-pass), the audio tail behind the
-     * whole heavy part (launch_light).  Until round 3 it was kept back until the NEXT call's serial
-     * stage had ended, so that it ran beside that call's heavy part and not beside a FIR; since its
-     * kernels fetch their input a tile ahead they no longer stretch beside the bandwidth kernels, and
-     * not keeping it back finishes every call 1.2 ms earlier (20 timed steps: +0.9 %, 160: +0.3 %). */
-    if (lpf_light && b->concurrency == 2 && b->dbg_light_hold != 0)
-    { /* Kept back (round 3's form, with two streams): the light part of this call is submitted with the NEXT
-       * call, behind that call's serial stage -- it then runs beside the next heavy part instead of beside the
-       * next-but-one IF FIR, whose window it otherwise shares from start to end.  Measured (docs/MEASUREMENTS.md,
-       * round 5): the FIR gains 0.02 of the HBM peak (0.60-0.61), the whole path loses 7.5 % -- the RDS PLL's
-       * table (16 KB of LDS on 32 CUs) and the light kernels' waves are in the whole-CU resampler's way.  Off. */
-      job.sL = sL;
-      if (b->dbg_light_hold == 2 && light_split)
-      { // only the audio half is kept back (no LDS, 128 waves); the RDS half goes out now
-        job.part = 1;
-        launch_light(b, job, sL, true);
-        job.part = 2;
-      }
-      else if (b->dbg_light_hold == 3 && light_split)
-      { // only the RDS half is kept back
-        job.part = 2;
-        launch_light(b, job, sL, true);
-        job.part = 1;
-      }
-      b->held_light.push_back(job);
+    /* The light part goes out at once: its RDS half behind the RDS half of the heavy part (it runs beside the
+     * resampler), the audio tail behind the whole heavy part.  (Until round 3 it was kept back until the NEXT
+     * call's serial stage had ended, so that it ran beside that call's heavy part and not beside a FIR -- built
+     * again and measured in round 5: the FIR gains 0.02 of the HBM peak, the whole path loses 7.5 %; removed.) */
+    // layout 2: the audio half on the stream the filters have in layout 1, beside the RDS half
+    hipStream_t s_aud = lpf_light ? b->s_lpf : sL;
+    if (!lpf_light)
+      after(sL, ce[fmd_batch::EV_RDSH]);
+    if (stage_mask & 16u) // (stage_mask: the energy experiment's half-by-half runs)
+    {
+      if (s_aud != sL && ci > 1) // call k-1's status record copies the RDS state this call's bit recovery writes
+        job.prev_aud = b->cev[(ci + fmd_batch::NSLOT - 1) % fmd_batch::NSLOT][fmd_batch::EV_AUD];
+      launch_light_rds(b, job, sL);
     }
     else
-    {
-      if (!lpf_light)
-        after(sL, ce[fmd_batch::EV_RDSH]);
-      if ((stage_mask & 48u) != 48u) // (energy experiment: one half of the light part, or none)
-        job.part = (stage_mask & 16u) ? 1 : 2;
-      if (stage_mask & 48u)
-        launch_light(b, job, sL, true);
-    }
+      signal(ce[fmd_batch::EV_RDS], sL);
+    job.audio_after = lpf_late ? fmd_batch::EV_ALP : fmd_batch::EV_HEAVY;
+    job.status_after_rds = s_aud != sL;
+    if (stage_mask & 32u)
+      launch_light_audio(b, job, s_aud);
+    else
+      signal(ce[fmd_batch::EV_AUD], s_aud);
   }
   mark(9);
   if (!serial_mode && b->concurrency < 2)

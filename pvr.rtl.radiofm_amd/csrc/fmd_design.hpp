@@ -30,7 +30,7 @@ struct Params
   bool us_version = false;
   unsigned table_size = 0;      // 0 -> 64 (FmDecode.cpp:249)
   unsigned if_filter_order = 0; // 0 -> 8*downsample (FmDecode.cpp:262)
-  int fir_reduction = 0;        // 0 sequential tap order (bit-exact), 1 shuffle-reduced (opt-in)
+  int fir_reduction = 0;        // 0 sequential tap order (bit-exact), 1 shuffle-reduced, 2 fused multiply-add (opt-in)
 };
 
 struct Biquad

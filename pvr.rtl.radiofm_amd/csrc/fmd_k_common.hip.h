@@ -173,6 +173,15 @@ __device__ __forceinline__ void lds_wait_ge(unsigned lds_addr, unsigned value, u
     dev_error(err, DEVERR_SERIAL_HANDSHAKE);
 }
 
+/* Which capture channel c tunes (fmd_batch_set_channels_per_capture: cpc consecutive channels share one).
+ * c is wave-uniform, but the compiler divides in vector registers: without the readfirstlane the capture's base
+ * address -- and with it every input load's address arithmetic -- lives in VGPRs (config 5's IF FIR: 3.22 instead
+ * of 3.0 ms alone, measured round 6). */
+__device__ __forceinline__ unsigned capture_of(unsigned c, unsigned cpc)
+{
+  return cpc > 1u ? (unsigned)__builtin_amdgcn_readfirstlane((int)(c / cpc)) : c;
+}
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
   // std::complex<float> product: (ac - bd) + i(ad + bc), four products and two sums, each rounded

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
     const float2* __restrict__ br, unsigned Hbb, int RB, unsigned order, const float* __restrict__ tab,
     unsigned nbm, const int* __restrict__ head, const int* __restrict__ steptab, unsigned nsteps,
     unsigned steps_per_wg, unsigned NBR, unsigned A, float2* __restrict__ out, unsigned Hout, unsigned C,
-    unsigned CP, unsigned exp, unsigned pace)
+    unsigned CP, unsigned prio)
 {
   constexpr int RSR_PRE = RSR_ROWS / RSR_NW; // rows a wave can hold for the next step
   constexpr int LEAD = 3;                    // batches the tap warmer runs ahead of the walk
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
    * CU's LDS, so a grid of groups x segments ran in rounds, and one CU that was not free at the start cost
    * a whole round more (0.53 instead of 0.36 ms inside the pipeline with 384 workgroups for 192 CUs).  A
    * run that crosses into the next group starts that group's ring afresh, like a segment. */
-  wave_prio((exp >> 8) & 3u);
+  wave_prio(prio);
   const unsigned units = (CP / 64u) * nsteps;
   unsigned u0 = min(units, blockIdx.x * steps_per_wg);
   const unsigned u1 = min(units, u0 + steps_per_wg);
@@ -365,13 +365,8 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
     for (int n = 0; n < RSR_PRE; n++)
       if (n < mine)
       { // read once: must not push the tap table out of the L2
-        if (exp & 32u)
-          pre[n] = *reinterpret_cast<const float2*>(rp + lane_off);
-        else
-        {
-          const fmd_f2v v = __builtin_nontemporal_load(reinterpret_cast<const fmd_f2v*>(rp + lane_off));
-          pre[n] = make_float2(v.x, v.y);
-        }
+        const fmd_f2v v = __builtin_nontemporal_load(reinterpret_cast<const fmd_f2v*>(rp + lane_off));
+        pre[n] = make_float2(v.x, v.y);
         rp += RSR_NW * row_bytes;
       }
   };
@@ -400,9 +395,8 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
     if (rounds <= 0)
       return;
     const uint64_t ta = reinterpret_cast<uint64_t>(tab) + ((uint64_t)step * RSR_NW * nbm + (uint64_t)b0) * (32 * R);
-    rs_warm_asm<R, RSR_NW>((unsigned)ta, (unsigned)(ta >> 32), nbm * (32u * R), (unsigned)rounds, pace);
+    rs_warm_asm<R, RSR_NW>((unsigned)ta, (unsigned)(ta >> 32), nbm * (32u * R), (unsigned)rounds, 0u);
   };
-  if (!(exp & 64u))
   { /* The taps arrive by scalar loads one batch ahead; a load that misses the L2 (the plan kernel wrote the
      * table on some other XCD) takes longer than that.  So the workgroups of an XCD (equal blockIdx.x % 8
      * under round-robin placement: speed only) first read the table (1.7 MB for 82 steps) through the
@@ -438,13 +432,13 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
   int topb = steptab[2 * s0];
   { // the first step's whole window
     const int r_hi = topb * 8 + 7;
-    for (int r0 = steptab[2 * s0 + 1] * 8; r0 <= r_hi && !(exp & 16u); r0 += RSR_NW * RSR_PRE)
+    for (int r0 = steptab[2 * s0 + 1] * 8; r0 <= r_hi; r0 += RSR_NW * RSR_PRE)
     {
       const int mine = warmer ? 0 : share(min(r_hi + 1 - r0, RSR_NW * RSR_PRE));
       fetch(r0, mine);
       stash(r0, mine);
     }
-    if (warmer && !(exp & 128u))
+    if (warmer)
       warm(s0, 0, LEAD);
   }
   __syncthreads();
@@ -453,16 +447,13 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
     // rows of the next step: in flight during this step's arithmetic
     const int ntop = s + 1 < s1 ? steptab[2 * (s + 1)] : topb;
     const int r_new0 = topb * 8 + 8;
-    const int mine = (exp & 4u) || warmer ? 0 : share((ntop - topb) * 8);
+    const int mine = warmer ? 0 : share((ntop - topb) * 8);
     fetch(r_new0, mine);
     if (warmer)
     {
-      if (!(exp & 128u))
-      {
-        warm(s, LEAD, (int)nbm - 1 - LEAD);
-        if (s + 1 < s1)
-          warm(s + 1, 0, LEAD);
-      }
+      warm(s, LEAD, (int)nbm - 1 - LEAD);
+      if (s + 1 < s1)
+        warm(s + 1, 0, LEAD);
       lds_barrier();
       topb = ntop;
       lds_barrier();
@@ -475,7 +466,7 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
 #pragma unroll
     for (int r = 0; r < R; r++)
       acc[r] = fmd_f2v{0.0f, 0.0f};
-    if (nb > 0 && !(exp & 8u))
+    if (nb > 0)
     {
       const float* __restrict__ kp = tab + (size_t)g * nbm * (8 * R);
       if (__builtin_expect(nonfinite_s == 0u, 1))
@@ -484,7 +475,7 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
         const uint64_t ka = reinterpret_cast<uint64_t>(kp);
         // (the low half of a generic LDS pointer is the LDS byte address)
         rs_walk_asm<R>(acc, off, cnt, (unsigned)(size_t)rsr_smem + lane * 16u, (NBR - 1u) * 4096u, (unsigned)ka,
-                       (unsigned)(ka >> 32), (exp & 1u) ? 0u : 32u * R);
+                       (unsigned)(ka >> 32), 32u * R);
       }
       else
       { // literal: only the rows of an output's own window, j ascending
@@ -511,7 +502,7 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
           }
         }
       }
-      if (live && !(exp & 2u))
+      if (live)
       {
 #pragma unroll
         for (int r = 0; r < R; r++)

@@ -1,5 +1,5 @@
 /*
- * fmd_k_tail.hip.h -- audio tail (k_audio_tail, k_audio_lpf_tail29), status record, RDS record export, stream probes,
+ * fmd_k_tail.hip.h -- audio tail (k_audio_tail), status record, RDS record export, stream probes,
  * device-math test kernel, history rolls.
  * Part of fmd_kernels.hip.h (layout, numerics contract and citations: see there and fmd_k_common.hip.h).
  */
@@ -140,293 +140,6 @@ __global__ __launch_bounds__(256) void k_audio_tail(const float2* __restrict__ l
   }
 }
 
-/* K7 + K8 as one kernel: the 29-tap audio low-pass (cFirFilter::ProcessTwo, FirFilter.cpp:387-413) in front of
- * the tail above, one lane per channel, nothing between them in memory.  The filter's delay line is the
- * reference's own ring buffer m_cZBuf[0 .. T-1], held in REGISTERS: position j keeps its sample until the ring
- * index m_State comes round again, and an output adds H[T - m_State + j] * Z[j] for j = 0 .. T-1 in that order --
- * with a0 = (T - m_State) % T (host-tracked: (g0 + i) % T for output i) that is tap (a0 + j) % T, age a0 first.
- *
- * Rounds of T outputs with a0 = 0 .. T-1 are straight-line code: every ring position and every tap a compile-time
- * register (taps in scalar register pairs, picked by op_sel), the multiply-add chain of every phase one asm block
- * (fmd_alp_mac.inc, tools/gen_audio_lpf_asm.py) -- each product consumed two instructions after it was issued:
- * 58 issue slots per frame and no wait slots (the compiler's own order costs 87, and it pads every inline-asm
- * statement it cannot see into).  A frame's input was loaded a whole round earlier.  The frames in front of the first whole round and behind
- * the last one (a call starts at a0 = g0 % T) go through a generic body: the new sample enters the ring by a
- * dynamic register index, the taps are read from a doubled table at a0.  (A first version dispatched every frame
- * to one of T bodies by a switch: correct, but the compiler cannot count outstanding loads across the switch and
- * waited for ALL of them in every frame -- 1570 cycles per frame alone on the chip.)
- * The delay line's T - 1 history rows are read from the front of the resampler's output buffer and written to
- * the front of the other parity's at the end, where k_ring_fir4's roll kept them: the two forms may follow each
- * other from call to call.
- * What it saves: the low-pass output's round trip (0.15 GB per call at 8192 channels) and a time-parallel
- * kernel of 10 000 small workgroups that ran starved beside the IF FIR (0.68 ms inside the pipeline for 0.075
- * alone); what it costs: 58 more packed instructions per frame in a lane-per-channel recurrence. */
-typedef float fmd_f32v __attribute__((ext_vector_type(32)));
-typedef float fmd_f16v __attribute__((ext_vector_type(16)));
-template <int U>
-__device__ __forceinline__ void alp_mac(fmd_f2v& acc, const fmd_f32v& zl, const fmd_f32v& zh, const fmd_f16v& ta,
-                                        const fmd_f16v& tb);
-#include "fmd_alp_mac.inc"
-
-template <int T>
-struct AudioLpfTail
-{
-  static_assert(T == 29, "ring positions 0 .. 14 in zl, 15 .. 28 in zh, pair 15 of each a scratch slot");
-  fmd_f32v zl, zh; // the ring: position p < 15 at zl[2p .. 2p+1], p >= 15 at zh[2(p-15) ..]; floats 30, 31: scratch
-  fmd_f16v ta, tb; // taps 0 .. 15 and 16 .. 28, wave-uniform: scalar registers (fmd_alp_mac.inc names them)
-  float de_re, de_im, w1a, w2a, w1b, w2b, vsum, vsumsq, one_minus_alpha;
-  int stereo;
-  AudioConsts k;
-  const float2* __restrict__ rs;
-  const float* __restrict__ taps2; // taps twice in a row: taps2[a0 + j] = tap (a0 + j) % T
-  float2* __restrict__ o;
-  size_t cp;
-  unsigned c, A, i;
-  bool active;
-
-  template <int P>
-  __device__ __forceinline__ fmd_f2v getz() const
-  {
-    if constexpr (P < 15)
-      return __builtin_shufflevector(zl, zl, 2 * P, 2 * P + 1);
-    else
-      return __builtin_shufflevector(zh, zh, 2 * (P - 15), 2 * (P - 15) + 1);
-  }
-  template <int P>
-  __device__ __forceinline__ void setz(float2 v)
-  {
-    if constexpr (P < 15)
-    {
-      zl[2 * P] = v.x;
-      zl[2 * P + 1] = v.y;
-    }
-    else
-    {
-      zh[2 * (P - 15)] = v.x;
-      zh[2 * (P - 15) + 1] = v.y;
-    }
-  }
-
-  __device__ __forceinline__ float2 frame(float2 v)
-  { // v.x = stereo, v.y = mono (ProcessTwo's A, B): the statements of k_audio_tail
-    de_re = one_minus_alpha * de_re + k.de_alpha * v.x;
-    const float s0 = de_re * 2.0f;
-    de_im = one_minus_alpha * de_im + k.de_alpha * v.y;
-    const float m0 = de_im * 2.0f;
-    const float w0a = s0 - k.n_a1 * w1a - k.n_a2 * w2a;
-    const float w0b = m0 - k.n_a1 * w1b - k.n_a2 * w2b;
-    const float s = k.n_b0 * w0a + k.n_b1 * w1a + k.n_b2 * w2a;
-    const float m = k.n_b0 * w0b + k.n_b1 * w1b + k.n_b2 * w2b;
-    w2a = w1a;
-    w1a = w0a;
-    w2b = w1b;
-    w1b = w0b;
-    const float mm = m * 0.5f;
-    const float2 f = stereo ? make_float2((m + s) * 0.5f, (m - s) * 0.5f) : make_float2(mm, mm);
-    vsum += f.x;
-    vsumsq += f.x * f.x;
-    vsum += f.y;
-    vsumsq += f.y * f.y;
-    return f;
-  }
-
-  template <int U>
-  __device__ __forceinline__ void slot(float2 x)
-  { // the output whose a0 is U: m_State = (T - U) % T takes the new sample
-    setz<(T - U) % T>(x);
-    fmd_f2v acc;
-    alp_mac<U>(acc, zl, zh, ta, tb);
-    const float2 f = frame(make_float2(acc.x, acc.y));
-    if (active)
-      o[i] = f;
-    i++;
-  }
-  template <int U>
-  __device__ __forceinline__ void round(float2 (&nxt)[T])
-  {
-    if constexpr (U < T)
-    {
-      const float2 x = nxt[U];
-      nxt[U] = row(i + (unsigned)T); // this slot's input of the next round
-      slot<U>(x);
-      round<U + 1>(nxt);
-    }
-  }
-
-  // any a0: the new sample by a dynamic register index (both halves of the ring take it, the one it does
-  // not belong to into its scratch slot), the taps from the doubled table
-  __device__ __forceinline__ void generic(unsigned a0, float2 x)
-  {
-    const unsigned su = a0 ? (unsigned)T - a0 : 0u;
-    const unsigned il = su < 15u ? 2u * su : 30u, ih = su >= 15u ? 2u * (su - 15u) : 30u;
-    zl[il] = x.x;
-    zl[il + 1] = x.y;
-    zh[ih] = x.x;
-    zh[ih + 1] = x.y;
-    const float* __restrict__ tb = taps2 + a0;
-    float2 acc = make_float2(tb[0] * zl[0], tb[0] * zl[1]);
-#pragma unroll
-    for (int j = 1; j < 15; j++)
-    {
-      acc.x += tb[j] * zl[2 * j];
-      acc.y += tb[j] * zl[2 * j + 1];
-    }
-#pragma unroll
-    for (int j = 15; j < T; j++)
-    {
-      acc.x += tb[j] * zh[2 * (j - 15)];
-      acc.y += tb[j] * zh[2 * (j - 15) + 1];
-    }
-    const float2 f = frame(acc);
-    if (active)
-      o[i] = f;
-    i++;
-  }
-  __device__ __forceinline__ float2 row(unsigned t) const // input of output t (clamped: nobody uses the rest)
-  {
-    return rs[(size_t)((unsigned)T - 1u + min(t, A - 1u)) * cp + c];
-  }
-  // outputs i .. stop - 1 through the generic body, inputs four frames ahead
-  __device__ __forceinline__ void stretch(unsigned& a0, unsigned stop)
-  {
-    float2 x0 = row(i), x1 = row(i + 1), x2 = row(i + 2), x3 = row(i + 3);
-    while (i < stop)
-    {
-      const float2 x = x0;
-      x0 = x1;
-      x1 = x2;
-      x2 = x3;
-      x3 = row(i + 4);
-      generic(a0, x);
-      a0 = a0 + 1u == (unsigned)T ? 0u : a0 + 1u;
-    }
-  }
-};
-
-__global__ __launch_bounds__(256) void k_audio_lpf_tail29(const float2* __restrict__ rs, float2* __restrict__ rs_next,
-                                                         unsigned A, unsigned g0, const float* __restrict__ taps2,
-                                                         unsigned C, unsigned CP, AudioConsts k, ChannelState st,
-                                                         float* __restrict__ audio, size_t audio_stride,
-                                                         unsigned stereo_q, unsigned call_index, unsigned prio)
-{
-  constexpr int T = 29;
-  wave_prio(prio);
-  const unsigned lane = threadIdx.x;
-  const unsigned c0 = (blockIdx.x * blockDim.y + threadIdx.y) * 64 + lane;
-  if (c0 - lane >= CP)
-    return;
-  AudioLpfTail<T> s;
-  s.active = c0 < C;
-  const unsigned c = s.active ? c0 : C - 1;
-  s.c = c;
-  s.cp = CP;
-  s.A = A;
-  s.i = 0;
-  s.k = k;
-  s.rs = rs;
-  s.taps2 = taps2;
-  s.de_re = st.F(F_DE_RE)[c];
-  s.de_im = st.F(F_DE_IM)[c];
-  s.w1a = st.F(F_N_W1A)[c];
-  s.w2a = st.F(F_N_W2A)[c];
-  s.w1b = st.F(F_N_W1B)[c];
-  s.w2b = st.F(F_N_W2B)[c];
-  s.stereo = st.I(I_STEREO_Q0 + (int)stereo_q)[c];
-  s.one_minus_alpha = 1.0f - k.de_alpha;
-  s.vsum = 0.0f;
-  s.vsumsq = 0.0f;
-  s.o = reinterpret_cast<float2*>(audio + (size_t)c * audio_stride);
-#pragma unroll
-  for (int m = 0; m < 16; m++)
-  {
-    s.ta[m] = taps2[m];
-    s.tb[m] = taps2[16 + m]; // (taps 29 .. 31 of the doubled table: unused)
-  }
-  const unsigned a0s = g0 % (unsigned)T;
-  // ring position j holds the sample of age (a0s + j) % T before the first output (buffer row of time t is
-  // T - 1 + t); age 0 is the position the first output overwrites
-  s.zl = 0.0f;
-  s.zh = 0.0f;
-  {
-    float2 h[T];
-#pragma unroll
-    for (int j = 0; j < T; j++)
-    {
-      unsigned age = a0s + (unsigned)j;
-      age = age >= (unsigned)T ? age - (unsigned)T : age;
-      h[j] = rs[(size_t)((unsigned)T - 1u - max(age, 1u)) * CP + c];
-    }
-#pragma unroll
-    for (int j = 0; j < 15; j++)
-    {
-      s.zl[2 * j] = h[j].x;
-      s.zl[2 * j + 1] = h[j].y;
-    }
-#pragma unroll
-    for (int j = 15; j < T; j++)
-    {
-      s.zh[2 * (j - 15)] = h[j].x;
-      s.zh[2 * (j - 15) + 1] = h[j].y;
-    }
-  }
-  unsigned a0 = a0s;
-  // the frames in front of the first whole round
-  s.stretch(a0, min(A, a0s ? (unsigned)T - a0s : 0u));
-  if (s.i + (unsigned)T <= A)
-  { // whole rounds: a0 = 0 .. T - 1, every frame's input loaded a round ahead
-    float2 nxt[T];
-#pragma unroll
-    for (int u = 0; u < T; u++)
-      nxt[u] = s.row(s.i + (unsigned)u);
-    while (s.i + (unsigned)T <= A)
-      s.template round<0>(nxt);
-  }
-  s.stretch(a0, A); // (a0 is 0 here unless the call had no whole round)
-  if (s.active)
-  {
-    // the delay line for the next call, where k_ring_fir4's roll keeps it: row T - 1 - age of the other buffer
-    const unsigned a0e = (a0s + A) % (unsigned)T;
-    float2 h[T];
-#pragma unroll
-    for (int j = 0; j < 15; j++)
-      h[j] = make_float2(s.zl[2 * j], s.zl[2 * j + 1]);
-#pragma unroll
-    for (int j = 15; j < T; j++)
-      h[j] = make_float2(s.zh[2 * (j - 15)], s.zh[2 * (j - 15) + 1]);
-#pragma unroll
-    for (int j = 0; j < T; j++)
-    {
-      unsigned age = a0e + (unsigned)j;
-      age = age >= (unsigned)T ? age - (unsigned)T : age;
-      if (age != 0)
-        rs_next[(size_t)((unsigned)T - 1u - age) * CP + c] = h[j];
-    }
-    st.F(F_DE_RE)[c] = s.de_re;
-    st.F(F_DE_IM)[c] = s.de_im;
-    st.F(F_N_W1A)[c] = s.w1a;
-    st.F(F_N_W2A)[c] = s.w2a;
-    st.F(F_N_W1B)[c] = s.w1b;
-    st.F(F_N_W2B)[c] = s.w2b;
-    const float n = (float)(2u * A);
-    const float rms = sqrtf(s.vsumsq / n);
-    const float mean = s.vsum / n;
-    const float level = (float)(0.95 * (double)st.F(F_AUDIO_LEVEL)[c] + 0.05 * (double)rms);
-    st.F(F_AUDIO_MEAN)[c] = mean;
-    st.F(F_AUDIO_RMS)[c] = rms;
-    st.F(F_AUDIO_LEVEL)[c] = level;
-    unsigned* __restrict__ h2 = st.ds + c; // the call's status record (see k_audio_tail)
-    const size_t CPs = st.CP;
-    h2[HS_IF_LEVEL * CPs] = __float_as_uint(st.F(F_IF_LEVEL)[c]);
-    h2[HS_BB_MEAN * CPs] = __float_as_uint(st.F(F_BB_MEAN)[c]);
-    h2[HS_BB_LEVEL * CPs] = __float_as_uint(st.F(F_BB_LEVEL)[c]);
-    h2[HS_P_LEVEL * CPs] = __float_as_uint(st.F(F_P_LEVEL)[c]);
-    h2[HS_STEREO * CPs] = (unsigned)s.stereo;
-    h2[HS_AUDIO_MEAN * CPs] = __float_as_uint(mean);
-    h2[HS_AUDIO_RMS * CPs] = __float_as_uint(rms);
-    h2[HS_AUDIO_LEVEL * CPs] = __float_as_uint(level);
-  }
-}
-
 /* The last kernel of a call: every channel's status record from device memory to the host's snapshot
  * under the per-channel sequence lock (HostStatusWord), a thread per channel -- one kernel of a few
  * waves pays the two system-scope fences, not the latency-bound audio tail. */
@@ -505,26 +218,6 @@ __global__ void k_delay(unsigned ticks)
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks)
     __builtin_amdgcn_s_sleep(4);
-}
-
-/* Ordering between two streams without a hardware event, where the order is only a matter of scheduling (the IF
- * FIR of call k + 2 should not start before the heavy part of call k has ended: they would fight for the same
- * CUs; no data passes between them).  A cross-queue event wait costs ~110 us between the end of one kernel and
- * the start of the other (measured: docs/MEASUREMENTS.md, round 5); a word in device memory that the first
- * stream sets (k_flag_set, one thread, behind the resampler) and one sleeping wave on the second stream polls
- * (k_gate_wait, directly in front of the FIR) costs two same-stream kernel gaps (~13 us each).  Call indices
- * only grow; the gate gives up after `limit` ticks of the 100 MHz clock -- it must never be what a call hangs on
- * (two streams that share a hardware queue: the batch does not use the gate then). */
-__global__ void k_flag_set(unsigned* flag, unsigned value)
-{
-  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ void k_gate_wait(const unsigned* flag, unsigned want, unsigned limit)
-{
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0 &&
-         __builtin_amdgcn_s_memrealtime() - t0 < limit)
-    __builtin_amdgcn_s_sleep(8);
 }
 
 __global__ void k_probe_nop(int* sink)

@@ -320,43 +320,133 @@ def test_two_post_streams_overlapped_at_4096_channels(oracle, fmsig, debug):
                     check=[0, 63, 2047, 2048, 4095], u8=False, debug=debug)
 
 
-@pytest.mark.parametrize("u8", [False, True], ids=["f32", "u8"])
-def test_fused_audio_tail_and_level_meter_inside_the_fir(oracle, fmsig, u8):
-    """Two opt-in forms (fmd_batch_debug_set "fuse_alp", "level_in_fir"): the 29-tap audio low-pass inside the
-    audio tail's kernel (k_audio_lpf_tail29: cFirFilter::ProcessTwo's ring buffer in registers, FirFilter.cpp:387-413,
-    whole rounds of 29 frames as straight-line code, the frames around them through the generic body) and
-    RMSLevelApprox (FmDecode.cpp:505-519) in the IF FIR's first workgroup of a channel -- on ragged calls: fewer
-    audio frames than taps, calls that start and end in the middle of a round, full blocks."""
+@pytest.mark.parametrize("layout", [0, 1, 2], ids=["heavy-stream", "own-stream", "light-streams"])
+def test_stream_layouts_of_an_overlapped_call(oracle, fmsig, layout):
+    """The three stream layouts of an overlapped call (fmd_batch_debug_set "lpf_late"; process_device_impl): the
+    post chain's two complex low-pass filters (cFirFilter::Process / ProcessTwo, FirFilter.cpp:330-413) on the heavy
+    stream (what long IF filters take), on a stream of their own (round 4's), or at the heads of the light part's
+    two streams (the default for short IF filters) -- on ragged calls: fewer audio frames than taps, full blocks,
+    consumed two calls late.  Same audio, status and groups bit for bit."""
     pkg = load_package()
     sizes = [N, 10007, 1001, 330, 65535, 150, 33001, N, 2000, 21120, N]
-    _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, 1024, sizes, check=[0, 63, 64, 511, 1023], u8=u8,
-                    debug=(("fuse_alp", 1), ("level_in_fir", 1)))
+    _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, 1024, sizes, check=[0, 63, 64, 511, 1023], u8=False,
+                    debug=(("lpf_late", layout),))
 
 
-def test_audio_low_pass_forms_follow_each_other(oracle, fmsig):
-    """The fused form keeps the low-pass's delay line where the separate kernel's roll keeps it (the front rows of
-    the resampler's output buffer): a batch may change form between any two calls."""
+def test_stream_layout_may_change_between_calls(oracle, fmsig):
+    """The layouts keep the filters' delay lines in the same rows (the front rows of the decimator's and the
+    resampler's output buffers, rolled by whoever ran the filter): a batch may change layout between any two
+    calls (the key drains the device first)."""
     pkg = load_package()
-    fs, D, C = 2.4e6, 11, 8
+    import torch
+    fs, D, C = 2.4e6, 11, 1024
+    chans = [fmsig.channel_params(fs, c % 4) for c in range(C)]
+    gen = fmsig.DeviceGenerator(chans, "cuda")
     b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
-    refs = [oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for _ in range(C)]
-    ps = [fmsig.channel_params(fs, c) for c in range(C)]
+    b.set_concurrency(2)
+    check = [0, 5, 1023]
+    refs = {c: oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for c in check}
+    a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
+    st = torch.cuda.current_stream().cuda_stream
     pos = 0
-    for k, n in enumerate([N, 30001, 500, N, 12345, 200, N, N]):
-        b.debug_set("fuse_alp", k & 1)
-        iq = np.stack([fmsig.generate_f32(p, pos, n) for p in ps]).view(np.complex64)
-        a = b.process_host(iq)
-        for c in range(C):
-            assert _bits_equal(a[c], refs[c].process_stream(iq[c])), (k, c, n)
+    for k, n in enumerate([N, 30002, 500, N, 12346, 200, N, N, N]):
+        b.debug_set("lpf_late", k % 3)
+        t = torch.zeros((C, n, 2), dtype=torch.float32, device="cuda")
+        gen.generate(t, pos, n)
+        audio = torch.zeros((C, a_stride), dtype=torch.float32, device="cuda")
+        nf = b.process_device(t.data_ptr(), n, n, audio.data_ptr(), a_stride, st)
+        b.wait(stream=st)
+        torch.cuda.synchronize()
+        a = audio[:, :nf].cpu().numpy()
+        for c in check:
+            assert _bits_equal(a[c], refs[c].process_stream(t[c].cpu().numpy().reshape(-1))), (k, c, n)
         pos += n
     b.close()
 
 
-@pytest.mark.parametrize("lag", [1, 2])
-def test_light_part_kept_back_for_the_next_call(oracle, fmsig, lag):
-    """Opt-in "light_hold": the light part of a call (RDS low-pass, PLL, matched filter, bits; audio low-pass, tail,
-    status) is submitted with the NEXT call, behind that call's serial stage; waits and collects of the newest
-    call submit it first.  Same audio, status and groups, consumed one and two calls late, ragged sizes."""
+@pytest.mark.parametrize("u8", [False, True], ids=["f32", "u8"])
+def test_batch_above_8192_channels_runs_as_sub_batches(oracle, fmsig, u8):
+    """One fmd_batch of 16 448 channels = a shell over three sub-batches (5504 + 5504 + 5440) that share the five
+    internal streams; a call is submitted sub-batch by sub-batch into one sequence of whole-CU pipeline calls
+    (fmd_batch::subs, csrc/fmd_batch.hip).  Channels are independent (FmDecode.h:201-212): the first and last
+    channel of every sub-batch against the CPU oracle bit for bit, and c / c + C/2 (which lie in DIFFERENT sub-batches)
+    identical in audio, status and RDS groups -- full and ragged calls, consumed two calls late."""
     pkg = load_package()
-    _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, 1024, [N, 30001, N, 8193, N, 12346, N, N],
-                    check=[0, 63, 512, 1023], u8=False, lag=lag, debug=(("light_hold", 1),))
+    C = 16448
+    _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, C, [N, 30001, N, N],
+                    check=[0, 5503, 5504, 8223, 8224, 11007, 11008, 16447], u8=u8)
+
+
+def test_sub_batches_through_every_entry_point(oracle, fmsig):
+    """The rest of the batch API over a shell (8320 channels = 4224 + 4096): the host-buffer entry point and the
+    device one in the default concurrency mode (caller's stream ordered after every call), Reset, the getters, a
+    stage tap, group decoder callbacks with the caller's channel numbers, device export with a channel offset."""
+    import torch
+    pkg = load_package()
+    fs, D, C = 2.4e6, 11, 8320
+    chans = [fmsig.channel_params(fs, c % 4) for c in range(C)]
+    gen = fmsig.DeviceGenerator(chans, "cuda")
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=True)
+    check = [0, 4223, 4224, 8319]
+    refs = {c: oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for c in check}
+    pos = 0
+    # host buffers in and out, short calls, a Reset in the middle (FmDecode.cpp:326-338)
+    for k, n in enumerate([16384, 8192, 16384, 12000, 16384]):
+        t = torch.empty((C, n, 2), dtype=torch.float32, device="cuda")
+        gen.generate(t, pos, n)
+        iq = t.cpu().numpy().reshape(C, 2 * n).view(np.complex64)
+        a = b.process_host(iq)
+        for c in check:
+            assert _bits_equal(a[c], refs[c].process_stream(iq[c])), (k, c)
+        assert np.array_equal(a[:4].view(np.uint32), a[C - 4:].view(np.uint32))  # same stations (C % 4 == 0)
+        if k == 2:
+            b.reset()
+            for c in check:
+                refs[c].reset()
+        pos += n
+    # device buffers, full blocks; the groups through the shell's group decoders (callbacks), then by device export
+    a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
+    t = torch.empty((C, N, 2), dtype=torch.float32, device="cuda")
+    audio = torch.zeros((C, a_stride), dtype=torch.float32, device="cuda")
+    rec = torch.zeros((4 * C, 4), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    exported = {c: [] for c in check}
+    for k in range(22):
+        gen.generate(t, pos, N)
+        torch.cuda.synchronize()
+        nf = b.process_device(t.data_ptr(), N, N, audio.data_ptr(), a_stride, st)
+        torch.cuda.synchronize()  # (mode 1: the caller's stream is behind the call)
+        a = audio[:, :nf].cpu().numpy()
+        for c in check:
+            assert _bits_equal(a[c], refs[c].process_stream(t[c].cpu().numpy().reshape(-1))), (k, c)
+        if k < 14:
+            b.collect_rds_array(cap=4 * C, run_group_decoder=True, stream=st)
+            if k == 13:
+                for c in check:
+                    assert b.sink.frames.get(c, []) == refs[c].uecp_frames(), c
+                assert b.sink.frames.get(4, []) == b.sink.frames.get(0, [])
+        else:
+            b.export_rds_device(rec.data_ptr(), 4 * C, channel_offset=1000, stream=st)
+            torch.cuda.synchronize()
+            r = rec.cpu().numpy()
+            r = r[r[:, 0] != 0]
+            ch = r[:, 0] - 1001
+            assert ((ch >= 0) & (ch < C)).all()
+            for c in check:
+                exported[c] += [(int(row[1]), (int(row[2]) & 0xffff, (int(row[2]) >> 16) & 0xffff,
+                                               int(row[3]) & 0xffff, (int(row[3]) >> 16) & 0xffff)) for row in r[ch == c]]
+            counts = np.bincount(ch, minlength=C)
+            assert (counts.reshape(-1, 4) == counts[:4]).all()  # every channel of a station reports as many groups
+        pos += N
+    for c in check:
+        first_exported = min((k for k, _ in exported[c]), default=None)
+        assert first_exported is not None
+        want = [(k, tuple(bl)) for k, bl in refs[c].rds_groups() if k >= first_exported]
+        assert sorted(exported[c]) == sorted(want), c
+        so, sg = refs[c].status(), b.status(c)
+        assert sg.stereo_detected == so.stereo
+        for f_o, f_g in ((so.if_level, sg.interface_level), (so.baseband_level, sg.baseband_level),
+                         (so.pilot_level, sg.pilot_level), (so.tuning_offset, sg.tuning_offset)):
+            assert np.float32(f_o) == np.float32(f_g), c
+        assert _bits_equal(b.tap("mono_rs", c), b.tap("mono_rs", c % 4))
+    b.close()

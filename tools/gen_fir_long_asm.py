@@ -4,8 +4,8 @@ one sample (8 bytes) at a time, as the inline-asm bodies of
 
     fir_long_odd_asm   G = 1   plain window, odd decimation D (a 16-byte read would be misaligned for
                                every other lane)
-    fir_long_e1_asm    G = 2   two-region window, D = 2 * odd without the b128 form
-    fir_long_e2_asm    G = 4   four-region window, D = 4 * odd (and higher powers of two)
+    (G = 2 / 4 without `b128`: the two- / four-region windows read 8 bytes at a time -- fir_long_e1_asm /
+     fir_long_e2_asm, shipped until round 5 behind a development key, no longer part of the library)
 
 in pvr.rtl.radiofm_amd/csrc/fmd_k_if.hip.h (D = 2 * odd normally runs fir_long_b128_asm,
 tools/gen_fir_long_b128_asm.py).

@@ -46,7 +46,6 @@ def main():
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--channels", type=int, default=8192)
     ap.add_argument("--fir-variants", action="store_true")
-    ap.add_argument("--forms", action="store_true")
     ap.add_argument("--alt-forms", action="store_true")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"])
     args = ap.parse_args()
@@ -113,18 +112,11 @@ def main():
             name, mask, calls, dt * 1e3, p, clk, p * dt, (p - p_idle) * dt, len(ws)))
         time.sleep(0.5)
     if args.fir_variants:  # the IF stage alone in its other forms: what its joules are made of
-        for name, keys in (("IF stage, 13 waves per CU (shipped)", {"fir_lds_pad": 0}),
-                           ("IF stage, 10 waves per CU", {"fir_lds_pad": 4096}),
-                           ("IF stage, 8 waves per CU", {"fir_lds_pad": 8192}),
-                           ("IF stage, 6 waves per CU", {"fir_lds_pad": 14336}),
-                           ("IF stage, 5 waves per CU", {"fir_lds_pad": 20480}),
-                           ("IF stage, 4 waves per CU", {"fir_lds_pad": 28672}),
-                           ("IF stage, 3 waves per CU", {"fir_lds_pad": 40960}),
+        for name, keys in (("IF stage, two outputs per lane (shipped)", {}),
                            ("IF stage, one output per lane (k_if_fir_mt)", {"fir_ro": 1}),
                            ("IF stage, three outputs per lane", {"fir_ro": 3}),
                            ("IF stage, one tile per workgroup (k_if_fir)", {"fir_nt": 1}),
                            ("IF stage, two outputs per lane (shipped)", {})):
-            b.debug_set("fir_lds_pad", keys.get("fir_lds_pad", 0))
             b.debug_set("fir_ro", keys.get("fir_ro", 2))
             b.debug_set("fir_nt", keys.get("fir_nt", 0))
             b.debug_set("stage_mask", 1)
@@ -142,43 +134,6 @@ def main():
             print("%-48s %.4f ms/call  %6.0f W  %4.0f MHz  %.3f J/call  (%.3f above idle)" % (
                 name, dt * 1e3, p, clk, p * dt, (p - p_idle) * dt))
             time.sleep(0.5)
-    if args.forms:  # the opt-in forms in joules: audio low-pass inside the tail, level meter inside the FIR
-        def measure(name, mask, keys):
-            for k_, v_ in keys.items():
-                b.debug_set(k_, v_)
-            b.debug_set("stage_mask", mask)
-            t0 = time.perf_counter()
-            run(40)
-            per = (time.perf_counter() - t0) / 40
-            calls = max(200, int(args.seconds / per))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run(calls)
-            t1 = time.perf_counter()
-            dt = (t1 - t0) / calls
-            lo, hi = t0 + 0.25 * (t1 - t0), t1 - 0.1 * (t1 - t0)
-            ws = [(w, c) for t, w, c in smp.samples if lo <= t <= hi]
-            p = sum(w for w, _ in ws) / max(1, len(ws))
-            clk = sum(c for _, c in ws) / max(1, len(ws))
-            print("%-58s %.4f ms/call  %6.0f W  %4.0f MHz  %.3f J/call  (%.3f above idle)" % (
-                name, dt * 1e3, p, clk, p * dt, (p - p_idle) * dt))
-            time.sleep(0.5)
-        for lp in (1, 2, 4):
-            measure("light part, RDS half, %d groups per workgroup" % lp, 16, {"light_pack": lp})
-            measure("light part, audio half, %d groups per workgroup" % lp, 32, {"light_pack": lp})
-            measure("whole call, %d groups per workgroup" % lp, 63, {"light_pack": lp})
-        b.debug_set("light_pack", 1)
-        measure("audio half: low-pass kernel + tail (shipped)", 32, {"fuse_alp": 0})
-        measure("audio half: low-pass inside the tail (k_audio_lpf_tail29)", 32, {"fuse_alp": 1})
-        measure("audio half: low-pass kernel + tail (shipped), again", 32, {"fuse_alp": 0})
-        measure("IF stage: level meter in its own kernel (shipped)", 1, {"level_in_fir": 0})
-        measure("IF stage: level meter inside the FIR", 1, {"level_in_fir": 1})
-        measure("IF stage: level meter in its own kernel (shipped), again", 1, {"level_in_fir": 0})
-        for pr in (3, 1, 0):
-            measure("whole call, audio low-pass inside the tail, priority %d" % pr, 63, {"fuse_alp": 1, "level_in_fir": 0, "alt_prio": pr})
-        measure("whole call, shipped", 63, {"fuse_alp": 0, "alt_prio": 3})
-        measure("whole call, both fusions", 63, {"fuse_alp": 1, "level_in_fir": 1})
-        measure("whole call, shipped, again", 63, {"fuse_alp": 0, "level_in_fir": 0})
     if args.alt_forms:  # the other forms of the heavy kernels and of the serial stage, in joules
         def measure2(name, mask, keys, undo):
             for k_, v_ in keys.items():
