@@ -19,9 +19,8 @@ import os
 import sys
 import time
 
-# The decoder runs three internal streams next to torch's; give HIP enough hardware queues that
-# they do not share one (must be set before the HIP runtime initialises).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES is left alone: the library picks five internal streams on separate hardware queues by
+# measurement, and HIP's default of 4 queues measures the same as 8 -- profiles/r6_*_bench_hw_queues_*.json.)
 # dmabuf IPC: what RCCL needs between processes on this pool (the driver exports it too; a launcher that did not
 # hand it down must not be what an N > 1 run fails on)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -202,6 +201,95 @@ def _spawn_ranks(n):
     raise SystemExit(0)
 
 
+def _supervise_rank():
+    """One rank of a run that creates an RCCL communicator (N > 1, or the forced world of one), as launched by
+    torch.distributed.run or by _spawn_ranks: THIS process stays a supervisor that has not imported torch and has not
+    touched HIP; the rank's work runs in a child (the same script, FMD_BENCH_WORKER=1).  The worker reports "here"
+    when the host-side rendezvous has returned (every rank is present) and "up" once its RCCL communicator exists and
+    a barrier behind it has passed (so "up" is all ranks or none).  RCCL's bootstrap stalls about once in 20 launches
+    on this pool -- no error, every rank waits inside ncclCommInitRank --: when "up" does not follow "here" within
+    FMD_BENCH_UP_TIMEOUT (60) seconds, or the worker dies before "up", the supervisor ends its worker and starts it
+    again, ONCE, with a fresh rendezvous (every rank's supervisor sees the same and does the same).  The C++ loop
+    has the same in tools/rank_supervisor.hpp.  Does not return."""
+    import signal
+    import subprocess
+    import threading
+    up_timeout = float(os.environ.get("FMD_BENCH_UP_TIMEOUT", "60"))
+    rank = os.environ.get("RANK", "0")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    child = [None]
+
+    def _end(grace=2.0):
+        p = child[0]
+        if p is None or p.poll() is not None:
+            return
+        for sg, wait in ((signal.SIGTERM, grace), (signal.SIGKILL, 5.0)):
+            try:
+                os.killpg(p.pid, sg)
+            except (ProcessLookupError, PermissionError):
+                pass
+            t_end = time.time() + wait
+            while p.poll() is None and time.time() < t_end:
+                time.sleep(0.02)
+            if p.poll() is not None:
+                return
+
+    def _on_signal(signum, _frame):
+        _end()
+        raise SystemExit(128 + signum)
+
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sg, _on_signal)
+    rc = 1
+    for attempt in (0, 1):
+        rfd, wfd = os.pipe()
+        env = dict(os.environ, FMD_BENCH_WORKER="1", FMD_BENCH_ATTEMPT=str(attempt), FMD_BENCH_STATUS_FD=str(wfd))
+        if attempt:
+            # a rendezvous of its own: under torch.distributed.run the agent's store stays, the workers' keys move
+            # (the prefix is the restart count); where rank 0's worker hosts the store itself, the next port
+            if env.get("TORCHELASTIC_USE_AGENT_STORE") == "True":
+                env["TORCHELASTIC_RESTART_COUNT"] = str(int(env.get("TORCHELASTIC_RESTART_COUNT", "0")) + 100)
+            elif "MASTER_PORT" in env:
+                env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 1)
+        p = subprocess.Popen(cmd, env=env, pass_fds=(wfd,), start_new_session=True)
+        child[0] = p
+        os.close(wfd)
+        marks = {}
+
+        def _read(fd=rfd, marks=marks):
+            with os.fdopen(fd, "r") as f:
+                for line in f:
+                    marks[line.strip()] = time.time()
+
+        threading.Thread(target=_read, daemon=True).start()
+        stalled = False
+        while p.poll() is None and "up" not in marks:
+            if "here" in marks and time.time() - marks["here"] > up_timeout:
+                stalled = True
+                break
+            time.sleep(0.05)
+        if "up" not in marks and attempt == 0 and (stalled or p.poll() not in (None, 0)):
+            sys.stderr.write("bench.py: rank %s: communicator not up (%s) -- ending the worker and starting it "
+                             "again, once\n" % (rank, "no answer %.0f s after the rendezvous" % up_timeout if stalled
+                                                else "worker exited with %s" % p.poll()))
+            sys.stderr.flush()
+            _end()
+            continue
+        rc = p.wait()
+        break
+    raise SystemExit(rc if rc >= 0 else 1)
+
+
+def _report(mark):
+    """worker -> supervisor (_supervise_rank): the marks "here" and "up" """
+    fd = os.environ.get("FMD_BENCH_STATUS_FD")
+    if fd:
+        try:
+            os.write(int(fd), (mark + "\n").encode())
+        except OSError:
+            pass
+
+
 def config2(args):
     """BASELINE configs[1]: 1 stereo FM channel + RDS, 2.4 MS/s, through the drop-in surface -- the call the
     reference's demux thread makes (cFmDecoder::ProcessStream, /root/reference/src/RadioReceiver.cpp:515-538):
@@ -301,9 +389,10 @@ def main():
     ap.add_argument("--lag", type=int, default=3, choices=[1, 2, 3, 4],
                     help="steps between submitting a call and consuming its outputs (host never blocks "
                          "on a call younger than this)")
-    ap.add_argument("--fir-reduction", type=int, default=0, choices=[0, 1],
+    ap.add_argument("--fir-reduction", type=int, default=0, choices=[0, 1, 2],
                     help="0: sequential tap order, bit-exact (default, what every reported figure uses); "
-                         "1: opt-in shuffle-reduced tap sum (not bit-exact; measured for DESIGN.md only)")
+                         "1: opt-in shuffle-reduced tap sum; 2: fused multiply-add in the reference's order (both "
+                         "not bit-exact: parity waived, measured for docs/MEASUREMENTS.md only)")
     ap.add_argument("--verify", action="store_true",
                     help="before the timed region: rank 0 checks the audio and RDS records it gathered "
                          "from every rank (a few channels each, first steps) bit for bit against its own "
@@ -311,6 +400,11 @@ def main():
                          "On by default with more than one rank (a multi-GPU number is only reported for "
                          "a gather that was checked); --no-verify turns it off")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--emulate-peers", type=int, default=0, metavar="P",
+                    help="sizing of rank 0 on one GPU (with FMD_BENCH_FORCE_DIST=1, a world of one): every step's gather "
+                         "also writes what P more ranks' receives would write into rank 0's buffers "
+                         "(fmd_gather_debug_emulate_peers)")
+    ap.add_argument("--emulate-wgs", type=int, default=2, help="workgroups per emulated peer")
     ap.add_argument("--side-stream", action="store_true",
                     help="development: submit from a non-default torch stream (the null stream orders itself "
                          "against every blocking stream of the process)")
@@ -327,6 +421,19 @@ def main():
         return config2(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _spawn_ranks(args.gpus)  # does not return
+    if ((int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("FMD_BENCH_FORCE_DIST") == "1")
+            and os.environ.get("FMD_BENCH_WORKER") != "1" and os.environ.get("FMD_BENCH_BACKEND", "nccl") == "nccl"):
+        _supervise_rank()  # does not return: the rank's work runs in a child that can be started again
+    if os.environ.get("FMD_BENCH_TEST_SUPERVISOR") == "1":  # test aid (tests/test_bench_launcher.py): a worker
+        _report("here")                                     # whose communicator never comes up the first time
+        if os.environ.get("FMD_BENCH_ATTEMPT") == "0":
+            time.sleep(600)
+        _report("up")
+        print(json.dumps({"test_worker": True, "attempt": int(os.environ["FMD_BENCH_ATTEMPT"]),
+                          "rank": int(os.environ.get("RANK", "0")),
+                          "restart_count": os.environ.get("TORCHELASTIC_RESTART_COUNT"),
+                          "master_port": os.environ.get("MASTER_PORT")}), flush=True)
+        return
     if os.environ.get("FMD_BENCH_TEST_HANG") == "1" and os.environ.get("FMD_BENCH_SPAWNED") == "1":
         time.sleep(600)  # test aid (tests/test_bench_launcher.py): a rank that never finishes
 
@@ -367,21 +474,28 @@ def main():
     # group counting from the gathered records) with a world of ONE rank -- what a box with a single
     # GPU can exercise of the RCCL path: the communicator is initialised and every gather call is made.
     dist_on = world > 1 or os.environ.get("FMD_BENCH_FORCE_DIST") == "1"
+    emu_peers = args.emulate_peers if (dist_on and world == 1) else 0
+    if args.emulate_peers and not emu_peers:
+        raise SystemExit("--emulate-peers needs FMD_BENCH_FORCE_DIST=1 and --gpus 1 (a world of one)")
     if world > 1 and not args.no_verify:
         args.verify = True
     if dist_on and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29549")
-    # FMD_BENCH_RENDEZVOUS=gloo (with the nccl data path): torch.distributed only carries the rendezvous and the
-    # barriers, over gloo on the host -- then the process holds ONE RCCL communicator (the C++ gather's) instead of
-    # two (torch's process group has its own, with its streams and proxy thread)
-    pg_backend = os.environ.get("FMD_BENCH_RENDEZVOUS", backend)
+    # torch.distributed only carries the rendezvous and the barriers, over gloo on the host: the process then holds
+    # ONE RCCL communicator (the C++ gather's) instead of two (torch's nccl process group has its own, with its
+    # streams and proxy thread) -- half as many bootstraps that can stall, and the host-side rendezvous returns when
+    # every rank is present, which is where the supervisor's clock starts (_supervise_rank).
+    # FMD_BENCH_RENDEZVOUS=nccl brings torch's own communicator back (round 5's default).
+    pg_backend = os.environ.get("FMD_BENCH_RENDEZVOUS", "gloo" if backend == "nccl" else backend)
     pg_dev = dev if pg_backend == "nccl" else "cpu"
     if dist_on:
         if pg_backend == "nccl":
+            _report("here")
             dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend=pg_backend, rank=rank, world_size=world)
+            _report("here")
 
     global FS, D
     order = 0
@@ -453,7 +567,7 @@ def main():
     shifts = (np.arange(C, dtype=np.int32) % table) - table // 2 if shared else None
     batch = pkg.Batch(pkg.make_params(FS, 0.0 if shared else -0.15 * FS, 48000.0, 15000.0, D,
                                       table_size=table, if_filter_order=order,
-                                      fir_reduction=0x101 if args.fir_reduction else 0),
+                                      fir_reduction={0: 0, 1: 0x101, 2: 0x102}[args.fir_reduction]),
                       C, tuning_shifts=shifts, device=local_rank, record_callbacks=False)
     if G > 1:
         batch.set_channels_per_capture(cpc)
@@ -475,8 +589,9 @@ def main():
         on = dev if (backend == "nccl" or not dist_on) else "cpu"
         # one tensor per slot, [world][...]: g_audio[slot][r] is rank r's part (the C++ gather writes at
         # rank * size; torch.distributed.gather takes the list of the parts)
-        g_audio = [torch.empty((world, C, a_stride), dtype=torch.float32, device=on) for _ in range(NBUF)]
-        g_rds = [torch.empty((world, RCAP, 4), dtype=torch.int32, device=on) for _ in range(NBUF)]
+        # (--emulate-peers P, world of one: room for the P ranks whose receives are emulated)
+        g_audio = [torch.empty((world + emu_peers, C, a_stride), dtype=torch.float32, device=on) for _ in range(NBUF)]
+        g_rds = [torch.zeros((world + emu_peers, RCAP, 4), dtype=torch.int32, device=on) for _ in range(NBUF)]
         if on == dev and backend == "nccl" and dist_on:
             # rank 0 has its own outputs produced IN PLACE, in its part of the receive buffers: the gather then has
             # nothing to copy for it (fmd_gather_step: d_audio == d_all_audio), 88 MB per step less through HBM
@@ -494,6 +609,10 @@ def main():
             uid.copy_(torch.frombuffer(bytearray(gmod.unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, src=0)
         gth = gmod.Gather(bytes(uid.cpu().numpy().tobytes()), rank, world, local_rank, C * a_stride, RCAP)
+        dist.barrier()  # every rank's communicator is up, or none says so
+        _report("up")
+        if emu_peers:
+            gth.emulate_peers(emu_peers, args.emulate_wgs)
     group_acc = torch.zeros((), dtype=torch.int64, device=dev)  # groups counted on the device
     stream = torch.cuda.current_stream().cuda_stream
     pending = [None] * NBUF
@@ -854,8 +973,8 @@ def main():
                 + (" -- input as RTL-SDR u8 byte pairs, ReadAsyncCB conversion fused into the IF "
                    "kernel (SURVEY 8(f)-2; not the BASELINE metric's input format)" if u8 else ""),
                        "input_format": args.input,
-                       "fir_reduction": "sequential (bit-exact)" if args.fir_reduction == 0
-                       else "shuffle (opt-in, NOT bit-exact)",
+                       "fir_reduction": {0: "sequential (bit-exact)", 1: "shuffle (opt-in, NOT bit-exact)",
+                                         2: "fused multiply-add (opt-in, NOT bit-exact)"}[args.fir_reduction],
                        "channels_per_gpu": C, "samples_per_call": N, "input_ring_blocks": ring,
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "internal_streams_sharing_a_hw_queue": batch.streams_sharing_queue(),
@@ -864,6 +983,11 @@ def main():
                                   % ("RCCL, grouped ncclSend / ncclRecv from C++ (include/fmd_gather.h)"
                                      if backend == "nccl" else backend, world, "" if world == 1 else "s"))
                        if dist_on else "none (1 GPU)",
+                       "emulated_peers": ({"peers": emu_peers, "workgroups_per_peer": args.emulate_wgs,
+                                           "bytes_written_per_step": emu_peers * (C * a_stride * 4 + RCAP * 16),
+                                           "note": "sizing aid: what that many ranks' receives would write into "
+                                                   "rank 0's buffers, every step, on the gather's stream"}
+                                          if emu_peers else None),
                        "host_ms_per_step": {"submit": round(host_ms["process"], 3),
                                             "wait": round(host_ms.get("wait", 0.0), 3),
                                             "collect_rds": round(host_ms["collect"], 3),

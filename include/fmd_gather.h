@@ -81,6 +81,16 @@ typedef struct fmd_gather_info_t
 } fmd_gather_info_t;
 int fmd_gather_info(fmd_gather* g, fmd_gather_info_t* out);
 
+/* Measurement aid, world of ONE only (refused otherwise): every later step also WRITES, on the library's stream and
+ * in the step's place, what `peers` more ranks' receives would write into rank 0's buffers -- peers x (audio_floats
+ * floats + rds_rows records) at d_all_audio + r * audio_floats / d_all_rds + r * rds_rows * 4, r = 1 .. peers (the
+ * caller's receive buffers must hold 1 + peers ranks) -- with `workgroups_per_peer` workgroups per peer, as RCCL's
+ * receive kernel would occupy a few CUs.  What it is for: sizing rank 0's extra load (its memory system and its
+ * power budget take 7 x 88 MB per step on an 8-GPU node) on a box with one GPU, before the first 8-GPU run
+ * (docs/MEASUREMENTS.md).  The bytes arrive as fast as the kernel can store them, not paced by
+ * seven xGMI links: a burst, i.e. the contention of a step is concentrated, its joules are the same.  0 = off. */
+int fmd_gather_debug_emulate_peers(fmd_gather* g, int peers, int workgroups_per_peer);
+
 #ifdef __cplusplus
 }
 #endif

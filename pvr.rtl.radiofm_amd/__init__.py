@@ -224,6 +224,7 @@ def _check(rc):
 
 FIR_SEQUENTIAL = 0
 FIR_SHUFFLE_PARITY_WAIVED = 0x101  # include/fmd.h: the shuffle-reduced IF FIR, outside the parity contract
+FIR_FMA_PARITY_WAIVED = 0x102  # FMD_FIR_FMA_PARITY_WAIVED: fused multiply-add, the reference's tap order
 
 
 def make_params(sample_rate_if, tuning_offset, sample_rate_pcm=48000.0, bandwidth_pcm=15000.0,

@@ -985,10 +985,18 @@ int create_one(const fmd_params* params, unsigned n_channels, const int* tuning_
       bad |= b->rsr_steps.alloc(step_ints);
       const void* fns[] = {reinterpret_cast<const void*>(&fmd::k_resample_ring<4, 4>),
                            reinterpret_cast<const void*>(&fmd::k_resample_ring<2, 8>),
+                           reinterpret_cast<const void*>(&fmd::k_resample_ring<2, 8, true>),
                            reinterpret_cast<const void*>(&fmd::k_resample_ring<2, 4>)};
       for (const void* f : fns)
         (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     }
+  }
+  if (b->params.fir_reduction == 2)
+  { // the fused multiply-add form of the resamplers is the ring kernel's, two outputs x eight waves: every call takes it
+    if (b->rsr_R != 2 || b->rsr_NW != 8)
+      return fail(FMD_ERR_ARG, "FMD_FIR_FMA_PARITY_WAIVED: the fused multiply-add form exists for the reference "
+                               "geometry only (this resampler window does not fit the 2 x 8 ring form)");
+    b->rsr_mode = 1;
   }
   bad |= b->sctab.alloc(d.sincos_tab.size());
   bad |= b->sctab256.alloc(d.sincos_tab256.size());

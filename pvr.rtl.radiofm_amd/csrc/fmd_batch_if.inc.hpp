@@ -38,8 +38,6 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   const size_t lds = (region << E) * sizeof(float2) + (longasm ? 32 * sizeof(float2) : 0);
   if (lds > 160 * 1024)
     return fail(FMD_ERR_ARG, "IF filter window does not fit in LDS");
-  if (b->if_dry_run) // fmd_batch_create: only whether this geometry can be launched at all
-    return FMD_OK;
   // fast staging: the tuner table is a power of two that divides a tile's sample span, so a lane
   // needs the same two table entries for every load (all reference configurations: T = 64)
   const bool pow2 = (T & (T - 1)) == 0 && T <= 2u * TILE && (size_t(TILE) * D) % T == 0;
@@ -67,7 +65,9 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
   // against 0.83 ms), and in the throughput-bound regime (> 8192 channels) the faster FIR only
   // takes from the kernels beside it (32 768 channels: 228 against 236 GS/s): two tiles only beside
   // the whole-CU serial stage.
-  const int fir_nt = b->dbg_fir_nt ? b->dbg_fir_nt : (b->concurrency == 2 && b->serial_exclusive ? 2 : 1);
+  // (the fused multiply-add form exists for the two-tile, two-outputs-per-lane kernel only: always that one)
+  const bool fma = b->params.fir_reduction == 2;
+  const int fir_nt = fma ? 2 : b->dbg_fir_nt ? b->dbg_fir_nt : (b->concurrency == 2 && b->serial_exclusive ? 2 : 1);
   unsigned nblocks = C * ntiles, ntiles_l = ntiles;
   size_t lds_l = lds;
   FirFn3<IN> kfn3 = nullptr; // k_if_fir_mt3
@@ -80,17 +80,24 @@ int launch_if_stage_t(fmd_batch* b, const void* d_iq, size_t iq_channel_stride, 
                   : &fmd::k_if_fir_mt<IN, 7, 2>;
     nblocks = C * ((ntiles + nt - 1) / nt);
     // two (three) outputs per lane (k_if_fir_mt3): every sample is read from LDS once for up to two (three) taps
-    const unsigned RO = unsigned(b->dbg_fir_ro), T3 = 64 * RO;
+    const unsigned RO = fma ? 2u : unsigned(b->dbg_fir_ro), T3 = 64 * RO;
     const unsigned rounds3 = unsigned(((size_t(T3 - 1) * D + d.if_order + 2) / 2 + 63) / 64);
     if (RO > 1 && nt == 2 && d.if_order == 88 && D == 11 && (size_t(T3) * D) % T == 0 &&
         rounds3 <= (RO == 3 ? 18u : 12u))
     {
-      kfn3 = RO == 3 ? &fmd::k_if_fir_mt3<IN, 18, 2, 3> : &fmd::k_if_fir_mt3<IN, 12, 2, 2>;
+      kfn3 = RO == 3 ? &fmd::k_if_fir_mt3<IN, 18, 2, 3>
+             : fma   ? &fmd::k_if_fir_mt3<IN, 12, 2, 2, 88, 11, true>
+                     : &fmd::k_if_fir_mt3<IN, 12, 2, 2>;
       ntiles_l = (M + T3 - 1) / T3;
       lds_l = (size_t(T3 - 1) * D + d.if_order + 4) * sizeof(float2);
       nblocks = C * ((ntiles_l + 1) / 2);
     }
   }
+  if (fma && !kfn3)
+    return fail(FMD_ERR_ARG, "FMD_FIR_FMA_PARITY_WAIVED: the fused multiply-add form exists for the reference geometry "
+                             "only (88-tap IF filter, downsample 11, power-of-two tuner table)");
+  if (b->if_dry_run) // fmd_batch_create: only whether this geometry can be launched at all
+    return FMD_OK;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -711,6 +711,8 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       };
       if (b->rsr_R == 4)
         go(&fmd::k_resample_ring<4, 4>);
+      else if (b->rsr_NW == 8 && b->params.fir_reduction == 2)
+        go(&fmd::k_resample_ring<2, 8, true>); // FMD_FIR_FMA_PARITY_WAIVED
       else if (b->rsr_NW == 8)
         go(&fmd::k_resample_ring<2, 8>);
       else

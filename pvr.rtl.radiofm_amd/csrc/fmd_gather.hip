@@ -1,6 +1,7 @@
 /*
  * fmd_gather.hip -- rank-0 gather of float audio and RDS records over RCCL (include/fmd_gather.h).
- * Host code only (no kernel of its own); its own library so that libfmd_hip.so does not need RCCL.
+ * Host code (its one kernel is a measurement aid: fmd_gather_debug_emulate_peers); its own library so that
+ * libfmd_hip.so does not need RCCL.
  *
  * Build: hipcc --offload-arch=gfx950 -O2 -fPIC -shared fmd_gather.hip -o libfmd_gather.so
  *        -L.. -lfmd_hip -lrccl
@@ -42,6 +43,23 @@ int gfail(int code, const std::string& msg)
 
 static_assert(sizeof(ncclUniqueId) == FMD_GATHER_ID_BYTES, "ncclUniqueId size");
 
+#ifdef __HIPCC__
+/* fmd_gather_debug_emulate_peers: the stores of `peers` receives -- workgroup w of peer p fills its share of that
+ * peer's n16 16-byte words (audio) and, the peer's first workgroup, of its record words. */
+__global__ __launch_bounds__(512) void k_emulate_recv(float4* audio, size_t audio16_per_rank, int4* rds,
+                                                      size_t rds16_per_rank, unsigned wgs_per_peer, unsigned tag)
+{
+  const unsigned p = blockIdx.x / wgs_per_peer + 1u, w = blockIdx.x % wgs_per_peer;
+  float4* a = audio + size_t(p) * audio16_per_rank;
+  const float v = __uint_as_float(0x3f000000u | (tag & 0xffffu));
+  for (size_t i = size_t(w) * 512 + threadIdx.x; i < audio16_per_rank; i += size_t(wgs_per_peer) * 512)
+    a[i] = make_float4(v, v, v, v);
+  if (w == 0)
+    for (size_t i = threadIdx.x; i < rds16_per_rank; i += 512)
+      rds[size_t(p) * rds16_per_rank + i] = make_int4(0, 0, 0, 0); // (no group: a zero row is padding)
+}
+#endif
+
 } // namespace
 
 struct fmd_gather
@@ -59,6 +77,8 @@ struct fmd_gather
   std::vector<hipEvent_t> t0, t1;  // timing of the steps since the last query (a ring of kTimed pairs)
   size_t timed = 0;
   double* d_word = nullptr;        // the barrier's all-reduce
+  bool failed = false;             // a step's send / receive failed: the communicator is in an unknown state
+  int emu_peers = 0, emu_wgs = 2;  // fmd_gather_debug_emulate_peers
 };
 
 extern "C" {
@@ -123,8 +143,8 @@ void fmd_gather_destroy(fmd_gather* g)
   (void)hipSetDevice(g->device);
   if (g->side)
     (void)hipStreamSynchronize(g->side);
-  if (g->comm)
-    (void)ncclCommDestroy(g->comm);
+  if (g->comm) // (after a failed step: abort -- a destroy would wait for the half-done collective)
+    (void)(g->failed ? ncclCommAbort(g->comm) : ncclCommDestroy(g->comm));
   for (auto e : g->t0)
     (void)hipEventDestroy(e);
   for (auto e : g->t1)
@@ -146,6 +166,9 @@ int fmd_gather_step(fmd_gather* g, fmd_batch* batch, int lag, unsigned channel_o
 {
   if (!g || !d_audio || !d_rds || (g->rank == 0 && (!d_all_audio || !d_all_rds)))
     return gfail(FMD_ERR_ARG, "fmd_gather_step: null buffer");
+  if (g->failed)
+    return gfail(FMD_ERR_STATE, "fmd_gather_step: an earlier step's send / receive failed -- the peers are inside a "
+                                "half-done step; tear the communicator down (fmd_gather_destroy) on every rank");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GHIP(hipSetDevice(g->device));
   int warn = FMD_OK;
@@ -194,12 +217,22 @@ int fmd_gather_step(fmd_gather* g, fmd_batch* batch, int lag, unsigned channel_o
           op(ncclRecv(d_all_rds + size_t(r) * rds_ints, rds_ints, ncclInt32, r, g->comm, g->side), "ncclRecv(rds)");
       }
     if (r_ != ncclSuccess)
-    {
+    { // the group still issues what was queued before the failure: this step is incomplete on some peer.  No later
+      // step is taken (the caller tears the communicator down: fmd_gather_destroy aborts it), and the step's open
+      // timing pair is dropped (t0 without t1)
       (void)ncclGroupEnd();
-      return gfail(FMD_ERR_DEVICE, std::string(what) + ": " + ncclGetErrorString(r_));
+      g->failed = true;
+      return gfail(FMD_ERR_DEVICE, std::string(what) + ": " + ncclGetErrorString(r_) +
+                                       " (the gather takes no further steps; destroy it on every rank)");
     }
   }
   GNCCL(ncclGroupEnd());
+#ifdef __HIPCC__
+  if (g->emu_peers > 0) // measurement aid: what `emu_peers` receives would write (world of one)
+    hipLaunchKernelGGL(k_emulate_recv, dim3(unsigned(g->emu_peers * g->emu_wgs)), dim3(512), 0, g->side,
+                       reinterpret_cast<float4*>(d_all_audio), g->audio_floats / 4, reinterpret_cast<int4*>(d_all_rds),
+                       size_t(g->rds_rows), unsigned(g->emu_wgs), unsigned(g->issued));
+#endif
   if (g->rank == 0)
   { // rank 0's own outputs: a device copy, on the same stream -- unless the caller had them produced in place
     // (d_audio == d_all_audio: 88 MB per step at 8192 channels that need not be read and written again)
@@ -261,6 +294,23 @@ float fmd_gather_ms_per_step(fmd_gather* g)
   const float mean = float(sum / double(n));
   g->timed = 0;
   return mean;
+}
+
+int fmd_gather_debug_emulate_peers(fmd_gather* g, int peers, int workgroups_per_peer)
+{
+  if (!g || peers < 0 || peers > 63 || workgroups_per_peer < 1 || workgroups_per_peer > 64)
+    return gfail(FMD_ERR_ARG, "fmd_gather_debug_emulate_peers: bad argument");
+  if (g->world != 1)
+    return gfail(FMD_ERR_STATE, "fmd_gather_debug_emulate_peers: a world of one only (real peers send real data)");
+  if (g->audio_floats % 4)
+    return gfail(FMD_ERR_ARG, "fmd_gather_debug_emulate_peers: audio_floats must be a multiple of 4");
+#ifndef __HIPCC__
+  if (peers)
+    return gfail(FMD_ERR_STATE, "fmd_gather_debug_emulate_peers: built without device code");
+#endif
+  g->emu_peers = peers;
+  g->emu_wgs = workgroups_per_peer;
+  return FMD_OK;
 }
 
 int fmd_gather_info(fmd_gather* g, fmd_gather_info_t* out)

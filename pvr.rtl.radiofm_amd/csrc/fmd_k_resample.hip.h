@@ -197,20 +197,31 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ br,
 constexpr int RSR_ROWS = 96;    // rows a workgroup can hold in registers for the next step
 constexpr int RSR_HEAD = 4 + 4; // ints per group header: top batch, batches, ring offset, -, pidx[R]
 
-template <int R>
+// (FMA: every multiply / add pair fused -- FMD_FIR_FMA_PARITY_WAIVED, the form that is measured against the
+// parity mode; two outputs per wave only)
+template <int R, bool FMA = false>
 __device__ __forceinline__ void rs_walk_asm(fmd_f2v (&acc)[R], unsigned& off, unsigned& cnt, unsigned lane16,
                                             unsigned wrap, unsigned klo, unsigned khi, unsigned kinc);
 template <>
-__device__ __forceinline__ void rs_walk_asm<4>(fmd_f2v (&acc)[4], unsigned& off, unsigned& cnt, unsigned lane16,
-                                               unsigned wrap, unsigned klo, unsigned khi, unsigned kinc)
+__device__ __forceinline__ void rs_walk_asm<4, false>(fmd_f2v (&acc)[4], unsigned& off, unsigned& cnt,
+                                                      unsigned lane16, unsigned wrap, unsigned klo, unsigned khi,
+                                                      unsigned kinc)
 {
 #include "fmd_rs_walk_r4.inc"
 }
 template <>
-__device__ __forceinline__ void rs_walk_asm<2>(fmd_f2v (&acc)[2], unsigned& off, unsigned& cnt, unsigned lane16,
-                                               unsigned wrap, unsigned klo, unsigned khi, unsigned kinc)
+__device__ __forceinline__ void rs_walk_asm<2, false>(fmd_f2v (&acc)[2], unsigned& off, unsigned& cnt,
+                                                      unsigned lane16, unsigned wrap, unsigned klo, unsigned khi,
+                                                      unsigned kinc)
 {
 #include "fmd_rs_walk_r2.inc"
+}
+template <>
+__device__ __forceinline__ void rs_walk_asm<2, true>(fmd_f2v (&acc)[2], unsigned& off, unsigned& cnt,
+                                                     unsigned lane16, unsigned wrap, unsigned klo, unsigned khi,
+                                                     unsigned kinc)
+{
+#include "fmd_rs_walk_r2_fma.inc"
 }
 
 template <int R, int NW>
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(64) void k_rs_plan(const float* __restrict__ coeff,
   }
 }
 
-template <int R, int RSR_NW>
+template <int R, int RSR_NW, bool FMA = false>
 __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
     const float2* __restrict__ br, unsigned Hbb, int RB, unsigned order, const float* __restrict__ tab,
     unsigned nbm, const int* __restrict__ head, const int* __restrict__ steptab, unsigned nsteps,
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
         unsigned off = (unsigned)h[2], cnt = (unsigned)nb >> 1;
         const uint64_t ka = reinterpret_cast<uint64_t>(kp);
         // (the low half of a generic LDS pointer is the LDS byte address)
-        rs_walk_asm<R>(acc, off, cnt, (unsigned)(size_t)rsr_smem + lane * 16u, (NBR - 1u) * 4096u, (unsigned)ka,
+        rs_walk_asm<R, FMA>(acc, off, cnt, (unsigned)(size_t)rsr_smem + lane * 16u, (NBR - 1u) * 4096u, (unsigned)ka,
                        (unsigned)(ka >> 32), 32u * R);
       }
       else
@@ -495,8 +506,16 @@ __global__ __launch_bounds__(64 * (RSR_NW + 1)) void k_resample_ring(
               if (j >= 0 && j <= (int)order)
               {
                 const float k = kp[(size_t)b * (8 * R) + q * R + r];
-                acc[r].x += k * x.x;
-                acc[r].y += k * x.y;
+                if (FMA)
+                {
+                  acc[r].x = __builtin_fmaf(k, x.x, acc[r].x);
+                  acc[r].y = __builtin_fmaf(k, x.y, acc[r].y);
+                }
+                else
+                {
+                  acc[r].x += k * x.x;
+                  acc[r].y += k * x.y;
+                }
               }
             }
           }

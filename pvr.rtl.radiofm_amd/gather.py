@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libfmd_gather.so")
 ID_BYTES = 128
 EXPORTS = ["fmd_gather_last_error", "fmd_gather_unique_id", "fmd_gather_create", "fmd_gather_destroy",
            "fmd_gather_step", "fmd_gather_wait", "fmd_gather_wait_lagged", "fmd_gather_barrier",
-           "fmd_gather_ms_per_step", "fmd_gather_info"]
+           "fmd_gather_ms_per_step", "fmd_gather_info", "fmd_gather_debug_emulate_peers"]
 _LIB = None
 
 
@@ -37,6 +37,7 @@ def lib():
         L.fmd_gather_ms_per_step.restype = C.c_float
         L.fmd_gather_ms_per_step.argtypes = [vp]
         L.fmd_gather_info.argtypes = [vp, C.POINTER(GatherInfo)]
+        L.fmd_gather_debug_emulate_peers.argtypes = [vp, i, i]
         _LIB = L
     return _LIB
 
@@ -97,6 +98,10 @@ class Gather:
     def ms_per_step(self):
         v = lib().fmd_gather_ms_per_step(self._h)
         return None if v < 0 else float(v)
+
+    def emulate_peers(self, peers, workgroups_per_peer=2):
+        """Measurement aid (world of one): every step also writes what `peers` more ranks' receives would write."""
+        _check(lib().fmd_gather_debug_emulate_peers(self._h, int(peers), int(workgroups_per_peer)))
 
     def info(self):
         """What the communicator itself reports: ranks_seen (ncclCommCount), rank, device, steps issued."""

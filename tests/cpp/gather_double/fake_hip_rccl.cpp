@@ -409,6 +409,13 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int world, ncclUniqueId id, int r
 {
   if (world < 1 || world > kMaxRanks || rank < 0 || rank >= world)
     return ncclInvalidArgument;
+  { // FAKE_RCCL_STALL_INIT=<rank>: that rank's bootstrap never returns on the first attempt (tests of the restart)
+    const char* stall = getenv("FAKE_RCCL_STALL_INIT");
+    const char* attempt = getenv("FAKE_RCCL_ATTEMPT");
+    if (stall && atoi(stall) == rank && !(attempt && attempt[0] == '1'))
+      for (;;)
+        pause();
+  }
   ncclComm* c = new ncclComm;
   c->rank = rank;
   c->world = world;
@@ -435,6 +442,20 @@ ncclResult_t ncclCommDestroy(ncclComm_t c)
 {
   if (g_depth)
     die("ncclCommDestroy with a group left open");
+  if (c->sh->alive.fetch_sub(1) == 1)
+    shm_unlink(c->name);
+  munmap(c->sh, sizeof(Shared));
+  delete c;
+  return ncclSuccess;
+}
+static int g_aborts = 0;
+extern "C" int fake_rccl_aborts(void)
+{
+  return g_aborts;
+}
+ncclResult_t ncclCommAbort(ncclComm_t c)
+{ // what a caller does with a communicator whose last collective is incomplete: no check of open groups
+  g_aborts++;
   if (c->sh->alive.fetch_sub(1) == 1)
     shm_unlink(c->name);
   munmap(c->sh, sizeof(Shared));

@@ -10,6 +10,10 @@
  *   world_n <ranks> <steps>          exit code 0 = every rank succeeded
  *   FAKE_RCCL_FAIL_RECV=1 world_n 2 1    rank 0's first receive fails: the step must report it and leave no
  *                                        group open
+ *   FAKE_RCCL_STALL_INIT=<rank> WORLD_N_UP_TIMEOUT=2 world_n 3 8
+ *                                        that rank's first ncclCommInitRank never returns (the pool's stalled
+ *                                        bootstrap): the parent (tools/rank_supervisor.hpp, what tools/node_bench
+ *                                        uses) ends all ranks and starts them again, once; the run then completes
  */
 #include <signal.h>
 #include <sys/mman.h>
@@ -22,8 +26,10 @@
 #include <vector>
 
 #include "../../../include/fmd_gather.h"
+#include "../../../tools/rank_supervisor.hpp"
 
 extern "C" int fake_rccl_group_depth(void);
+extern "C" int fake_rccl_aborts(void);
 extern "C" int hipStreamCreateWithFlags(void**, unsigned);
 extern "C" int hipStreamSynchronize(void*);
 extern "C" int hipMemcpyAsync(void*, const void*, size_t, int, void*);
@@ -58,13 +64,19 @@ static int32_t rds_value(int r, int step, size_t k)
   return int32_t((r << 24) | (step << 12) | int(k & 0xFFF));
 }
 
-static int rank_main(int rank, int world, int steps, const uint8_t* id, bool expect_failure)
+static int rank_main(int rank, int world, int steps, const uint8_t* id, bool expect_failure, int attempt, int up_fd)
 {
+  setenv("FAKE_RCCL_ATTEMPT", attempt ? "1" : "0", 1); // (the double's stalling ncclCommInitRank reads it)
   const size_t AFL = 50021; // floats per rank and step: larger than the double's rings, not a round number
   const unsigned ROWS = 37;
   const int NBUF = 6;
   fmd_gather* g = nullptr;
   CHECK(fmd_gather_create(id, rank, world, rank, AFL, ROWS, &g) == FMD_OK);
+  {
+    const char u = 'U';
+    (void)!write(up_fd, &u, 1);
+    close(up_fd);
+  }
   fmd_gather_info_t inf;
   CHECK(fmd_gather_info(g, &inf) == FMD_OK);
   CHECK(inf.ranks_seen == world && inf.rank == rank && inf.world_asked == world && inf.steps_issued == 0);
@@ -131,6 +143,11 @@ static int rank_main(int rank, int world, int steps, const uint8_t* id, bool exp
     {
       CHECK(rc < 0 && strstr(fmd_gather_last_error(), "ncclRecv") != nullptr);
       CHECK(fake_rccl_group_depth() == 0); // the failed step closed its group
+      // ... and the gather takes no further step (its peers are inside a half-done one); destroy aborts
+      const int rc2 = fmd_gather_step(g, nullptr, 0, 0, &audio[0], &rds[0], &all_a[0], &all_r[0], st);
+      CHECK(rc2 == FMD_ERR_STATE && strstr(fmd_gather_last_error(), "tear the communicator down") != nullptr);
+      fmd_gather_destroy(g);
+      CHECK(fake_rccl_aborts() == 1);
       _exit(0);
     }
     CHECK(rc >= 0);
@@ -158,32 +175,17 @@ int main(int argc, char** argv)
 {
   const int world = argc > 1 ? atoi(argv[1]) : 2, steps = argc > 2 ? atoi(argv[2]) : 40;
   const bool expect_failure = getenv("FAKE_RCCL_FAIL_RECV") != nullptr;
-  uint8_t id[FMD_GATHER_ID_BYTES];
-  if (fmd_gather_unique_id(id) != FMD_OK) // (the double's id is a name: made before the ranks exist)
+  uint8_t id[2][FMD_GATHER_ID_BYTES]; // (the double's id is a name: made before the ranks exist; one per attempt)
+  if (fmd_gather_unique_id(id[0]) != FMD_OK || (usleep(1000), fmd_gather_unique_id(id[1])) != FMD_OK)
     return 2;
-  std::vector<pid_t> kids;
-  for (int r = 0; r < world; r++)
-  {
-    const pid_t p = fork();
-    if (p == 0)
-    {
-      alarm(120); // no rank outlives two minutes, whatever happens to its parent
-      _exit(rank_main(r, world, steps, id, expect_failure));
-    }
-    kids.push_back(p);
-  }
-  int bad = 0;
-  for (size_t left = kids.size(); left; left--)
-  { // a rank that fails leaves its peers waiting for it: end them (by pid) instead of hanging
-    int st = 0;
-    const pid_t p = wait(&st);
-    if (p < 0)
-      break;
-    if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0) && !bad++)
-      for (pid_t k : kids)
-        if (k != p)
-          kill(k, SIGKILL);
-  }
-  shm_unlink(reinterpret_cast<const char*>(id)); // (ranks that left through _exit did not remove the double's segment)
+  const int up_timeout = getenv("WORLD_N_UP_TIMEOUT") ? atoi(getenv("WORLD_N_UP_TIMEOUT")) : 60;
+  int attempts = 0;
+  const int bad = fmd_launch::run_ranks(
+      world, up_timeout, 120,
+      [&](int r, int attempt, int up_fd) { return rank_main(r, world, steps, id[attempt], expect_failure, attempt, up_fd); },
+      &attempts);
+  fprintf(stderr, "world_n: attempts %d\n", attempts);
+  shm_unlink(reinterpret_cast<const char*>(id[1]));
+  shm_unlink(reinterpret_cast<const char*>(id[0])); // (ranks that left through _exit did not remove the double's segment)
   return bad ? 1 : 0;
 }

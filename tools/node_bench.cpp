@@ -4,7 +4,8 @@
  * over RCCL (include/fmd_gather.h).  The same loop as bench.py's (calls overlapped, outputs consumed
  * LAG steps late), same JSON keys; bench.py stays the driver's entry point.
  *
- *   tools/node_bench --gpus N [--steps K] [--warmup W] [--channels C] [--watchdog seconds] [--verify]
+ *   tools/node_bench --gpus N [--steps K] [--warmup W] [--channels C] [--watchdog seconds] [--up-timeout seconds]
+ *                    [--verify]
  *
  * The parent forks the N ranks BEFORE anything touches HIP; rank 0 writes the communicator's id into a
  * file the others wait for.  Build: make -C pvr.rtl.radiofm_amd/csrc ../../tools/node_bench
@@ -23,6 +24,7 @@
 #include <vector>
 
 #include "../include/fmd_gather.h"
+#include "rank_supervisor.hpp"
 #include "fmsig.h"
 #include "fmsig_core.h"
 
@@ -46,7 +48,7 @@ static void make_station(double fs, unsigned g, fmsig_chan* ch, uint8_t* dbits)
   fmsig_rds_dbits(&p, dbits);
 }
 
-static int rank_main(int rank, int world, int K, int W, unsigned C, const std::string& idfile, bool verify)
+static int rank_main(int rank, int world, int K, int W, unsigned C, const std::string& idfile, bool verify, int up_fd)
 {
   const double fs = 2.4e6;
   const unsigned N = 65536, D = 11, RING = 10, LAG = 3, NBUF = LAG + 3;
@@ -68,6 +70,20 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
     CHECK(f && fread(id, 1, sizeof id, f) == sizeof id);
     fclose(f);
   }
+  // the decoder and the communicator first: the parent waits for "communicator up" (rank_supervisor.hpp)
+  fmd_params par{fs, -0.15 * fs, 48000.0, 15000.0, D, 0, 0, 0, FMD_FIR_SEQUENTIAL};
+  fmd_batch* b = nullptr;
+  CHECK(fmd_batch_create(&par, C, nullptr, rank, nullptr, nullptr, &b) == FMD_OK);
+  CHECK(fmd_batch_set_concurrency(b, 2) == FMD_OK);
+  const size_t stride = (fmd_batch_max_audio_floats(b, N) + 63) / 64 * 64, afl = stride * C;
+  fmd_gather* g = nullptr;
+  CHECK(fmd_gather_create(id, rank, world, rank, afl, C, &g) == FMD_OK);
+  if (up_fd >= 0)
+  { // the communicator is up: tell the parent (tools/rank_supervisor.hpp starts all ranks over when one never does)
+    const char u = 'U';
+    (void)!write(up_fd, &u, 1);
+    close(up_fd);
+  }
   // stations rank * C .. rank * C + C - 1 (tools/fmsig_py.channel_params), generated on the device
   std::vector<fmsig_chan> ch(C);
   std::vector<uint8_t> dbits(size_t(C) * FMSIG_RDS_PERIOD_BITS);
@@ -83,16 +99,10 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
     CHECK(fmsig_device_generate(d_ch, d_bits, FMSIG_RDS_PERIOD_BITS, C, uint64_t(r) * N, N, iq + size_t(r) * C * N * 2, N, nullptr) == 0);
   CHECK(hipDeviceSynchronize() == hipSuccess);
 
-  fmd_params par{fs, -0.15 * fs, 48000.0, 15000.0, D, 0, 0, 0, FMD_FIR_SEQUENTIAL};
-  fmd_batch* b = nullptr;
-  CHECK(fmd_batch_create(&par, C, nullptr, rank, nullptr, nullptr, &b) == FMD_OK);
-  CHECK(fmd_batch_set_concurrency(b, 2) == FMD_OK);
-  const size_t stride = (fmd_batch_max_audio_floats(b, N) + 63) / 64 * 64, afl = stride * C;
-  fmd_gather* g = nullptr;
-  CHECK(fmd_gather_create(id, rank, world, rank, afl, C, &g) == FMD_OK);
-  float *audio, *all_a = nullptr;
-  int32_t *rds, *all_r = nullptr;
-  CHECK(hipMalloc(reinterpret_cast<void**>(&audio), NBUF * afl * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&rds), size_t(NBUF) * C * 16) == hipSuccess);
+  float *audio = nullptr, *all_a = nullptr;
+  int32_t *rds = nullptr, *all_r = nullptr;
+  if (rank != 0) // (rank 0's outputs are produced in place, in its part of the receive buffers: audio_of / rds_of)
+    CHECK(hipMalloc(reinterpret_cast<void**>(&audio), NBUF * afl * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&rds), size_t(NBUF) * C * 16) == hipSuccess);
   if (rank == 0)
     CHECK(hipMalloc(reinterpret_cast<void**>(&all_a), size_t(NBUF) * world * afl * 4) == hipSuccess &&
           hipMalloc(reinterpret_cast<void**>(&all_r), size_t(NBUF) * world * C * 16) == hipSuccess);
@@ -240,7 +250,10 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
     vjson = "{\"steps\": " + std::to_string(verified_steps) + ", \"ranks\": " + std::to_string(world) + ", \"per_rank_ok\": [";
     for (int r = 0; r < world; r++)
       vjson += std::string(r ? ", " : "") + (rank_ok[size_t(r)] ? "true" : "false");
-    vjson += "], \"ok\": true}";
+    bool all_ok = true;
+    for (int r = 0; r < world; r++)
+      all_ok = all_ok && rank_ok[size_t(r)] != 0;
+    vjson += std::string("], \"ok\": ") + (all_ok ? "true" : "false") + "}";
   }
   if (rank == 0)
     printf("{\"metric\": \"IQ MS/s demodulated (whole node) + achieved HBM GB/s on FIR stage\", \"value\": %.1f, \"unit\": \"MS/s\", "
@@ -261,6 +274,7 @@ int main(int argc, char** argv)
   unsigned C = 8192;
   bool verify = false;
   unsigned watchdog = 900; // seconds after which a rank ends itself (a stalled RCCL bootstrap must not hang the node)
+  int up_timeout = 60;     // seconds for every rank's communicator to be up, else all ranks are started again, once
   for (int i = 1; i < argc; i++)
     if (std::string(argv[i]) == "--verify")
     { // a flag without a value: take it out of the key / value pairs
@@ -278,28 +292,24 @@ int main(int argc, char** argv)
     else if (k == "--warmup") W = atoi(argv[i + 1]);
     else if (k == "--channels") C = unsigned(atoi(argv[i + 1]));
     else if (k == "--watchdog") watchdog = unsigned(atoi(argv[i + 1]));
+    else if (k == "--up-timeout") up_timeout = atoi(argv[i + 1]);
   }
   const std::string idfile = "/tmp/fmd_node_bench_" + std::to_string(getpid()) + ".id";
   setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); // dmabuf IPC: what RCCL needs on this pool
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);
-  std::vector<pid_t> kids;
-  for (int r = 0; r < gpus; r++) // before anything touches HIP
+  // The ranks are forked before anything touches HIP; when not every one of them has its communicator up after
+  // `up_timeout` seconds (a stalled RCCL bootstrap: ~1 launch in 20 on this pool), all of them are ended and started
+  // again, once, with a fresh id file (tools/rank_supervisor.hpp).
+  int attempts = 0;
+  const int worst = fmd_launch::run_ranks(
+      gpus, up_timeout, watchdog,
+      [&](int r, int attempt, int up_fd) {
+        return rank_main(r, gpus, K, W, C, idfile + "." + std::to_string(attempt), verify, up_fd);
+      },
+      &attempts);
+  for (int a = 0; a < attempts; a++)
   {
-    const pid_t p = fork();
-    if (p == 0)
-    {
-      alarm(watchdog);
-      _exit(rank_main(r, gpus, K, W, C, idfile, verify));
-    }
-    kids.push_back(p);
+    unlink((idfile + "." + std::to_string(a)).c_str());
+    unlink((idfile + "." + std::to_string(a) + ".tmp").c_str());
   }
-  int worst = 0;
-  for (pid_t p : kids)
-  {
-    int st = 0;
-    waitpid(p, &st, 0);
-    worst |= !(WIFEXITED(st) && WEXITSTATUS(st) == 0);
-  }
-  unlink(idfile.c_str());
   return worst;
 }

@@ -17,7 +17,7 @@ import sys
 import threading
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES left at HIP's default, like bench.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--channels", type=int, default=8192)
     ap.add_argument("--fir-variants", action="store_true")
     ap.add_argument("--alt-forms", action="store_true")
+    ap.add_argument("--fma", action="store_true",
+                    help="the parity-waived fused multiply-add form (FMD_FIR_FMA_PARITY_WAIVED) instead of the parity mode")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"])
     args = ap.parse_args()
     import numpy as np  # noqa: F401
@@ -61,7 +63,8 @@ def main():
     iq = torch.empty((RING, C, N, 2), dtype=torch.uint8 if u8 else torch.float32, device=dev)
     for r in range(RING):
         gen.generate(iq[r], r * N, N)
-    b = pkg.Batch(pkg.make_params(FS, -0.15 * FS, 48000.0, 15000.0, D), C, record_callbacks=False)
+    b = pkg.Batch(pkg.make_params(FS, -0.15 * FS, 48000.0, 15000.0, D,
+                                  fir_reduction=pkg.FIR_FMA_PARITY_WAIVED if args.fma else 0), C, record_callbacks=False)
     b.set_concurrency(2)
     a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
     audio = [torch.zeros((C, a_stride), dtype=torch.float32, device=dev) for _ in range(NBUF)]
