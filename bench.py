@@ -400,11 +400,22 @@ def main():
                          "On by default with more than one rank (a multi-GPU number is only reported for "
                          "a gather that was checked); --no-verify turns it off")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--gather-root", default="0", choices=["0", "rotate"],
+                    help="N > 1, RCCL data path: which rank receives a step's outputs -- 0: rank 0, every step (default); "
+                         "rotate: step i goes to rank i %% N (fmd_gather_step_root): rank 0 alone would take 7 x 88 MB "
+                         "of writes per step at 8 GPUs, 8-10 %% of its throughput (emulated: docs/MEASUREMENTS.md)")
     ap.add_argument("--emulate-peers", type=int, default=0, metavar="P",
                     help="sizing of rank 0 on one GPU (with FMD_BENCH_FORCE_DIST=1, a world of one): every step's gather "
                          "also writes what P more ranks' receives would write into rank 0's buffers "
                          "(fmd_gather_debug_emulate_peers)")
     ap.add_argument("--emulate-wgs", type=int, default=2, help="workgroups per emulated peer")
+    ap.add_argument("--emulate-role", default="root", choices=["root", "sender", "rotate"],
+                    help="which rank of a P + 1 rank node this GPU plays: the root of every step (rank 0 of the "
+                         "fixed-root gather), a sender in every step (its message read once per step), or a rank of a "
+                         "rotating root (receives in every (P+1)-th step, sends otherwise)")
+    ap.add_argument("--emulate-peer-channels", type=int, default=0,
+                    help="channels each emulated peer's message is sized for (default: --channels); rank 0 of an "
+                         "unequal split decodes fewer channels than every peer sends")
     ap.add_argument("--side-stream", action="store_true",
                     help="development: submit from a non-default torch stream (the null stream orders itself "
                          "against every blocking stream of the process)")
@@ -578,6 +589,7 @@ def main():
     NBUF = args.lag + 3  # outputs are consumed LAG steps after they are produced, then gathered
     audio = [torch.zeros((C, a_stride), dtype=torch.float32, device=dev) for _ in range(NBUF)]
     RCAP = C  # RDS records per rank per step (a group takes 87.6 ms, a step 27.3 ms: <= 1 per channel)
+    CMSG = max(C, args.emulate_peer_channels) if emu_peers else C  # channels a rank's gather message is sized for
     rds_dev = [torch.zeros((RCAP, 4), dtype=torch.int32, device=dev) for _ in range(NBUF)]
     # N > 1 (and --verify): the RDS groups of a step leave the decoder as fixed-size records in device
     # memory (fmd_batch_export_rds_device) and go into the gather as they are -- no host round trip.
@@ -585,18 +597,28 @@ def main():
     # group decoder would.
     use_export = dist_on or args.verify
     g_audio = g_rds = None
-    if rank == 0 and (dist_on or args.verify):
+    rotate = args.gather_root == "rotate" and dist_on and backend == "nccl"
+
+    def root_of(i):
+        return i % world if rotate else 0
+
+    audio_own, rds_own = audio, rds_dev  # (a root's outputs are produced in place: see below)
+    if (rank == 0 or rotate) and (dist_on or args.verify):
         on = dev if (backend == "nccl" or not dist_on) else "cpu"
         # one tensor per slot, [world][...]: g_audio[slot][r] is rank r's part (the C++ gather writes at
         # rank * size; torch.distributed.gather takes the list of the parts)
         # (--emulate-peers P, world of one: room for the P ranks whose receives are emulated)
-        g_audio = [torch.empty((world + emu_peers, C, a_stride), dtype=torch.float32, device=on) for _ in range(NBUF)]
-        g_rds = [torch.zeros((world + emu_peers, RCAP, 4), dtype=torch.int32, device=on) for _ in range(NBUF)]
+        # (--emulate-peer-channels: the emulated peers' messages are sized for that many channels each -- rank 0 of an
+        # unequal split decodes fewer channels than it receives per peer; its own part of the buffers is then larger
+        # than what it fills)
+        g_audio = [torch.empty((world + emu_peers, CMSG, a_stride), dtype=torch.float32, device=on) for _ in range(NBUF)]
+        g_rds = [torch.zeros((world + emu_peers, CMSG, 4), dtype=torch.int32, device=on) for _ in range(NBUF)]
         if on == dev and backend == "nccl" and dist_on:
             # rank 0 has its own outputs produced IN PLACE, in its part of the receive buffers: the gather then has
             # nothing to copy for it (fmd_gather_step: d_audio == d_all_audio), 88 MB per step less through HBM
-            audio = [g[0] for g in g_audio]
-            rds_dev = [g[0] for g in g_rds]
+            # (a rotating root: rank r's part is the r-th, and it is used in the steps r is the root of)
+            audio = [g[rank][:C] for g in g_audio]
+            rds_dev = [g[rank][:RCAP] for g in g_rds]
             for t in rds_dev:
                 t.zero_()
     # RCCL: the data path is the C++ gather of include/fmd_gather.h (grouped ncclSend / ncclRecv on a
@@ -608,11 +630,12 @@ def main():
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(gmod.unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, src=0)
-        gth = gmod.Gather(bytes(uid.cpu().numpy().tobytes()), rank, world, local_rank, C * a_stride, RCAP)
+        gth = gmod.Gather(bytes(uid.cpu().numpy().tobytes()), rank, world, local_rank, CMSG * a_stride, CMSG)
         dist.barrier()  # every rank's communicator is up, or none says so
         _report("up")
         if emu_peers:
             gth.emulate_peers(emu_peers, args.emulate_wgs)
+            gth.emulate_role({"root": 1, "sender": 0, "rotate": emu_peers + 1}[args.emulate_role])
     group_acc = torch.zeros((), dtype=torch.int64, device=dev)  # groups counted on the device
     stream = torch.cuda.current_stream().cuda_stream
     pending = [None] * NBUF
@@ -638,9 +661,12 @@ def main():
         if gth is not None:
             # export of the RDS records (on the torch stream) + the step's sends / receives (on the
             # library's stream, behind the torch stream as it stands now): one C call
-            pending[slot] = ("ticket", gth.step(batch, lag, rank * C, audio[slot].data_ptr(), rds_dev[slot].data_ptr(),
-                                                g_audio[slot].data_ptr() if rank == 0 else None,
-                                                g_rds[slot].data_ptr() if rank == 0 else None, stream))
+            root = root_of(i)
+            a_buf, r_buf = out_bufs(i)
+            pending[slot] = ("ticket", gth.step(batch, lag, rank * C, a_buf.data_ptr(), r_buf.data_ptr(),
+                                                g_audio[slot].data_ptr() if rank == root else None,
+                                                g_rds[slot].data_ptr() if rank == root else None, stream, root=root),
+                             root)
         elif use_export:
             batch.export_rds_device(rds_dev[slot].data_ptr(), RCAP, channel_offset=rank * C,
                                     stream=stream, lag=lag)
@@ -661,13 +687,21 @@ def main():
             group_acc.add_((rds_dev[slot][:, 0] != 0).sum())
         state["finalized"] = i
 
+    def out_bufs(i):
+        """Where step i's audio and RDS records are produced: in this rank's part of its receive buffers in the steps
+        it is the root of (the gather then copies nothing for it), in buffers of its own otherwise."""
+        slot = i % NBUF
+        if rotate and rank != root_of(i):
+            return audio_own[slot], rds_own[slot]
+        return audio[slot], rds_dev[slot]
+
     def release(slot):
         """Before a slot's buffers are written again: its gather must have read them."""
         if pending[slot] is None:
             return
         if isinstance(pending[slot], tuple):  # the C++ gather: order the torch stream behind that step
             gth.wait_for(pending[slot][1], stream)
-            if rank == 0:
+            if rank == pending[slot][2]:  # the step's root counts what arrived
                 group_acc.add_((g_rds[slot][:, :, 0] != 0).sum())
         elif isinstance(pending[slot], list):
             for w in pending[slot]:
@@ -687,7 +721,7 @@ def main():
         release(slot)
         th0 = time.perf_counter()
         nf = batch.process_device(iq[i % ring].data_ptr(), (N if G > 1 else 0) if shared else N, N,
-                                  audio[slot].data_ptr(), a_stride, stream, u8=u8)
+                                  out_bufs(i)[0].data_ptr(), a_stride, stream, u8=u8)
         host_t["process"] += time.perf_counter() - th0
         state["submitted"] = i
         if i - LAG > state["finalized"]:
@@ -744,7 +778,7 @@ def main():
         drain()
         base = V
         ok = 1.0
-        if rank == 0:
+        if rank == 0 or rotate:  # (a rotating root: every rank checks the steps it received)
             picks = sorted({0, 1, C // 2, C - 1})
             if shared:
                 vshifts = np.concatenate([shifts[picks] for _ in range(world)]).astype(np.int32)
@@ -775,6 +809,8 @@ def main():
                 vb.wait(stream=stream)
                 vg = vb.collect_rds_array(cap=4 * nv, stream=stream)
                 torch.cuda.synchronize()
+                if root_of(i) != rank:
+                    continue
                 want_a = vaudio[:, :vnf].cpu().numpy().view(np.uint32)
                 slot = i % NBUF
                 for r in range(world):
@@ -792,12 +828,16 @@ def main():
             vb.close()
             verify = {"steps": V, "channels_per_rank": picks, "ranks": world, "mismatches": bad,
                       "per_rank_ok": [not any(b[2] == r for b in bad) for r in range(world)],
-                      "ok": not bad}
+                      "ok": not bad, "gather_root": args.gather_root}
             ok = 0.0 if bad else 1.0
             if bad:
                 sys.stderr.write("bench.py --verify: MISMATCH %r\n" % (bad,))
         if dist_on:
             ok = reduce_scalar(ok, dist.ReduceOp.MIN)
+            if rotate:  # the roots' verdicts on every sender, combined
+                per = [reduce_scalar(1.0 if verify["per_rank_ok"][r] else 0.0, dist.ReduceOp.MIN) for r in range(world)]
+                verify["per_rank_ok"] = [p == 1.0 for p in per]
+                verify["ok"] = ok == 1.0
         if ok != 1.0:
             raise SystemExit(4)
 
@@ -830,7 +870,9 @@ def main():
             dt * 1e3, " ".join("%.2f" % t for t in ts),
             " ".join("%.2f" % (b - a) for a, b in zip([0.0] + ts[:-1], ts))))
     if use_export:
-        total_groups = int(group_acc.item())  # rank 0: groups that arrived from every rank
+        total_groups = int(group_acc.item())  # the root: groups that arrived from every rank
+        if rotate:  # every rank was the root of every world-th step
+            total_groups = int(reduce_scalar(float(total_groups), dist.ReduceOp.SUM))
     serial_probe = None
     if "serial_probe=1" in args.debug_set:  # dev aid: per-workgroup timing of the serial stage
         pr = batch.debug_serial_probe()
@@ -981,10 +1023,12 @@ def main():
                        "audio_floats_per_channel_step": nf, "rds_groups_in_timed_region": total_groups,
                        "gather": ("rank-0 gather of audio + RDS records per step over %s (%d rank%s)"
                                   % ("RCCL, grouped ncclSend / ncclRecv from C++ (include/fmd_gather.h)"
-                                     if backend == "nccl" else backend, world, "" if world == 1 else "s"))
+                                     if backend == "nccl" else backend, world, "" if world == 1 else "s")
+                                  + ("; the root rotates: step i to rank i % N" if rotate else ""))
                        if dist_on else "none (1 GPU)",
                        "emulated_peers": ({"peers": emu_peers, "workgroups_per_peer": args.emulate_wgs,
-                                           "bytes_written_per_step": emu_peers * (C * a_stride * 4 + RCAP * 16),
+                                           "channels_per_peer": CMSG, "role": args.emulate_role,
+                                           "bytes_written_per_step": emu_peers * (CMSG * a_stride * 4 + CMSG * 16),
                                            "note": "sizing aid: what that many ranks' receives would write into "
                                                    "rank 0's buffers, every step, on the gather's stream"}
                                           if emu_peers else None),

@@ -55,6 +55,15 @@ void fmd_gather_destroy(fmd_gather* g);
 int fmd_gather_step(fmd_gather* g, fmd_batch* batch, int lag, unsigned channel_offset, const float* d_audio,
                     int32_t* d_rds, float* d_all_audio, int32_t* d_all_rds, void* stream);
 
+/* The same step with rank `root` as its receiver (every rank passes the same root for the same step; d_all_audio /
+ * d_all_rds are needed on that rank only; its own part is rank root's slot: in place when d_audio == d_all_audio +
+ * root * audio_floats).  A caller that rotates the root -- step i to rank i % world -- spreads what rank 0 alone
+ * would take: 7 x 88 MB of writes per step into one GPU's memory system at 8 GPUs, which costs that GPU 8-10 % of
+ * its throughput (emulated on one GPU, docs/MEASUREMENTS.md round 6) and with it the node, against ~1 % on every
+ * GPU.  Each rank then holds every world-th step's outputs of all channels. */
+int fmd_gather_step_root(fmd_gather* g, int root, fmd_batch* batch, int lag, unsigned channel_offset,
+                         const float* d_audio, int32_t* d_rds, float* d_all_audio, int32_t* d_all_rds, void* stream);
+
 /* Orders `stream` behind every step issued so far (before d_audio / d_rds / the receive buffers are
  * written again or read); _lagged: behind all but the `lag` (< 16) youngest -- a caller that rotates
  * its buffers waits only for the step that last used the one it is about to write. */
@@ -90,6 +99,12 @@ int fmd_gather_info(fmd_gather* g, fmd_gather_info_t* out);
  * (docs/MEASUREMENTS.md).  The bytes arrive as fast as the kernel can store them, not paced by
  * seven xGMI links: a burst, i.e. the contention of a step is concentrated, its joules are the same.  0 = off. */
 int fmd_gather_debug_emulate_peers(fmd_gather* g, int peers, int workgroups_per_peer);
+/* ... and, on top of it, which role this one GPU plays in a node of `world` = peers + 1 ranks: `every` = 1 the root of
+ * every step (rank 0 of a fixed-root gather: the default above); `every` = world a rank of a ROTATING root -- the
+ * receives of `peers` ranks in every world-th step, and in the others what a sender does to its own memory system: its
+ * message read once (audio_floats floats + the records, `workgroups_per_peer` workgroups); `every` = 0 a sender in
+ * every step (ranks 1 .. of a fixed-root gather). */
+int fmd_gather_debug_emulate_role(fmd_gather* g, int every);
 
 #ifdef __cplusplus
 }

@@ -380,7 +380,9 @@ namespace
 {
 
 constexpr unsigned kMaxProfCalls = 512;
-// channels of one batch with buffers of its own: 64 CUs' worth of the whole-CU serial stage (128 channels per CU)
+// channels of one batch with buffers of its own: 64 CUs' worth of the whole-CU serial stage (128 channels per CU), the
+// size the pipeline is balanced for.  (Measured, round 6: ONE batch of 8320 channels = 65 CUs still runs at the
+// 8192-channel rate, 8448 / 8704 / 9216 lose 10-13 % -- profiles/r6_f_*: no headroom above it worth a special case.)
 constexpr unsigned kSubBatchChannels = 8192;
 
 inline bool is_shell(const fmd_batch* b)

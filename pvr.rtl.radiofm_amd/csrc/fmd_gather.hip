@@ -58,6 +58,22 @@ __global__ __launch_bounds__(512) void k_emulate_recv(float4* audio, size_t audi
     for (size_t i = threadIdx.x; i < rds16_per_rank; i += 512)
       rds[size_t(p) * rds16_per_rank + i] = make_int4(0, 0, 0, 0); // (no group: a zero row is padding)
 }
+/* ... and a sender's share: its message read once (the bytes leave over xGMI, nothing is written locally) */
+__global__ __launch_bounds__(512) void k_emulate_send(const float4* audio, size_t audio16, unsigned* sink)
+{
+  float acc = 0.0f;
+  const size_t stride = size_t(gridDim.x) * 512;
+  size_t i = size_t(blockIdx.x) * 512 + threadIdx.x;
+  for (; i + 3 * stride < audio16; i += 4 * stride)
+  { // four loads in flight per lane: a few workgroups read at the rate a link can take
+    const float4 a = audio[i], b = audio[i + stride], c = audio[i + 2 * stride], d = audio[i + 3 * stride];
+    acc += a.x + b.y + c.z + d.w;
+  }
+  for (; i < audio16; i += stride)
+    acc += audio[i].x;
+  if (acc == 1.2345e38f) // never (keeps the loads)
+    *sink = 1u;
+}
 #endif
 
 } // namespace
@@ -79,6 +95,7 @@ struct fmd_gather
   double* d_word = nullptr;        // the barrier's all-reduce
   bool failed = false;             // a step's send / receive failed: the communicator is in an unknown state
   int emu_peers = 0, emu_wgs = 2;  // fmd_gather_debug_emulate_peers
+  int emu_every = 1;               // fmd_gather_debug_emulate_role: receives every n-th step (0: never), sends otherwise
 };
 
 extern "C" {
@@ -164,7 +181,15 @@ void fmd_gather_destroy(fmd_gather* g)
 int fmd_gather_step(fmd_gather* g, fmd_batch* batch, int lag, unsigned channel_offset, const float* d_audio,
                     int32_t* d_rds, float* d_all_audio, int32_t* d_all_rds, void* stream_)
 {
-  if (!g || !d_audio || !d_rds || (g->rank == 0 && (!d_all_audio || !d_all_rds)))
+  return fmd_gather_step_root(g, 0, batch, lag, channel_offset, d_audio, d_rds, d_all_audio, d_all_rds, stream_);
+}
+
+int fmd_gather_step_root(fmd_gather* g, int root, fmd_batch* batch, int lag, unsigned channel_offset,
+                         const float* d_audio, int32_t* d_rds, float* d_all_audio, int32_t* d_all_rds, void* stream_)
+{
+  if (!g || root < 0 || root >= g->world)
+    return gfail(FMD_ERR_ARG, "fmd_gather_step: null gather or root outside the world");
+  if (!d_audio || !d_rds || (g->rank == root && (!d_all_audio || !d_all_rds)))
     return gfail(FMD_ERR_ARG, "fmd_gather_step: null buffer");
   if (g->failed)
     return gfail(FMD_ERR_STATE, "fmd_gather_step: an earlier step's send / receive failed -- the peers are inside a "
@@ -204,14 +229,16 @@ int fmd_gather_step(fmd_gather* g, fmd_batch* batch, int lag, unsigned channel_o
       }
       return r_ == ncclSuccess;
     };
-    if (g->rank != 0)
+    if (g->rank != root)
     {
-      if (op(ncclSend(d_audio, g->audio_floats, ncclFloat, 0, g->comm, g->side), "ncclSend(audio)"))
-        op(ncclSend(d_rds, rds_ints, ncclInt32, 0, g->comm, g->side), "ncclSend(rds)");
+      if (op(ncclSend(d_audio, g->audio_floats, ncclFloat, root, g->comm, g->side), "ncclSend(audio)"))
+        op(ncclSend(d_rds, rds_ints, ncclInt32, root, g->comm, g->side), "ncclSend(rds)");
     }
     else
-      for (int r = 1; r < g->world && r_ == ncclSuccess; r++)
+      for (int r = 0; r < g->world && r_ == ncclSuccess; r++)
       {
+        if (r == root)
+          continue;
         if (op(ncclRecv(d_all_audio + size_t(r) * g->audio_floats, g->audio_floats, ncclFloat, r, g->comm, g->side),
                "ncclRecv(audio)"))
           op(ncclRecv(d_all_rds + size_t(r) * rds_ints, rds_ints, ncclInt32, r, g->comm, g->side), "ncclRecv(rds)");
@@ -228,18 +255,24 @@ int fmd_gather_step(fmd_gather* g, fmd_batch* batch, int lag, unsigned channel_o
   }
   GNCCL(ncclGroupEnd());
 #ifdef __HIPCC__
-  if (g->emu_peers > 0) // measurement aid: what `emu_peers` receives would write (world of one)
+  if (g->emu_peers > 0 && (g->emu_every == 0 || g->issued % uint64_t(g->emu_every) != 0))
+    hipLaunchKernelGGL(k_emulate_send, dim3(unsigned(8 * g->emu_wgs)), dim3(512), 0, g->side,
+                       reinterpret_cast<const float4*>(d_audio), g->audio_floats / 4,
+                       reinterpret_cast<unsigned*>(g->d_word));
+  else if (g->emu_peers > 0) // measurement aid: what `emu_peers` receives would write (world of one)
     hipLaunchKernelGGL(k_emulate_recv, dim3(unsigned(g->emu_peers * g->emu_wgs)), dim3(512), 0, g->side,
                        reinterpret_cast<float4*>(d_all_audio), g->audio_floats / 4, reinterpret_cast<int4*>(d_all_rds),
                        size_t(g->rds_rows), unsigned(g->emu_wgs), unsigned(g->issued));
 #endif
-  if (g->rank == 0)
-  { // rank 0's own outputs: a device copy, on the same stream -- unless the caller had them produced in place
-    // (d_audio == d_all_audio: 88 MB per step at 8192 channels that need not be read and written again)
-    if (d_all_audio != d_audio)
-      GHIP(hipMemcpyAsync(d_all_audio, d_audio, g->audio_floats * sizeof(float), hipMemcpyDeviceToDevice, g->side));
-    if (d_all_rds != d_rds)
-      GHIP(hipMemcpyAsync(d_all_rds, d_rds, rds_ints * sizeof(int32_t), hipMemcpyDeviceToDevice, g->side));
+  if (g->rank == root)
+  { // the root's own outputs: a device copy, on the same stream -- unless the caller had them produced in place
+    // (d_audio == its slot of d_all_audio: 88 MB per step at 8192 channels that need not be read and written again)
+    float* own_a = d_all_audio + size_t(root) * g->audio_floats;
+    int32_t* own_r = d_all_rds + size_t(root) * rds_ints;
+    if (own_a != d_audio)
+      GHIP(hipMemcpyAsync(own_a, d_audio, g->audio_floats * sizeof(float), hipMemcpyDeviceToDevice, g->side));
+    if (own_r != d_rds)
+      GHIP(hipMemcpyAsync(own_r, d_rds, rds_ints * sizeof(int32_t), hipMemcpyDeviceToDevice, g->side));
   }
   GHIP(hipEventRecord(g->t1[tslot], g->side));
   g->timed++;
@@ -310,6 +343,14 @@ int fmd_gather_debug_emulate_peers(fmd_gather* g, int peers, int workgroups_per_
 #endif
   g->emu_peers = peers;
   g->emu_wgs = workgroups_per_peer;
+  return FMD_OK;
+}
+
+int fmd_gather_debug_emulate_role(fmd_gather* g, int every)
+{
+  if (!g || every < 0 || every > 64)
+    return gfail(FMD_ERR_ARG, "fmd_gather_debug_emulate_role: bad argument");
+  g->emu_every = every;
   return FMD_OK;
 }
 

@@ -8,8 +8,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfmd_gather.so")
 ID_BYTES = 128
 EXPORTS = ["fmd_gather_last_error", "fmd_gather_unique_id", "fmd_gather_create", "fmd_gather_destroy",
-           "fmd_gather_step", "fmd_gather_wait", "fmd_gather_wait_lagged", "fmd_gather_barrier",
-           "fmd_gather_ms_per_step", "fmd_gather_info", "fmd_gather_debug_emulate_peers"]
+           "fmd_gather_step", "fmd_gather_step_root", "fmd_gather_wait", "fmd_gather_wait_lagged", "fmd_gather_barrier",
+           "fmd_gather_ms_per_step", "fmd_gather_info", "fmd_gather_debug_emulate_peers",
+           "fmd_gather_debug_emulate_role"]
 _LIB = None
 
 
@@ -31,6 +32,7 @@ def lib():
         L.fmd_gather_create.argtypes = [vp, i, i, i, C.c_size_t, u, C.POINTER(vp)]
         L.fmd_gather_destroy.argtypes = [vp]
         L.fmd_gather_step.argtypes = [vp, vp, i, u, vp, vp, vp, vp, vp]
+        L.fmd_gather_step_root.argtypes = [vp, i, vp, i, u, vp, vp, vp, vp, vp]
         L.fmd_gather_wait.argtypes = [vp, vp]
         L.fmd_gather_wait_lagged.argtypes = [vp, u, vp]
         L.fmd_gather_barrier.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
@@ -38,6 +40,7 @@ def lib():
         L.fmd_gather_ms_per_step.argtypes = [vp]
         L.fmd_gather_info.argtypes = [vp, C.POINTER(GatherInfo)]
         L.fmd_gather_debug_emulate_peers.argtypes = [vp, i, i]
+        L.fmd_gather_debug_emulate_role.argtypes = [vp, i]
         _LIB = L
     return _LIB
 
@@ -75,10 +78,10 @@ class Gather:
     def __del__(self):
         self.close()
 
-    def step(self, batch, lag, channel_offset, d_audio, d_rds, d_all_audio, d_all_rds, stream):
-        """Returns the step's ticket (for wait_for)."""
-        _check(lib().fmd_gather_step(self._h, batch._h if batch is not None else None, lag, channel_offset,
-                                     d_audio, d_rds, d_all_audio, d_all_rds, stream))
+    def step(self, batch, lag, channel_offset, d_audio, d_rds, d_all_audio, d_all_rds, stream, root=0):
+        """Returns the step's ticket (for wait_for).  root: the rank that receives this step (fmd_gather_step_root)."""
+        _check(lib().fmd_gather_step_root(self._h, int(root), batch._h if batch is not None else None, lag,
+                                          channel_offset, d_audio, d_rds, d_all_audio, d_all_rds, stream))
         self.issued += 1
         return self.issued - 1
 
@@ -102,6 +105,10 @@ class Gather:
     def emulate_peers(self, peers, workgroups_per_peer=2):
         """Measurement aid (world of one): every step also writes what `peers` more ranks' receives would write."""
         _check(lib().fmd_gather_debug_emulate_peers(self._h, int(peers), int(workgroups_per_peer)))
+
+    def emulate_role(self, every):
+        """1: the root of every step; peers + 1: a rank of a rotating root; 0: a sender in every step."""
+        _check(lib().fmd_gather_debug_emulate_role(self._h, int(every)))
 
     def info(self):
         """What the communicator itself reports: ranks_seen (ncclCommCount), rank, device, steps issued."""

@@ -10,6 +10,9 @@
  *   world_n <ranks> <steps>          exit code 0 = every rank succeeded
  *   FAKE_RCCL_FAIL_RECV=1 world_n 2 1    rank 0's first receive fails: the step must report it and leave no
  *                                        group open
+ *   WORLD_N_ROTATE=1 world_n 3 40        step i is gathered to rank i % world (fmd_gather_step_root): every rank is
+ *                                        a root in turn, has its own part produced in place in its slot of its
+ *                                        receive buffers, and checks every byte of the steps it received
  *   FAKE_RCCL_STALL_INIT=<rank> WORLD_N_UP_TIMEOUT=2 world_n 3 8
  *                                        that rank's first ncclCommInitRank never returns (the pool's stalled
  *                                        bootstrap): the parent (tools/rank_supervisor.hpp, what tools/node_bench
@@ -82,13 +85,18 @@ static int rank_main(int rank, int world, int steps, const uint8_t* id, bool exp
   CHECK(inf.ranks_seen == world && inf.rank == rank && inf.world_asked == world && inf.steps_issued == 0);
   void* st = nullptr;
   CHECK(hipStreamCreateWithFlags(&st, 0) == 0);
-  std::vector<float> audio(size_t(NBUF) * AFL), all_a(rank == 0 ? size_t(NBUF) * world * AFL : 0);
-  std::vector<int32_t> rds(size_t(NBUF) * ROWS * 4), all_r(rank == 0 ? size_t(NBUF) * world * ROWS * 4 : 0);
+  const bool rotate = getenv("WORLD_N_ROTATE") != nullptr;
+  auto root_of = [&](int step) { return rotate ? step % world : 0; };
+  const bool receives = rotate || rank == 0;
+  std::vector<float> audio(size_t(NBUF) * AFL), all_a(receives ? size_t(NBUF) * world * AFL : 0);
+  std::vector<int32_t> rds(size_t(NBUF) * ROWS * 4), all_r(receives ? size_t(NBUF) * world * ROWS * 4 : 0);
   std::vector<float> stage_a(AFL);
   std::vector<int32_t> stage_r(size_t(ROWS) * 4);
-  const bool inplace = getenv("WORLD_N_INPLACE") != nullptr;
+  const bool inplace = getenv("WORLD_N_INPLACE") != nullptr || rotate;
   long checked = 0;
-  auto verify = [&](int step) { // rank 0: what every rank sent in `step`
+  auto verify = [&](int step) { // the step's root: what every rank sent in `step`
+    if (root_of(step) != rank)
+      return;
     const int s = step % NBUF;
     for (int r = 0; r < world; r++)
     {
@@ -115,7 +123,7 @@ static int rank_main(int rank, int world, int steps, const uint8_t* id, bool exp
     // the step that last used this slot (NBUF steps ago) must have read it / filled it: all but the NBUF - 1 youngest
     CHECK(fmd_gather_wait_lagged(g, NBUF - 1, st) == FMD_OK);
     CHECK(hipStreamSynchronize(st) == 0);
-    if (rank == 0 && i >= NBUF)
+    if (i >= NBUF)
       verify(i - NBUF);
     // the step's outputs are produced ON THE CALLER'S STREAM, late (a busy stream, then a copy from staging
     // buffers): a gather that does not order its own stream behind the caller's sends the poison below
@@ -124,9 +132,10 @@ static int rank_main(int rank, int world, int steps, const uint8_t* id, bool exp
     for (size_t k = 0; k < size_t(ROWS) * 4; k++)
       stage_r[k] = rds_value(rank, i, k);
     // (WORLD_N_INPLACE: rank 0 has its outputs produced in its part of the receive buffers, like tools/node_bench)
-    float* const my_a = (rank == 0 && inplace) ? &all_a[size_t(s) * world * AFL] : &audio[size_t(s) * AFL];
-    int32_t* const my_r = (rank == 0 && inplace) ? &all_r[size_t(s) * world * ROWS * 4] : &rds[size_t(s) * ROWS * 4];
-    if (rank == 0)
+    const int root = root_of(i);
+    float* const my_a = (rank == root && inplace) ? &all_a[(size_t(s) * world + root) * AFL] : &audio[size_t(s) * AFL];
+    int32_t* const my_r = (rank == root && inplace) ? &all_r[(size_t(s) * world + root) * ROWS * 4] : &rds[size_t(s) * ROWS * 4];
+    if (rank == root)
     { // poison the receive slot: stale data from NBUF steps ago must not pass for this step's
       memset(&all_a[size_t(s) * world * AFL], 0xFF, size_t(world) * AFL * 4);
       memset(&all_r[size_t(s) * world * ROWS * 4], 0xFF, size_t(world) * ROWS * 16);
@@ -136,9 +145,9 @@ static int rank_main(int rank, int world, int steps, const uint8_t* id, bool exp
     fake_hip_stream_busy(st, 1500);
     CHECK(hipMemcpyAsync(my_a, stage_a.data(), AFL * 4, 0, st) == 0);
     CHECK(hipMemcpyAsync(my_r, stage_r.data(), size_t(ROWS) * 16, 0, st) == 0);
-    const int rc = fmd_gather_step(g, nullptr, 0, 0, my_a, my_r,
-                                   rank == 0 ? &all_a[size_t(s) * world * AFL] : nullptr,
-                                   rank == 0 ? &all_r[size_t(s) * world * ROWS * 4] : nullptr, st);
+    const int rc = fmd_gather_step_root(g, root, nullptr, 0, 0, my_a, my_r,
+                                        rank == root ? &all_a[size_t(s) * world * AFL] : nullptr,
+                                        rank == root ? &all_r[size_t(s) * world * ROWS * 4] : nullptr, st);
     if (expect_failure && rank == 0)
     {
       CHECK(rc < 0 && strstr(fmd_gather_last_error(), "ncclRecv") != nullptr);
@@ -155,15 +164,17 @@ static int rank_main(int rank, int world, int steps, const uint8_t* id, bool exp
   if (expect_failure)
     _exit(0); // (a sender whose peer gave up: nothing more to check)
   CHECK(fmd_gather_wait(g, st) == FMD_OK && hipStreamSynchronize(st) == 0);
-  if (rank == 0)
-    for (int i = steps > NBUF ? steps - NBUF : 0; i < steps; i++)
-      verify(i);
+  for (int i = steps > NBUF ? steps - NBUF : 0; i < steps; i++)
+    verify(i);
   double mx = -1.0;
   CHECK(fmd_gather_barrier(g, 10.0 + rank, &mx) == FMD_OK && mx == 10.0 + (world - 1));
   CHECK(fmd_gather_barrier(g, 5.0 - rank, &mx) == FMD_OK && mx == 5.0);
   CHECK(fmd_gather_ms_per_step(g) >= 0.0f && fmd_gather_ms_per_step(g) < 0.0f); // the second query has nothing to report
   CHECK(fmd_gather_info(g, &inf) == FMD_OK && inf.steps_issued == uint64_t(steps) && inf.ranks_seen == world);
-  if (rank == 0)
+  if (rotate) // every rank was a root in turn
+    printf("{\"rank\": %d, \"world\": %d, \"rank_step_messages_checked\": %ld, \"rccl_ranks_seen\": %d}\n", rank, world,
+           checked, inf.ranks_seen);
+  else if (rank == 0)
     printf("{\"world\": %d, \"steps\": %d, \"rank_step_messages_checked\": %ld, \"rccl_ranks_seen\": %d}\n", world, steps,
            checked, inf.ranks_seen);
   fflush(stdout);

@@ -191,3 +191,25 @@ def test_the_library_reads_no_environment_variable():
     # (error messages may name a constant of include/fmd.h; nothing else that looks like a variable)
     declared = set(re.findall(r"FMD_[A-Z0-9_]+", open(os.path.join(ROOT, "include", "fmd.h")).read()))
     assert set(re.findall(r"FMD_[A-Z0-9_]+", names)) <= declared
+
+
+def test_development_keys_are_the_documented_ones():
+    """fmd_batch_debug_set takes the keys INTEGRATION.md section 3 lists, each with the test that exercises it -- no
+    more (round 6 cut 32 keys to 14), and every test the table names exists."""
+    src = open(os.path.join(ROOT, "pvr.rtl.radiofm_amd", "csrc", "fmd_batch.hip")).read()
+    body = src[src.index("int fmd_batch_debug_set(fmd_batch* b, const char* key, int value)"):]
+    body = body[:body.index("\nint fmd_batch_wait(")]
+    keys = set(re.findall(r'k == "([a-z_0-9]+)"', body))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("| key | values | what it selects | exercised by |"):]
+    table = table[:table.index("\n\n")]
+    documented = set()
+    for row in table.splitlines()[2:]:
+        cells = [c.strip() for c in row.strip("|").split("|")]
+        documented |= set(re.findall(r"`([a-z_0-9]+)`", cells[0]))
+        for path, name in re.findall(r"`(tests/[a-z_0-9]+\.py|test_[a-z_0-9]+\.py)(?:::([a-z_0-9]+))?`", cells[-1]):
+            path = path if path.startswith("tests/") else "tests/" + path
+            text = open(os.path.join(ROOT, path)).read()
+            assert not name or ("def %s(" % name) in text, (path, name)
+    assert keys == documented, (sorted(keys - documented), sorted(documented - keys))
+    assert len(keys) <= 14

@@ -71,3 +71,20 @@ def test_a_stalled_bootstrap_restarts_all_ranks_once(world_n):
     # no stall: one attempt
     out = subprocess.run([world_n, "2", "4"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "world_n: attempts 1" in out.stderr
+
+
+@pytest.mark.parametrize("world,steps", [(3, 40), (8, 24)])
+def test_rotating_root_spreads_the_receive_load(world_n, world, steps):
+    """fmd_gather_step_root: step i is gathered to rank i % world -- every rank is the receiver of every world-th step
+    (with its own part produced in place in ITS slot of its receive buffers) and a sender otherwise; what rank 0 alone
+    would take (7 x 88 MB of writes per step at 8 GPUs: 8-10 % of that GPU's throughput, docs/MEASUREMENTS.md) is
+    spread evenly.  Every root checks every byte of the steps it received."""
+    env = dict(os.environ, WORLD_N_ROTATE="1")
+    out = subprocess.run([world_n, str(world), str(steps)], capture_output=True, text=True, timeout=180, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert sorted(l["rank"] for l in lines) == list(range(world))
+    assert all(l["rccl_ranks_seen"] == world for l in lines)
+    assert sum(l["rank_step_messages_checked"] for l in lines) == world * steps
+    for l in lines:  # a rank is the root of the steps i with i % world == rank
+        assert l["rank_step_messages_checked"] == world * len(range(l["rank"], steps, world))

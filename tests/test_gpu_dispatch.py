@@ -450,3 +450,42 @@ def test_sub_batches_through_every_entry_point(oracle, fmsig):
             assert np.float32(f_o) == np.float32(f_g), c
         assert _bits_equal(b.tap("mono_rs", c), b.tap("mono_rs", c % 4))
     b.close()
+
+
+@pytest.mark.parametrize("excl", [0, 1], ids=["shared-form", "whole-cu-form"])
+def test_serial_stage_forms_at_the_other_batch_size(oracle, fmsig, excl):
+    """"serial_exclusive" of fmd_batch_debug_set: the serial stage's whole-CU form (one role wave per SIMD of a CU:
+    the default for 1024-8192 channels) forced on a batch that would take the shared form (512 channels) and the
+    other way round (1024) -- FM PLL, pilot PLL and level meters (FmDecode.cpp:362-415, 143-229, 522-539) bit for
+    bit either way, overlapped calls, ragged sizes."""
+    pkg = load_package()
+    C = 512 if excl else 1024
+    _run_overlapped(pkg, fmsig, oracle, 2.4e6, 11, C, [N, 30001, N, 8192, N], check=[0, 63, 64, C // 2 - 1, C - 1],
+                    u8=False, debug=(("serial_exclusive", excl),))
+
+
+def test_stage_mask_leaves_the_launched_part_intact(oracle, fmsig):
+    """"stage_mask" (tools/power_by_stage.py's joules per part: only the named parts of a call are launched, every
+    event is still recorded): with only the IF stage launched the calls still complete in order and the IF FIR's
+    output (cFineTuner + cDownsampleFilter, DownConvert.cpp:98-154) is what the full path's IF stage writes."""
+    import torch
+    pkg = load_package()
+    fs, D, C = 2.4e6, 11, 1024
+    gen = fmsig.DeviceGenerator([fmsig.channel_params(fs, c % 8) for c in range(C)], "cuda")
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
+    b.set_concurrency(2)
+    b.debug_set("stage_mask", 1)
+    ref = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
+    audio = torch.zeros((C, a_stride), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for k in range(4):
+        t = torch.empty((C, N, 2), dtype=torch.float32, device="cuda")
+        gen.generate(t, k * N, N)
+        b.process_device(t.data_ptr(), N, N, audio.data_ptr(), a_stride, st)
+        b.wait(stream=st)
+        torch.cuda.synchronize()
+        ref.process_stream(t[5].cpu().numpy().reshape(-1))
+        assert _bits_equal(b.tap("demod", 5).view(np.float32), ref.taps()["demod"].view(np.float32)), k
+    b.debug_set("stage_mask", 63)
+    b.close()

@@ -5,7 +5,7 @@
  * LAG steps late), same JSON keys; bench.py stays the driver's entry point.
  *
  *   tools/node_bench --gpus N [--steps K] [--warmup W] [--channels C] [--watchdog seconds] [--up-timeout seconds]
- *                    [--verify]
+ *                    [--gather-root 0|rotate] [--verify]
  *
  * The parent forks the N ranks BEFORE anything touches HIP; rank 0 writes the communicator's id into a
  * file the others wait for.  Build: make -C pvr.rtl.radiofm_amd/csrc ../../tools/node_bench
@@ -48,8 +48,12 @@ static void make_station(double fs, unsigned g, fmsig_chan* ch, uint8_t* dbits)
   fmsig_rds_dbits(&p, dbits);
 }
 
-static int rank_main(int rank, int world, int K, int W, unsigned C, const std::string& idfile, bool verify, int up_fd)
+static int rank_main(int rank, int world, int K, int W, unsigned C, const std::string& idfile, bool verify, bool rotate,
+                     int up_fd)
 {
+  // --gather-root rotate: step i is gathered to rank i % world (fmd_gather_step_root) instead of rank 0
+  auto root_of = [&](int step) { return rotate ? step % world : 0; };
+  const bool receives = rotate || rank == 0;
   const double fs = 2.4e6;
   const unsigned N = 65536, D = 11, RING = 10, LAG = 3, NBUF = LAG + 3;
   CHECK(hipSetDevice(rank) == hipSuccess);
@@ -101,9 +105,9 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
 
   float *audio = nullptr, *all_a = nullptr;
   int32_t *rds = nullptr, *all_r = nullptr;
-  if (rank != 0) // (rank 0's outputs are produced in place, in its part of the receive buffers: audio_of / rds_of)
+  if (rotate || rank != 0) // (a root's outputs are produced in place, in its part of its receive buffers: audio_of / rds_of)
     CHECK(hipMalloc(reinterpret_cast<void**>(&audio), NBUF * afl * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&rds), size_t(NBUF) * C * 16) == hipSuccess);
-  if (rank == 0)
+  if (receives)
     CHECK(hipMalloc(reinterpret_cast<void**>(&all_a), size_t(NBUF) * world * afl * 4) == hipSuccess &&
           hipMalloc(reinterpret_cast<void**>(&all_r), size_t(NBUF) * world * C * 16) == hipSuccess);
   hipStream_t st;
@@ -111,18 +115,25 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
   int submitted = -1, finalized = -1;
   unsigned nf = 0;
   std::vector<unsigned> nfs;
-  // rank 0 has its own outputs produced in place: slot s of its audio / record buffers is its part (the first) of
-  // slot s of the receive buffers, and the gather has nothing to copy for it
-  auto audio_of = [&](int s) { return rank == 0 ? all_a + size_t(s) * world * afl : audio + size_t(s) * afl; };
-  auto rds_of = [&](int s) { return rank == 0 ? all_r + size_t(s) * world * C * 4 : rds + size_t(s) * C * 4; };
-  auto finalize = [&](int lag) { // outputs of step finalized + 1: on their way to rank 0
+  // a step's root has its own outputs produced in place: slot s of its audio / record buffers is its part (the
+  // rank-th) of slot s of its receive buffers, and the gather has nothing to copy for it
+  auto audio_of = [&](int i) {
+    const int s = i % int(NBUF);
+    return rank == root_of(i) ? all_a + (size_t(s) * world + rank) * afl : audio + size_t(s) * afl;
+  };
+  auto rds_of = [&](int i) {
+    const int s = i % int(NBUF);
+    return rank == root_of(i) ? all_r + (size_t(s) * world + rank) * C * 4 : rds + size_t(s) * C * 4;
+  };
+  auto finalize = [&](int lag) { // outputs of step finalized + 1: on their way to the step's root
     const int i = ++finalized, s = i % int(NBUF);
-    CHECK(fmd_gather_step(g, b, lag, unsigned(rank) * C, audio_of(s), rds_of(s),
-                          all_a ? all_a + size_t(s) * world * afl : nullptr, all_r ? all_r + size_t(s) * world * C * 4 : nullptr, st) >= 0);
+    CHECK(fmd_gather_step_root(g, root_of(i), b, lag, unsigned(rank) * C, audio_of(i), rds_of(i),
+                               all_a ? all_a + size_t(s) * world * afl : nullptr,
+                               all_r ? all_r + size_t(s) * world * C * 4 : nullptr, st) >= 0);
   };
   auto step = [&](int i) {
     CHECK(fmd_gather_wait_lagged(g, NBUF - LAG - 1, st) == FMD_OK); // the gather that last read this slot's buffers
-    CHECK(fmd_batch_process_device(b, iq + size_t(i % int(RING)) * C * N * 2, N, N, audio_of(i % int(NBUF)), stride, &nf, st) == FMD_OK);
+    CHECK(fmd_batch_process_device(b, iq + size_t(i % int(RING)) * C * N * 2, N, N, audio_of(i), stride, &nf, st) == FMD_OK);
     submitted = i;
     nfs.push_back(nf); // (audio floats per channel of step i: 2620 / 2622 at 2.4 MS/s)
     if (i - int(LAG) > finalized)
@@ -150,15 +161,16 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
   double seen_short = 0.0;
   CHECK(fmd_gather_barrier(g, double(world - inf.ranks_seen), &seen_short) == FMD_OK);
   CHECK(seen_short == 0.0 && inf.rank == rank);
-  /* --verify: what rank 0 received from every rank in the last warm-up steps against a recomputation of four
-   * stations per rank in a batch of its own (same generator, same call sequence), bit for bit: audio rows and
-   * RDS records.  Every rank learns the verdict (the barrier's maximum) and leaves with code 4 on a mismatch. */
+  /* --verify: what a root (rank 0; every rank where the root rotates) received from every rank in the last warm-up
+   * steps against a recomputation of four stations per rank in a batch of its own (same generator, same call
+   * sequence), bit for bit: audio rows and RDS records.  Every rank learns the verdict (the barriers' maxima) and
+   * leaves with code 4 on a mismatch. */
   std::vector<int> rank_ok(size_t(world), 1);
   int verified_steps = 0;
   if (verify)
   {
     double bad = 0.0;
-    if (rank == 0)
+    if (receives)
     {
       std::vector<unsigned> picks = {0u, 1u, C / 2, C - 1};
       std::sort(picks.begin(), picks.end());
@@ -192,7 +204,7 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
         CHECK(fmd_batch_wait(vb, st) >= 0);
         CHECK(fmd_batch_export_rds_device(vb, vrds, vrows, 0, 0, st) >= 0);
         CHECK(hipStreamSynchronize(st) == hipSuccess);
-        if (i < W - V)
+        if (i < W - V || root_of(i) != rank)
           continue;
         verified_steps++;
         const int s = i % int(NBUF);
@@ -226,12 +238,21 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
       for (int r = 0; r < world; r++)
         if (!rank_ok[size_t(r)])
         {
-          fprintf(stderr, "node_bench --verify: what rank 0 received from rank %d differs from the recomputation\n", r);
+          fprintf(stderr, "node_bench --verify: what rank %d received from rank %d differs from the recomputation\n", rank, r);
           bad = 1.0;
         }
     }
-    double worst = 0.0;
+    double worst = 0.0, steps_all = 0.0;
     CHECK(fmd_gather_barrier(g, bad, &worst) == FMD_OK);
+    for (int r = 0; r < world; r++)
+    { // every rank's view of every sender (a rotating root: the roots' verdicts combined)
+      double w = 0.0;
+      CHECK(fmd_gather_barrier(g, rank_ok[size_t(r)] ? 0.0 : 1.0, &w) == FMD_OK);
+      rank_ok[size_t(r)] = w == 0.0;
+    }
+    CHECK(fmd_gather_barrier(g, double(verified_steps), &steps_all) == FMD_OK);
+    if (rotate)
+      verified_steps = int(steps_all); // (the most steps any one root verified)
     if (worst != 0.0)
       _exit(4);
   }
@@ -259,9 +280,10 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
     printf("{\"metric\": \"IQ MS/s demodulated (whole node) + achieved HBM GB/s on FIR stage\", \"value\": %.1f, \"unit\": \"MS/s\", "
            "\"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.4f, \"higher_is_better\": true, \"scaling\": \"weak\", "
            "\"vs_baseline\": null, \"dtype\": \"f32\", \"data\": \"synthetic\", \"config\": {\"workload\": \"BASELINE configs[3] per-GPU shard: "
-           "%u independent FM stereo+RDS channels/GPU @2.4 MS/s, 65536 IQ/channel/step (tools/node_bench.cpp: C++ host, RCCL gather to rank 0)\", "
+           "%u independent FM stereo+RDS channels/GPU @2.4 MS/s, 65536 IQ/channel/step (tools/node_bench.cpp: C++ host, RCCL gather to %s)\", "
            "\"audio_floats_per_channel_step\": %u, \"gather_ms_per_step_rank0\": %.4f}, \"rccl_ranks_seen\": %d, \"verify\": %s}\n",
-           double(world) * C * N * K / dmax / 1e6, world, K, W, dmax / K * 1e3, C, nf, gms, inf.ranks_seen, vjson.c_str());
+           double(world) * C * N * K / dmax / 1e6, world, K, W, dmax / K * 1e3, C, rotate ? "a rotating root: step i to rank i % world" : "rank 0",
+           nf, gms, inf.ranks_seen, vjson.c_str());
   fflush(stdout); // (the rank leaves through _exit)
   fmd_gather_destroy(g);
   fmd_batch_destroy(b);
@@ -272,7 +294,7 @@ int main(int argc, char** argv)
 {
   int gpus = 1, K = 40, W = 8;
   unsigned C = 8192;
-  bool verify = false;
+  bool verify = false, rotate = false;
   unsigned watchdog = 900; // seconds after which a rank ends itself (a stalled RCCL bootstrap must not hang the node)
   int up_timeout = 60;     // seconds for every rank's communicator to be up, else all ranks are started again, once
   for (int i = 1; i < argc; i++)
@@ -293,6 +315,7 @@ int main(int argc, char** argv)
     else if (k == "--channels") C = unsigned(atoi(argv[i + 1]));
     else if (k == "--watchdog") watchdog = unsigned(atoi(argv[i + 1]));
     else if (k == "--up-timeout") up_timeout = atoi(argv[i + 1]);
+    else if (k == "--gather-root") rotate = std::string(argv[i + 1]) == "rotate";
   }
   const std::string idfile = "/tmp/fmd_node_bench_" + std::to_string(getpid()) + ".id";
   setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); // dmabuf IPC: what RCCL needs on this pool
@@ -303,7 +326,7 @@ int main(int argc, char** argv)
   const int worst = fmd_launch::run_ranks(
       gpus, up_timeout, watchdog,
       [&](int r, int attempt, int up_fd) {
-        return rank_main(r, gpus, K, W, C, idfile + "." + std::to_string(attempt), verify, up_fd);
+        return rank_main(r, gpus, K, W, C, idfile + "." + std::to_string(attempt), verify, rotate, up_fd);
       },
       &attempts);
   for (int a = 0; a < attempts; a++)
