@@ -74,20 +74,6 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
     CHECK(f && fread(id, 1, sizeof id, f) == sizeof id);
     fclose(f);
   }
-  // the decoder and the communicator first: the parent waits for "communicator up" (rank_supervisor.hpp)
-  fmd_params par{fs, -0.15 * fs, 48000.0, 15000.0, D, 0, 0, 0, FMD_FIR_SEQUENTIAL};
-  fmd_batch* b = nullptr;
-  CHECK(fmd_batch_create(&par, C, nullptr, rank, nullptr, nullptr, &b) == FMD_OK);
-  CHECK(fmd_batch_set_concurrency(b, 2) == FMD_OK);
-  const size_t stride = (fmd_batch_max_audio_floats(b, N) + 63) / 64 * 64, afl = stride * C;
-  fmd_gather* g = nullptr;
-  CHECK(fmd_gather_create(id, rank, world, rank, afl, C, &g) == FMD_OK);
-  if (up_fd >= 0)
-  { // the communicator is up: tell the parent (tools/rank_supervisor.hpp starts all ranks over when one never does)
-    const char u = 'U';
-    (void)!write(up_fd, &u, 1);
-    close(up_fd);
-  }
   // stations rank * C .. rank * C + C - 1 (tools/fmsig_py.channel_params), generated on the device
   std::vector<fmsig_chan> ch(C);
   std::vector<uint8_t> dbits(size_t(C) * FMSIG_RDS_PERIOD_BITS);
@@ -103,6 +89,21 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
     CHECK(fmsig_device_generate(d_ch, d_bits, FMSIG_RDS_PERIOD_BITS, C, uint64_t(r) * N, N, iq + size_t(r) * C * N * 2, N, nullptr) == 0);
   CHECK(hipDeviceSynchronize() == hipSuccess);
 
+  // (input first, then the decoder: the allocation order bench.py has -- with the decoder's buffers in front of the
+  // 43 GB input ring the same loop measured 3-4 % slower, round 6)
+  fmd_params par{fs, -0.15 * fs, 48000.0, 15000.0, D, 0, 0, 0, FMD_FIR_SEQUENTIAL};
+  fmd_batch* b = nullptr;
+  CHECK(fmd_batch_create(&par, C, nullptr, rank, nullptr, nullptr, &b) == FMD_OK);
+  CHECK(fmd_batch_set_concurrency(b, 2) == FMD_OK);
+  const size_t stride = (fmd_batch_max_audio_floats(b, N) + 63) / 64 * 64, afl = stride * C;
+  fmd_gather* g = nullptr;
+  CHECK(fmd_gather_create(id, rank, world, rank, afl, C, &g) == FMD_OK);
+  if (up_fd >= 0)
+  { // the communicator is up: tell the parent (tools/rank_supervisor.hpp starts all ranks over when one never does)
+    const char u = 'U';
+    (void)!write(up_fd, &u, 1);
+    close(up_fd);
+  }
   float *audio = nullptr, *all_a = nullptr;
   int32_t *rds = nullptr, *all_r = nullptr;
   if (rotate || rank != 0) // (a root's outputs are produced in place, in its part of its receive buffers: audio_of / rds_of)
@@ -296,7 +297,8 @@ int main(int argc, char** argv)
   unsigned C = 8192;
   bool verify = false, rotate = false;
   unsigned watchdog = 900; // seconds after which a rank ends itself (a stalled RCCL bootstrap must not hang the node)
-  int up_timeout = 60;     // seconds for every rank's communicator to be up, else all ranks are started again, once
+  int up_timeout = 90;     // seconds for every rank's communicator to be up (HIP start-up and the input ring's
+                           // generation included), else all ranks are started again, once
   for (int i = 1; i < argc; i++)
     if (std::string(argv[i]) == "--verify")
     { // a flag without a value: take it out of the key / value pairs
