@@ -714,10 +714,11 @@ static const hb_proto HB_PROTOS[] = {
 
 typedef struct
 {
-  int len;          /* 11 => the unrolled 11-tap class, else generic */
+  int len;          /* 11 => the unrolled 11-tap class, 0 => CCicN3DecimateBy2, else generic */
   float coef[51];   /* RealType table (double literals narrowed to float) */
   cf32* buf;        /* generic: m_pHBFirBuf */
   cf32 d[10];       /* 11-tap: d0..d9 */
+  cf32 xodd, xeven; /* CIC: m_Xodd, m_Xeven (DownConvert.cpp:692-696) */
 } hb_stage;
 
 typedef struct
@@ -753,8 +754,8 @@ static void rdsdc_set_frequency(rds_dc* c, float nco_freq) /* DownConvert.cpp:31
   c->osc_sin = sinf(c->nco_inc);
 }
 
-/* returns <0 when the chain would need the CIC stage (baseband >= 5.3 MHz),
- * which never happens on this path and is not restated. */
+/* (the CIC stage -- baseband >= 5.33 MHz, which cRadioReceiver never asks for, RadioReceiver.cpp:285 -- is
+ * restated since round 6: cic3 below) */
 static int rdsdc_init(rds_dc* c, float in_rate, float max_bw)
 {
   memset(c, 0, sizeof(*c));
@@ -768,8 +769,15 @@ static int rdsdc_init(rds_dc* c, float in_rate, float max_bw)
   while (((double)f > ((double)max_bw / HB_PROTOS[N_HB_PROTOS - 1].max_bw)) &&
          ((double)f > MIN_OUTPUT_RATE))
   {
+    if (n >= MAX_DECSTAGES)
+      return -1; /* (the reference's pointer array holds 10 stages, DownConvert.h; more would overrun it) */
     if ((double)f >= ((double)max_bw / CIC3_MAX))
-      return -1;
+    { /* :340-341 */
+      memset(&c->st[n], 0, sizeof(c->st[n]));
+      c->st[n++].len = 0;
+      f = (float)((double)f / 2.0);
+      continue;
+    }
     for (int k = 0; k < N_HB_PROTOS; k++)
     {
       if ((double)f >= ((double)max_bw / HB_PROTOS[k].max_bw))
@@ -867,6 +875,24 @@ static int hb_11(hb_stage* s, int n, cf32* data)
   return n / 2;
 }
 
+/* CCicN3DecimateBy2::DecBy2 (DownConvert.cpp:706-727), in place.  "InLength must be an even number" (:701): with
+ * an odd one the loop reads pInData[InLength], whatever the buffer holds there -- restated as written (the buffer is
+ * the caller's, stale contents included); the product refuses such calls. */
+static int cic3(hb_stage* s, int n, cf32* data)
+{
+  int j = 0;
+  for (int i = 0; i < n; i += 2, j++)
+  { /* mag gn=8 */
+    const cf32 even = data[i], odd = data[i + 1];
+    /* .125 * (odd + m_Xeven + 3.0 * (m_Xodd + even)): float sums, then double arithmetic, narrowed on store */
+    data[j].re = (float)(.125 * ((double)(odd.re + s->xeven.re) + 3.0 * (double)(s->xodd.re + even.re)));
+    data[j].im = (float)(.125 * ((double)(odd.im + s->xeven.im) + 3.0 * (double)(s->xodd.im + even.im)));
+    s->xodd = odd;
+    s->xeven = even;
+  }
+  return j;
+}
+
 static int rdsdc_process(rds_dc* c, int n, cf32* data, cf32* out)
 {
   /* quadrature-oscillator NCO with amplitude servo (:436-442, :464-465) */
@@ -884,7 +910,9 @@ static int rdsdc_process(rds_dc* c, int n, cf32* data, cf32* out)
   }
   int m = n;
   for (int k = 0; k < c->nstages; k++)
-    m = (c->st[k].len == 11) ? hb_11(&c->st[k], m, data) : hb_generic(&c->st[k], m, data);
+    m = (c->st[k].len == 0)    ? cic3(&c->st[k], m, data)
+        : (c->st[k].len == 11) ? hb_11(&c->st[k], m, data)
+                               : hb_generic(&c->st[k], m, data);
   for (int i = 0; i < m; i++)
     out[i] = data[i];
   return m;

@@ -842,7 +842,12 @@ int create_one(const fmd_params* params, unsigned n_channels, const int* tuning_
       bool ok = true;
       for (const auto& h : d.hb)
       {
-        if (h.len == 11)
+        if (h.cic)
+        { // (an even number of inputs: process_device_impl)
+          ok = ok && n >= 2 && n % 2 == 0;
+          n = n / 2;
+        }
+        else if (h.len == 11)
         {
           ok = ok && n >= 20;
           n = n / 2;

@@ -207,7 +207,15 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   {
     hb_in[s] = R;
     const unsigned L = unsigned(d.hb[s].len);
-    if (L == 11)
+    if (d.hb[s].cic)
+    { // CCicN3DecimateBy2: "InLength must be an even number" (DownConvert.cpp:701) -- with an odd one the class
+      // reads one sample past its block (whatever the buffer holds): outside the contract here
+      if (R % 2u || R < 2u)
+        return fail(FMD_ERR_SIZE, "at this baseband rate the RDS decimator starts with CIC stages: the baseband length "
+                                  "of a call must be a multiple of 2 per CIC stage (the reference reads past an odd block)");
+      R = R / 2; // :726
+    }
+    else if (L == 11)
     { // the unrolled class reads InLength - 10 .. and its first nine outputs unconditionally (:596-661)
       if (R < 20)
         return fail(FMD_ERR_SIZE, "block too short for the 11-tap half-band stage");
@@ -311,7 +319,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   /* ---- which form the RDS decimator takes: decided here, the serial stage's form follows from it ---- */
   bool hb_all_normal = d.hb.size() <= 3;
   for (size_t s = 0; s < d.hb.size(); s++)
-    hb_all_normal = hb_all_normal && hb_mode[s] == HB_NORMAL && d.hb[s].len != 11;
+    hb_all_normal = hb_all_normal && hb_mode[s] == HB_NORMAL && d.hb[s].len != 11 && !d.hb[s].cic;
   /* Large batches in the usual geometries: the three half-band stages as one stream, intermediate rows in
    * LDS (k_halfband_chain).  Everything else -- short calls with a stage outside its normal regime, the
    * 11-tap class, chains of another length, small batches -- keeps one launch per stage. */
@@ -599,7 +607,7 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       for (size_t s = 0; s < d.hb.size(); s++)
       {
         const unsigned n_out =
-            (d.hb[s].len == 11 || hb_mode[s] == HB_PASS) ? hb_in[s] / 2 : (hb_in[s] + 1) / 2;
+            (d.hb[s].cic || d.hb[s].len == 11 || hb_mode[s] == HB_PASS) ? hb_in[s] / 2 : (hb_in[s] + 1) / 2;
         const bool last = (s + 1 == d.hb.size());
         float2* outp = last ? b->rdsraw[q].p : b->hbbuf[s].p;
         const unsigned Hout = last ? (T_lpf - 1) : unsigned(d.hb[s + 1].len - 1);
@@ -614,7 +622,10 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
           in = outp;
           continue;
         }
-        if (d.hb[s].len == 11)
+        if (d.hb[s].cic)
+          hipLaunchKernelGGL(fmd::k_cic3, dim3(CP / 64, (n_out + 3) / 4), dim3(64, 4), 0, sR, in, outp, n_out, C, CP,
+                             Hout);
+        else if (d.hb[s].len == 11)
           hipLaunchKernelGGL(fmd::k_halfband11, dim3(CP / 64, (n_out + 3) / 4), dim3(64, 4), 0, sR, in, outp,
                              n_out, b->hbcoef[s], C, CP, Hout);
         else if (hb4 && (d.hb[s].len - 1) / 2 >= 4 && d.hb[s].len <= 55)

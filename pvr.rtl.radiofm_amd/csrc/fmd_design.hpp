@@ -40,8 +40,10 @@ struct Biquad
 
 struct HalfBand
 {
-  int len;
+  int len;                 // taps; len - 1 = the rows of delay line in front of a stage's input
   std::vector<float> coef;
+  bool cic = false;        // CCicN3DecimateBy2 (DownConvert.cpp:690-727) instead of a half-band: len = 3, i.e. two rows
+                           // of delay line (m_Xeven, m_Xodd), no coefficient table
 };
 
 struct Design
@@ -313,8 +315,18 @@ inline Design make_design(const Params& p)
     float f = d.fs_bb;
     while ((double(f) > (double(max_bw) / protos.back().max_bw)) && (double(f) > 7900.0 * 2.0))
     {
+      if (d.hb.size() >= 9) // m_pDecimatorPtrs[MAX_DECSTAGES = 10], the last one stays null (DownConvert.h:63, 168)
+        throw std::invalid_argument("fmd: baseband rate needs more decimate-by-2 stages than the reference's list holds");
       if (double(f) >= (double(max_bw) / (.5 - .4985)))
-        throw std::invalid_argument("fmd: baseband rate needs the CIC stage (unsupported)");
+      { // CIC order 3 (:340-341): baseband rates from 5.33 MHz up (cRadioReceiver never asks: RadioReceiver.cpp:285)
+        HalfBand h;
+        h.len = 3;
+        h.coef.assign(3, 0.0f);
+        h.cic = true;
+        d.hb.push_back(h);
+        f = float(double(f) / 2.0);
+        continue;
+      }
       for (const auto& pr : protos)
       {
         if (double(f) >= (double(max_bw) / pr.max_bw))
@@ -360,9 +372,11 @@ inline Design make_design(const Params& p)
       mc[unsigned(i) + L] = float(.75 * c * shape);
       mc[L - unsigned(i)] = float(-.75 * c * shape);
     }
-    if (2 * L > 75 || L == 0)
+    if (L == 0)
       throw std::invalid_argument("fmd: RDS matched filter length out of range");
-    d.rds_mf_taps.assign(mc.begin(), mc.begin() + 2 * L); // first 2L of 2L+1 (:77)
+    // first 2L of 2L+1 (:77); cFirFilter::InitConstFir keeps at most MAX_NUMCOEF = 75 of them (FirFilter.cpp:305-306:
+    // RDS rates above 44.5 kHz, e.g. a 12 MS/s baseband: 78 -> 75)
+    d.rds_mf_taps.assign(mc.begin(), mc.begin() + std::min<size_t>(2 * L, 75));
     d.rds_lpf_taps = make_kaiser_lp(1.0f, 40.0f, 2400.0f, float(1.3 * 2400.0), d.rds_rate);
     d.bitsync = make_biquad(BQ_BP, float(bitrate), 500, d.rds_rate);
   }

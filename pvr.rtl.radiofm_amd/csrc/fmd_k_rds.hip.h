@@ -149,6 +149,26 @@ __global__ __launch_bounds__(256) void k_halfband11(const float2* __restrict__ i
   out[(size_t)(Hout + o) * CP + c] = make_float2(ar, ai);
 }
 
+/* CCicN3DecimateBy2::DecBy2 (DownConvert.cpp:706-727): the first stage(s) at baseband rates of 5.33 MHz and more.
+ * out[j] = .125 * (odd + m_Xeven + 3.0 * (m_Xodd + even)) with even = x[2j], odd = x[2j + 1], m_Xeven = x[2j - 2],
+ * m_Xodd = x[2j - 1]: a window of four rows, two of them delay line (rows 0, 1 of `in`), time-parallel.  The two
+ * float sums first, then double arithmetic, narrowed once -- the reference's promotions (.125 and 3.0 are double
+ * literals).  InLength / 2 outputs: the host refuses odd lengths (the class reads past the block then, :701). */
+__global__ __launch_bounds__(256) void k_cic3(const float2* __restrict__ in, float2* __restrict__ out, unsigned n_out,
+                                              unsigned C, unsigned CP, unsigned Hout)
+{
+  const unsigned c = blockIdx.x * 64 + threadIdx.x;
+  const unsigned wy = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
+  const unsigned o = blockIdx.y * blockDim.y + wy;
+  if (c >= C || o >= n_out)
+    return;
+  const float2* __restrict__ p = in + (size_t)(2 * o) * CP + c;
+  const float2 xe = p[0], xo = p[CP], ev = p[(size_t)2 * CP], od = p[(size_t)3 * CP];
+  const float re = (float)(.125 * ((double)(od.x + xe.x) + 3.0 * (double)(xo.x + ev.x)));
+  const float im = (float)(.125 * ((double)(od.y + xe.y) + 3.0 * (double)(xo.y + ev.y)));
+  out[(size_t)(Hout + o) * CP + c] = make_float2(re, im);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* K4: cFirFilter::Process(complex) / ProcessTwo (FirFilter.cpp:330-350, :387-413),            */
 /*     time-parallel.  The reference walks its ring buffer from slot 0, so output i (global     */

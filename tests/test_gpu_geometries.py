@@ -95,9 +95,8 @@ def test_call_size_limits(fmsig):
     assert d1.ProcessStream(fmsig.generate_f32(p1, 0, 32000).view(np.complex64)).size > 10000
     # unsupported configurations fail at construction, loudly
     with pytest.raises(pkg.FmdError):
-        pkg.FmDecoder(16.2e6, 0.0, 48000.0, 15000.0, 3)  # baseband 5.4 MHz would need the CIC stage
-    with pytest.raises(pkg.FmdError):
         pkg.Batch(pkg.make_params(0.0, 0.0), 1)
+    # (a baseband rate of 5.33 MHz and more -- the CIC stage -- is decoded since round 6: test_cic_first_stage)
     # the serial stage addresses its row buffers with 32-bit lane offsets: a batch that would pass 4 GB in one of
     # them (9000 channels without decimation: 65552 * 9000 * 8 bytes of IF-FIR output) runs as sub-batches that
     # stay below it (fmd_batch_create: here two of 4544 channels; until round 5 it was refused)
@@ -191,6 +190,41 @@ def test_eleven_tap_half_band_first_stage(oracle, fmsig, fs, D, sizes):
         assert _bits_equal(a[0], ref) and _bits_equal(a[1], ref), (k, n)
     so, sg = o.status(), b.status(1)
     assert sg.rds_state == so.rds_state and np.float32(sg.pilot_level) == np.float32(so.pilot_level)
+    b.close()
+
+
+@pytest.mark.parametrize("fs,D,ncic,sizes", [(6.4e6, 1, 1, [32000, 20000, 4000, 32000, 2048, 32000]),
+                                             (12.0e6, 1, 2, [32000, 16000, 32000, 4096]),
+                                             (16.2e6, 3, 1, [65532, 30000, 65532])])
+def test_cic_first_stage(oracle, fmsig, fs, D, ncic, sizes):
+    """Baseband rates of 5.33 MHz and more start the RDS decimator with CCicN3DecimateBy2 (DownConvert.cpp:340-341,
+    :690-727: .125 * (odd + m_Xeven + 3.0 * (m_Xodd + even)), two samples of state), twice from 10.67 MHz up, in front
+    of six or seven half-band stages; cRadioReceiver never asks for such a rate (RadioReceiver.cpp:285) but
+    cFmDecoder's constructor takes it.  RDS stage taps, audio and getters bit for bit; a call whose baseband length is
+    not a multiple of 2 per CIC stage is refused (the class reads one sample past an odd block, :701) and leaves the
+    decoder as it was.  The reference's own outputs for two such streams: tests/golden/ref_streams.npz."""
+    pkg = load_package()
+    p = fmsig.default_params(fs, noise_sigma=0.01, seed=27)
+    o = oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D)
+    assert o.rds_hb_lengths()[:ncic] == [0] * ncic and o.rds_hb_lengths()[ncic] == 11
+    b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), 2)
+    b.enable_taps()
+    start = 0
+    for k, n in enumerate(sizes * 2):
+        if k == 3:  # an odd baseband length: refused, nothing changes
+            with pytest.raises(pkg.FmdError):
+                b.process_host(np.zeros((2, (2 * ncic + 1) * D * 101), np.complex64))
+        iq = fmsig.generate_f32(p, start, n)
+        start += n
+        ref = o.process_stream(iq)
+        a = b.process_host(np.stack([iq, iq]).view(np.complex64))
+        t = o.taps()
+        for name in ("baseband", "mono_rs", "rds_lpf", "rds_pll", "rds_mf", "rds_sync"):
+            assert _bits_equal(b.tap(name, 1).view(np.float32), t[name].view(np.float32)), (k, n, name)
+        assert _bits_equal(a[0], ref) and _bits_equal(a[1], ref), (k, n)
+    so, sg = o.status(), b.status(1)
+    assert sg.rds_state == so.rds_state and np.float32(sg.pilot_level) == np.float32(so.pilot_level)
+    assert np.float32(sg.interface_level) == np.float32(so.if_level)
     b.close()
 
 

@@ -338,6 +338,12 @@ def streams(quick):
         ("2.4 MS/s all group types, weak RDS (FEC, sync loss)", 2.4e6, 11, 0,
          {"seed": 23, "schedule": "all_types", "noise_sigma": 0.11, "a_rds": 0.02}, full(400)),
         ("1.0 MS/s all group types", 1.0e6, 4, 0, {"seed": 24, "schedule": "all_types"}, full(100)),
+        # baseband rates >= 5.33 MHz put CCicN3DecimateBy2 in front of the half-bands (DownConvert.cpp:340-341,
+        # 690-727; cRadioReceiver never asks for it): 6.4 MHz = one CIC stage + six half-bands, 12 MHz = two + six;
+        # even call sizes only (the class reads one sample past an odd-length block: DownConvert.cpp:701)
+        ("6.4 MS/s, D = 1: CIC stage in front of the half-bands", 6.4e6, 1, 0, {"seed": 25},
+         [32000] * 10 + [20000, 4000, 32000, 2048, 32000, 32000] + [32000] * 150),
+        ("12 MS/s, D = 1: two CIC stages", 12.0e6, 1, 0, {"seed": 26}, [32000] * 12 + [16000, 32000]),
     ]
     if quick:
         s = [(n, fs, D, us, kw, calls[:max(6, len(calls) // 5)]) for n, fs, D, us, kw, calls in s]
