@@ -458,6 +458,16 @@ def main():
     wd = threading.Timer(args.watchdog, _expired)
     wd.daemon = True
     wd.start()
+    if os.environ.get("FMD_BENCH_WORKER") == "1":
+        # a worker must not outlive its supervisor (_supervise_rank: a launcher that is killed outright cannot end it)
+        parent = os.getppid()
+
+        def _orphan_check():
+            while os.getppid() == parent:
+                time.sleep(1.0)
+            os._exit(3)
+
+        threading.Thread(target=_orphan_check, daemon=True).start()
 
     import torch
     import torch.distributed as dist
