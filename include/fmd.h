@@ -330,6 +330,9 @@ int fmd_debug_math(int what, unsigned n, const float* a, const float* b, float* 
  * records of workgroups that did not exist stay zero.  Returns the number of records written (0
  * when the probe is off).  Synchronises the device. */
 int fmd_batch_debug_serial_probe(fmd_batch* b, long long* out, unsigned cap_workgroups);
+/* Dev aid: which internal streams share a hardware queue with the caller's `stream` (bit i: internal stream i waits
+ * behind it; bit 8 + i: it waits behind internal stream i; 0 = none).  Drains the device. */
+int fmd_batch_debug_stream_conflicts(fmd_batch* b, void* stream);
 /* Dev aid (overlapped calls at profiling level 1, whole-CU serial stage): per profiled call when its
  * IF FIR, its serial stage, its audio tail, its half-band chain and its resampler started and ended on
  * the device (the last two only in their large-batch forms), in ms since the first profiled call's FIR

@@ -113,6 +113,7 @@ EXPORTS = [
     "fmd_group_decoder_reset", "fmd_group_decoder_push", "fmd_uecp_stuff_frame",
     "fmd_batch_take_rds_lost", "fmd_batch_status_call_index",
     "fmd_batch_debug_set_spin_limit", "fmd_batch_debug_timeline", "fmd_batch_debug_set",
+    "fmd_batch_debug_stream_conflicts",
     "fmd_batch_debug_host_ms", "fmd_decoder_batch",
 ]
 
@@ -172,6 +173,7 @@ def lib():
         L.fmd_batch_get_audio_level.argtypes = [vp, u, C.POINTER(FmdAudioLevel)]
         L.fmd_debug_math.argtypes = [i, u, vp, vp, vp, vp]
         L.fmd_batch_debug_serial_probe.argtypes = [vp, vp, u]
+        L.fmd_batch_debug_stream_conflicts.argtypes = [vp, vp]
         L.fmd_design_lanczos.argtypes = [u, C.c_double, vp, u]
         L.fmd_design_lp_kaiser.argtypes = [C.c_float] * 5 + [vp, u]
         L.fmd_design_biquad.argtypes = [i, C.c_float, C.c_float, C.c_float, vp]
@@ -386,6 +388,10 @@ class Batch:
         buf = np.full((cap, 10), -1.0, dtype=np.float32)
         n = _check(lib().fmd_batch_debug_timeline(self._h, buf.ctypes.data, cap))
         return buf[:n].copy()
+
+    def debug_stream_conflicts(self, stream=None):
+        """Bit mask of internal streams that share a hardware queue with `stream` (0: none); drains the device."""
+        return _check(lib().fmd_batch_debug_stream_conflicts(self._h, stream))
 
     def debug_set_spin_limit(self, limit):
         _check(lib().fmd_batch_debug_set_spin_limit(self._h, limit))

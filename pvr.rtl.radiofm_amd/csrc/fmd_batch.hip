@@ -1323,14 +1323,25 @@ static int wait_impl(fmd_batch* b, int lag, void* stream_, bool take_lost)
       return rc;
     return take_lost ? take_lost_groups(b) : FMD_OK;
   }
+  /* Only events that have not completed yet become waits of the caller's stream: a completed event orders nothing.
+   * (Until round 6 every wait went through all eligible slots -- up to 32 barrier packets per step in the caller's
+   * queue, nearly all for calls long complete.  On the null stream that cost nothing measurable; on a stream of the
+   * caller's own the command processor's work on them cost 4-7 % of the whole path: tools/node_bench 275 000 against
+   * 288 000 MS/s on the null stream, bench.py --side-stream 264 000 against 284 000; docs/MEASUREMENTS.md, round 6.) */
+  auto wait_if_pending = [&](hipEvent_t e) {
+    if (hipEventQuery(e) == hipSuccess)
+      return hipSuccess;
+    (void)hipGetLastError(); // (hipErrorNotReady is not an error)
+    return hipStreamWaitEvent(stream, e, 0);
+  };
   for (int q = 0; q < fmd_batch::NSLOT; q++)
     if (slot_eligible(b, q, lag))
     {
-      HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_AUD], 0));
-      HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_RDS], 0));
-      HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_INDONE], 0));
+      HIPCHK(wait_if_pending(b->cev[q][fmd_batch::EV_AUD]));
+      HIPCHK(wait_if_pending(b->cev[q][fmd_batch::EV_RDS]));
+      HIPCHK(wait_if_pending(b->cev[q][fmd_batch::EV_INDONE]));
       // the history rolls behind the heavy part (br, mix, half-band tails) belong to the call too
-      HIPCHK(hipStreamWaitEvent(stream, b->cev[q][fmd_batch::EV_ROLL], 0));
+      HIPCHK(wait_if_pending(b->cev[q][fmd_batch::EV_ROLL]));
     }
   // asynchronous: reports what the device has flagged so far (calls that have finished)
   if (int rc = check_device_errors(b))
@@ -2133,6 +2144,39 @@ int fmd_batch_debug_timeline(fmd_batch* b, float* out, unsigned cap_calls)
   }
   (void)hipGetLastError();
   return int(n);
+}
+
+/* Which of the batch's internal streams share a hardware queue with `stream` (the caller's): bit i = internal
+ * stream i (0 IF FIR, 1 serial stage, 2 heavy, 3 light RDS half, 4 light audio half / filters) had to wait for a wave
+ * that kept `stream` busy; bit 8 + i = `stream` had to wait for internal stream i.  Drains the device. */
+int fmd_batch_debug_stream_conflicts(fmd_batch* b, void* stream_)
+{
+  if (!b)
+    return fail(FMD_ERR_ARG, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  hipStream_t caller = static_cast<hipStream_t>(stream_);
+  hipStream_t in[5] = {b->s_fir, b->s_ser, b->s_post, b->s_rds, b->s_lpf};
+  const long long spin = 1200000; // ~0.5 ms
+  int mask = 0;
+  auto waits_behind = [&](hipStream_t busy, hipStream_t probe) {
+    hipLaunchKernelGGL(fmd::k_probe_spin, dim3(1), dim3(64), 0, busy, spin, nullptr);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(fmd::k_probe_nop, dim3(1), dim3(64), 0, probe, nullptr);
+    (void)hipStreamSynchronize(probe);
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    (void)hipStreamSynchronize(busy);
+    return us >= 250.0;
+  };
+  for (int i = 0; i < 5; i++)
+    if (in[i])
+    {
+      if (waits_behind(caller, in[i]))
+        mask |= 1 << i;
+      if (waits_behind(in[i], caller))
+        mask |= 1 << (8 + i);
+    }
+  return mask;
 }
 
 int fmd_batch_debug_serial_probe(fmd_batch* b, long long* out, unsigned cap_workgroups)
