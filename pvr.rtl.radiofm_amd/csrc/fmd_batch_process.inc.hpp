@@ -369,11 +369,23 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   }
 
   /* ---- K1: tuner + IF decimating FIR  (stream F) ---- */
-  signal(ce[fmd_batch::EV_IN], stream);
-  after(sF, ce[fmd_batch::EV_IN]);
+  /* The input is ready in the order of the caller's stream.  Where that stream has nothing pending (the usual case:
+   * the host has just synchronised it for the previous outputs, or never uses it for anything else) the input IS
+   * ready and no event has to carry that: one record in the caller's queue and one barrier packet in front of the IF
+   * FIR less per call (+1.5 % whole path on the null stream, round 6). */
+  const bool input_pending = serial_mode ? false : hipStreamQuery(stream) != hipSuccess;
+  (void)hipGetLastError(); // (hipErrorNotReady is an answer, not an error)
+  if (input_pending)
+  {
+    signal(ce[fmd_batch::EV_IN], stream);
+    after(sF, ce[fmd_batch::EV_IN]);
+  }
   if (have_prev2)
   {
-    after(sF, pe2[fmd_batch::EV_SER]); // demod[q] was last read by the serial stage two calls ago
+    // (demod[q] was last read by the serial stage two calls ago: EV_SER of that call -- implied by its EV_HEAVY below,
+    // the heavy part starts behind the serial stage; not where an energy experiment leaves the heavy part out)
+    if (stage_mask != 63u)
+      after(sF, pe2[fmd_batch::EV_SER]);
     // Also run behind the bandwidth-heavy part of the post chain of two calls ago (half-bands, RDS
     // low-pass, resamplers, audio low-pass): side by side with those the FIR and they were both
     // ~25 % slower.  The rest of that chain (RDS PLL, matched filter, bit recovery, audio tail) is
