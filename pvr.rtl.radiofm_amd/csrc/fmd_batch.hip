@@ -218,13 +218,13 @@ struct fmd_batch
   int profiling = 0;
   int write_taps = 0; // stage taps of the RDS recurrences are only written on request
 
-  // Internal streams: the FIR of the next call (s_fir), the serial demodulator of this call
-  // (s_ser) and everything behind it (s_post: RDS chain, then audio chain; large batches put the
-  // RDS chain on s_rds, see fmd_batch_create) are independent
-  // chains tied together, and to the caller's stream, with events.  Three streams on purpose:
-  // HIP multiplexes streams onto a few hardware queues (4 by default) and two chains sharing
-  // a queue block each other.  demod, br and mix are double-buffered by call parity so no
-  // chain waits on a buffer a younger call still reads.
+  // Internal streams: the IF FIR of the next calls (s_fir), the serial stage of this call (s_ser), the heavy part of
+  // the post chain behind it (s_post: half-band chain, resampler) and its light part (s_rds, s_lpf: see the stream
+  // layouts in process_device_impl; a batch of one or two wavefronts runs its RDS chain and its audio chain side by
+  // side on s_rds / s_post) are independent chains tied together, and to the caller's stream, with events.  Streams
+  // of their own on purpose, and picked by measurement (pick_independent_streams): HIP multiplexes streams onto a
+  // few hardware queues and two chains sharing a queue block each other.  demod, br, mix and the filters' inputs
+  // are double-buffered by call parity so no chain waits on a buffer a younger call still reads.
   //   concurrency 0: everything on the caller's stream (also forced by profiling level 2)
   //   concurrency 1: internal streams, the caller's stream is ordered after every call (default)
   //   concurrency 2: as 1, but the caller's stream is only ordered after a call by fmd_batch_wait /
