@@ -416,6 +416,9 @@ def main():
     ap.add_argument("--emulate-peer-channels", type=int, default=0,
                     help="channels each emulated peer's message is sized for (default: --channels); rank 0 of an "
                          "unequal split decodes fewer channels than every peer sends")
+    ap.add_argument("--no-host-throttle", action="store_true",
+                    help="N > 1 / --verify path: do not block the host on the call LAG steps back (round 5's behaviour: "
+                         "the host runs eight calls ahead)")
     ap.add_argument("--side-stream", action="store_true",
                     help="development: submit from a non-default torch stream (the null stream orders itself "
                          "against every blocking stream of the process)")
@@ -749,6 +752,14 @@ def main():
                     e = torch.cuda.Event(enable_timing=True)
                     e.record()
                     step_events.append((state["finalized"], e))
+            if use_export and not args.no_host_throttle:
+                # The host blocks on the call LAG steps back, like the N = 1 path does inside fmd_batch_collect_rds:
+                # without it nothing stops the host before the decoder's own limit of eight calls in flight, and the
+                # device runs 15-20 % slower behind a queue that deep at the driver's flags (round 6: 225 500 -> 251 500 MS/s
+                # with a world of one; the gather's own stream is not waited for)
+                th2 = time.perf_counter()
+                torch.cuda.current_stream().synchronize()
+                host_t["wait"] = host_t.get("wait", 0.0) + (time.perf_counter() - th2)
         return nf
 
     def drain():
