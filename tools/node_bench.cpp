@@ -5,7 +5,7 @@
  * LAG steps late), same JSON keys; bench.py stays the driver's entry point.
  *
  *   tools/node_bench --gpus N [--steps K] [--warmup W] [--channels C] [--watchdog seconds] [--up-timeout seconds]
- *                    [--gather-root 0|rotate] [--own-stream 0|1] [--verify]
+ *                    [--gather-root 0|rotate] [--own-stream 0|1|2|3] [--verify]
  *
  * The parent forks the N ranks BEFORE anything touches HIP; rank 0 writes the communicator's id into a
  * file the others wait for.  Build: make -C pvr.rtl.radiofm_amd/csrc ../../tools/node_bench
@@ -49,7 +49,7 @@ static void make_station(double fs, unsigned g, fmsig_chan* ch, uint8_t* dbits)
 }
 
 static int rank_main(int rank, int world, int K, int W, unsigned C, const std::string& idfile, bool verify, bool rotate,
-                     bool own_stream, int up_fd)
+                     int own_stream, int up_fd)
 {
   // --gather-root rotate: step i is gathered to rank i % world (fmd_gather_step_root) instead of rank 0
   auto root_of = [&](int step) { return rotate ? step % world : 0; };
@@ -112,12 +112,19 @@ static int rank_main(int rank, int world, int K, int W, unsigned C, const std::s
     CHECK(hipMalloc(reinterpret_cast<void**>(&all_a), size_t(NBUF) * world * afl * 4) == hipSuccess &&
           hipMalloc(reinterpret_cast<void**>(&all_r), size_t(NBUF) * world * C * 16) == hipSuccess);
   hipStream_t st = nullptr;
-  // The caller's stream is the null stream, like bench.py's: the same loop on a stream of its own runs 3-4 % slower
-  // (276 800-282 600 against 288 700-293 500 MS/s, three alternating runs on one box; bench.py --side-stream: the
-  // same) although the batch's probe finds no hardware queue shared with it (fmd_batch_debug_stream_conflicts: 0) --
-  // measured in round 6, cause not found; "--own-stream 1" brings the created stream back.
-  if (own_stream)
+  // The caller's stream is the null stream, like bench.py's: the same loop on a created stream of the default priority
+  // runs 3-4 % slower (283 200-285 500 against 289 300-293 000 MS/s, three alternating runs on one box; bench.py
+  // --side-stream: the same) although the batch's probe finds no hardware queue shared with it
+  // (fmd_batch_debug_stream_conflicts: 0); a created stream at the least or the greatest priority does not (290 500-
+  // 293 000).  "--own-stream 1 | 2 | 3": default / least / greatest priority (docs/MEASUREMENTS.md, round 6).
+  if (own_stream == 1)
     CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
+  else if (own_stream >= 2)
+  { // 2: at the least priority (what the decoder's heavy and light streams have), 3: at the greatest
+    int lo = 0, hi = 0;
+    CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess);
+    CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, own_stream == 2 ? lo : hi) == hipSuccess);
+  }
   int submitted = -1, finalized = -1;
   unsigned nf = 0;
   std::vector<unsigned> nfs;
@@ -304,7 +311,8 @@ int main(int argc, char** argv)
 {
   int gpus = 1, K = 40, W = 8;
   unsigned C = 8192;
-  bool verify = false, rotate = false, own_stream = false;
+  bool verify = false, rotate = false;
+  int own_stream = 0;
   unsigned watchdog = 900; // seconds after which a rank ends itself (a stalled RCCL bootstrap must not hang the node)
   int up_timeout = 90;     // seconds for every rank's communicator to be up (HIP start-up and the input ring's
                            // generation included), else all ranks are started again, once
@@ -327,7 +335,7 @@ int main(int argc, char** argv)
     else if (k == "--watchdog") watchdog = unsigned(atoi(argv[i + 1]));
     else if (k == "--up-timeout") up_timeout = atoi(argv[i + 1]);
     else if (k == "--gather-root") rotate = std::string(argv[i + 1]) == "rotate";
-    else if (k == "--own-stream") own_stream = atoi(argv[i + 1]) != 0;
+    else if (k == "--own-stream") own_stream = atoi(argv[i + 1]);
   }
   const std::string idfile = "/tmp/fmd_node_bench_" + std::to_string(getpid()) + ".id";
   setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); // dmabuf IPC: what RCCL needs on this pool
