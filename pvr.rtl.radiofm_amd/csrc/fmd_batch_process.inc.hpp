@@ -386,15 +386,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
     // the heavy part starts behind the serial stage; not where an energy experiment leaves the heavy part out)
     if (stage_mask != 63u)
       after(sF, pe2[fmd_batch::EV_SER]);
-    // Also run behind the bandwidth-heavy part of the post chain of two calls ago (half-bands, RDS
-    // low-pass, resamplers, audio low-pass): side by side with those the FIR and they were both
-    // ~25 % slower.  The rest of that chain (RDS PLL, matched filter, bit recovery, audio tail) is
-    // lane-per-channel work that leaves most CUs idle: the FIR runs beside it.
-    // (behind the RDS half only, i.e. beside the resampler and the audio low-pass: measured, the FIR then
-    // takes 1.00 instead of 0.95 ms and the period does not move; again with the faster serial stage of
-    // round 3's end, which has slack: FIR 1.09 instead of 0.98 ms, period the same 2.00-2.01 ms)
-    // (a hardware event between two queues costs ~110 us from the resampler's end to the FIR's start, every
-    // call; a word in device memory in its place: 76 us, and the period did not move -- round 5, removed)
+    // Also run behind the bandwidth-heavy part of the post chain of two calls ago (half-band chain, resampler):
+    // side by side with those the FIR and they were both ~25 % slower.  The rest of that chain (the light part) is
+    // lane-per-channel work that leaves most CUs idle: the FIR runs beside it.  (Behind the RDS half only, or
+    // through a word in device memory instead of the event: measured in rounds 3 and 5, the period did not move --
+    // docs/MEASUREMENTS.md.)
     after(sF, pe2[fmd_batch::EV_HEAVY]);
   }
   // a batch that is one of several sub-batches sharing these streams (fmd_batch_create above 8192 channels): the
@@ -438,19 +434,14 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   after(sS, ce[fmd_batch::EV_FIR]);
   {
     const fmd::DemodConsts k = demod_consts(d);
-    // Up to 8192 channels the batch is latency-bound by this stage and needs at most 64 CUs for
-    // it: two channel groups per workgroup, one role wave per SIMD of a CU (k_demod_serial).
-    // Larger batches need the CUs for throughput and keep the shared form.
+    // From 1024 channels on the stage owns whole CUs: two channel groups per workgroup, one role wave per SIMD of a
+    // CU (k_demod_serial<2, ..>; at most 64 CUs: larger batches are sub-batches); smaller batches share their CUs.
     const unsigned groups = CP / 64;
     const FmdSincosTab sct{d.sct_inv_h, d.sct_h_hi, d.sct_h_lo};
     const unsigned Hmix = unsigned(d.hb[0].len - 1);
-    /* Two groups per workgroup = one role wave on each SIMD of a CU, 64 CUs for 8192 channels.  The
-     * waves no longer claim their SIMD's whole register file (round 3): since the staging and the table
-     * read were taken off the stage's critical path it has ~10 % slack against the period, and the
-     * bandwidth kernels' waves that now fit beside it (131 of the CU's 160 KB of LDS are the stage's, so
-     * mostly kernels without LDS) gain more than the stage loses: +2.1 %, +-0, +1.4 % whole path on three
-     * boxes, never slower (stage 1.71 -> 1.83 ms, FIR 1.02 -> 0.97 ms inside the pipeline on the
-     * first).  "serial_claim" = 1 of fmd_batch_debug_set brings the claim back. */
+    /* Two groups per workgroup = one role wave on each SIMD of a CU, 64 CUs for 8192 channels.  The waves do not
+     * claim their SIMD's whole register file (round 3: the bandwidth kernels' waves that fit beside the stage gain
+     * more than it loses, +1-2 % whole path); "serial_claim" = 1 of fmd_batch_debug_set brings the claim back. */
     const bool serial_claim = b->dbg_serial_claim != 0;
     auto kser2 = nomix ? (serial_claim ? &fmd::k_demod_serial<2, true, false> : &fmd::k_demod_serial<2, false, false>)
                        : (serial_claim ? &fmd::k_demod_serial<2, true, true> : &fmd::k_demod_serial<2, false, true>);
@@ -484,13 +475,11 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   const dim3 rt(256);
   auto rgrid = [&](unsigned H) { return dim3((CP + 255) / 256, std::max(1u, std::min(H, 64u))); };
 
-  /* With overlapped calls three things become runnable the moment this call's serial stage ends: the
-   * next call's serial stage (already queued behind it), this call's post chain and the previous
-   * call's light part.  The exclusive serial stage needs EMPTY CUs; when the half-band kernel of the
-   * post chain is dispatched first it fills every CU and the serial stage starts only once those
-   * workgroups have drained (measured: 136 us after its predecessor ended, every call).  So the
-   * post chain and the light part start behind a single wave that idles for a few microseconds:
-   * the serial stage is dispatched first (30-50 us after its predecessor, period 2.50 -> 2.42 ms). */
+  /* With overlapped calls the next call's serial stage and this call's post chain become runnable the moment this
+   * call's serial stage ends.  The whole-CU serial stage needs EMPTY CUs; when the half-band kernel is dispatched first
+   * it fills every CU and the serial stage starts only once those workgroups have drained (136 us late, every call).
+   * So the post chain starts behind a single wave that idles for a few microseconds: the serial stage is dispatched
+   * first (30-50 us after its predecessor, period 2.50 -> 2.42 ms). */
   constexpr unsigned kPostDelayUs = 20;
   // wave priority of the ring resampler in the overlapped pipeline (the half-band chain's stays 0)
   const unsigned rsr_prio = (!serial_mode && b->concurrency == 2) ? 2u : 0u;
@@ -499,10 +488,9 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
       hipLaunchKernelGGL(fmd::k_delay, dim3(1), dim3(64), 0, s, kPostDelayUs * 100u);
   };
 
-  /* The post chain in four pieces.  "Heavy" = bandwidth / LDS bound and filling the chip; "light" =
-   * lane-per-channel recurrences on CP/64 workgroups. */
-  /* History rolls of a chain whose stages all run in their normal regime: collected and done in one
-   * launch at the chain's end (k_roll_set) instead of one launch behind every stage. */
+  /* The post chain: "heavy" = bandwidth / LDS bound and filling the chip, "light" = lane-per-channel recurrences on
+   * CP / 64 workgroups.  History rolls of a chain whose stages all run in their normal regime are collected and done
+   * in one launch at the chain's end (k_roll_set) instead of one launch behind every stage. */
   fmd::RollSet rolls{};
   unsigned nrolls = 0, roll_hmax = 1;
   auto roll_later = [&](const float2* src, float2* dst, unsigned H, unsigned n) {
