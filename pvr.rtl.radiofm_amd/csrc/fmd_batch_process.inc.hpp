@@ -423,12 +423,9 @@ int process_device_impl(fmd_batch* b, const void* d_iq, IqFormat fmt, size_t iq_
   signal(ce[fmd_batch::EV_INDONE], sF);
 
   /* ---- K2: baseband-rate recurrences  (stream S) ---- */
-  // br[q] / mix[q] were last read by the resampler / first half-band two calls ago: this call's FIR
-  // already waited for that call's whole heavy part (EV_HEAVY above), so EV_FIR covers them and the
-  // serial stream carries one wait instead of three between two serial stages
-  // (EV_HEAVY, which that FIR waited for, is recorded in FRONT of the history rolls behind the heavy part,
-  // so that the FIR starts earlier; the rolls read the tails of br[q] / mix[q]: one more wait here, met long
-  // before the FIR's)
+  // br[q] / mix[q] were last read by the resampler / first half-band two calls ago: this call's FIR already waited
+  // for that call's heavy part (EV_HEAVY above), so EV_FIR covers them.  EV_HEAVY is recorded in FRONT of the history
+  // rolls behind the heavy part (the FIR starts earlier); the rolls read the tails of br[q] / mix[q]: EV_ROLL
   if (have_prev2)
     after(sS, pe2[fmd_batch::EV_ROLL]);
   after(sS, ce[fmd_batch::EV_FIR]);
