@@ -400,10 +400,11 @@ def main():
                          "On by default with more than one rank (a multi-GPU number is only reported for "
                          "a gather that was checked); --no-verify turns it off")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--gather-root", default="0", choices=["0", "rotate"],
-                    help="N > 1, RCCL data path: which rank receives a step's outputs -- 0: rank 0, every step (default); "
-                         "rotate: step i goes to rank i %% N (fmd_gather_step_root): rank 0 alone would take 7 x 88 MB "
-                         "of writes per step at 8 GPUs, 8-10 %% of its throughput (emulated: docs/MEASUREMENTS.md)")
+    ap.add_argument("--gather-root", default="rotate", choices=["0", "rotate"],
+                    help="N > 1: which rank receives a step's outputs -- rotate (default): step i goes to rank i %% N "
+                         "(fmd_gather_step_root), every rank takes 1 / N of the receive load; 0: rank 0, every step -- it "
+                         "alone then takes 7 x 88 MB of writes per step at 8 GPUs, 9 %% of its throughput, and the node "
+                         "runs at its pace (emulated on one GPU: docs/MEASUREMENTS.md, round 6)")
     ap.add_argument("--emulate-peers", type=int, default=0, metavar="P",
                     help="sizing of rank 0 on one GPU (with FMD_BENCH_FORCE_DIST=1, a world of one): every step's gather "
                          "also writes what P more ranks' receives would write into rank 0's buffers "
@@ -610,7 +611,7 @@ def main():
     # group decoder would.
     use_export = dist_on or args.verify
     g_audio = g_rds = None
-    rotate = args.gather_root == "rotate" and dist_on and backend == "nccl"
+    rotate = args.gather_root == "rotate" and dist_on
 
     def root_of(i):
         return i % world if rotate else 0
@@ -681,7 +682,7 @@ def main():
                                                 g_rds[slot].data_ptr() if rank == root else None, stream, root=root),
                              root)
         elif use_export:
-            batch.export_rds_device(rds_dev[slot].data_ptr(), RCAP, channel_offset=rank * C,
+            batch.export_rds_device(out_bufs(i)[1].data_ptr(), RCAP, channel_offset=rank * C,
                                     stream=stream, lag=lag)
         if dist_on and gth is None:
             ev = torch.cuda.Event()
@@ -689,10 +690,12 @@ def main():
             if True:  # host-staged over gloo (development aid: several ranks on one GPU)
                 tg0 = time.perf_counter()
                 ev.synchronize()
-                a_h, r_h = audio[slot].cpu(), rds_dev[slot].cpu()
-                w = dg.gather_step(a_h, r_h, list(g_audio[slot]) if rank == 0 else None,
-                                   list(g_rds[slot]) if rank == 0 else None, dst=0, async_op=True)
-                pending[slot] = list(w)
+                root = root_of(i)  # (a rotating root over gloo too: the same host logic as with RCCL, two ranks on one GPU)
+                a_buf, r_buf = out_bufs(i)
+                a_h, r_h = a_buf.cpu(), r_buf.cpu()
+                w = dg.gather_step(a_h, r_h, list(g_audio[slot]) if rank == root else None,
+                                   list(g_rds[slot]) if rank == root else None, dst=root, async_op=True)
+                pending[slot] = [root] + list(w)
                 host_t["gather_host"] = host_t.get("gather_host", 0.0) + (time.perf_counter() - tg0)
         elif use_export and gth is None:  # one rank, --verify: "gathered" = this rank's own outputs
             g_audio[slot][0].copy_(audio[slot], non_blocking=True)
@@ -717,9 +720,9 @@ def main():
             if rank == pending[slot][2]:  # the step's root counts what arrived
                 group_acc.add_((g_rds[slot][:, :, 0] != 0).sum())
         elif isinstance(pending[slot], list):
-            for w in pending[slot]:
+            for w in pending[slot][1:]:
                 w.wait()
-            if rank == 0:
+            if rank == pending[slot][0]:  # the step's root counts what arrived
                 group_acc.add_(int((g_rds[slot][:, :, 0] != 0).sum()))
         else:
             torch.cuda.current_stream().wait_event(pending[slot])  # device-side wait

@@ -81,21 +81,27 @@ def test_rccl_path_with_a_world_of_one():
     assert d["rccl_ranks_seen"] == 1 and d["per_rank"][0]["rccl_rank"] == 0
 
 
-def test_bench_starts_its_own_ranks():
+@pytest.mark.parametrize("root", ["0", "rotate"])
+def test_bench_starts_its_own_ranks(root):
     """The driver's own invocation shape, `python bench.py --gpus 2 ...`, with NO rank variables in the
     environment: bench.py becomes the launcher (before importing torch), starts one child per rank and
     passes rank 0's JSON line through as the last line of stdout.  Two ranks share this box's one GPU
-    (gloo + FMD_BENCH_SHARE_GPU, as above); --verify is on by default with more than one rank."""
+    (gloo + FMD_BENCH_SHARE_GPU, as above); --verify is on by default with more than one rank.  `rotate`: step i is
+    gathered to rank i % 2 -- the host logic of the rotating root (which buffers a step's outputs go to, every root
+    verifying the steps it received, the groups counted over all roots) with two real ranks."""
     env = {k: v for k, v in os.environ.items()
            if k not in ("LD_PRELOAD", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(FMD_BENCH_BACKEND="gloo", FMD_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline",
                           "--channels", "192", "--steps", "30", "--warmup", "3", "--ring", "24",
-                          "--watchdog", "240"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+                          "--watchdog", "240", "--gather-root", root], env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
     last = out.stdout.strip().splitlines()[-1]
     d = json.loads(last)  # the JSON line is the LAST line of stdout
     assert d["n_gpus"] == 2 and d["verify"]["ok"] and d["verify"]["ranks"] == 2
+    assert d["verify"]["per_rank_ok"] == [True, True] and d["config"]["rds_groups_in_timed_region"] >= 0
+    assert ("the root rotates" in d["config"]["gather"]) == (root == "rotate")
     assert [r["rank"] for r in d["per_rank"]] == [0, 1]
     assert all(r["ms_per_step"] > 0 and r["if_fir_ms"] > 0 and r["gather_ms_per_step"] is not None
                for r in d["per_rank"])
