@@ -10,8 +10,8 @@ channels per GPU at 2.4 MS/s (65 536 over 8 GPUs), one step = one ProcessStream 
 IQ samples on every channel: tuner mix -> 88-tap decimating FIR -> FM PLL -> pilot PLL / stereo ->
 RDS chain -> resamplers -> audio filters -> float stereo audio + RDS groups.  Inputs are generated
 on the device and are resident in HBM before the timed region.  With N > 1 every rank owns its
-own channels (no exchange during compute) and rank 0 gathers float audio and RDS groups of
-every step over RCCL.  Prints ONE JSON line on rank 0.
+own channels (no exchange during compute) and float audio and RDS groups of every step are gathered
+over RCCL -- step i to rank i % N (--gather-root 0: to rank 0, every step).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -669,7 +669,7 @@ def main():
 
     def finalize(i, lag):
         """Outputs of step i (call index i+1), complete on the torch stream: with N > 1 its audio and
-        RDS records are gathered to rank 0 over RCCL on the side stream (overlapping the next steps'
+        RDS records are gathered to the step's root over RCCL on the side stream (overlapping the next steps'
         compute); rank 0 counts the groups that arrived."""
         slot = i % NBUF
         if gth is not None:
@@ -1045,10 +1045,10 @@ def main():
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "internal_streams_sharing_a_hw_queue": batch.streams_sharing_queue(),
                        "audio_floats_per_channel_step": nf, "rds_groups_in_timed_region": total_groups,
-                       "gather": ("rank-0 gather of audio + RDS records per step over %s (%d rank%s)"
+                       "gather": ("gather of audio + RDS records per step over %s (%d rank%s)"
                                   % ("RCCL, grouped ncclSend / ncclRecv from C++ (include/fmd_gather.h)"
                                      if backend == "nccl" else backend, world, "" if world == 1 else "s")
-                                  + ("; the root rotates: step i to rank i % N" if rotate else ""))
+                                  + ("; the root rotates: step i to rank i % N" if rotate else "; root: rank 0"))
                        if dist_on else "none (1 GPU)",
                        "emulated_peers": ({"peers": emu_peers, "workgroups_per_peer": args.emulate_wgs,
                                            "channels_per_peer": CMSG, "role": args.emulate_role,
