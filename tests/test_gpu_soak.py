@@ -55,10 +55,11 @@ def _a_stride(pkg, params):
 
 
 def _run(torch, make_batch, iq, iq_stride, w, *, concurrency, lag, calls, debug=(), stalls=False, own_stream=False,
-         channel0=0, keep_audio=0, u8=False):
+         channel0=0, keep_audio=0, u8=False, sizes=None, reset_at=()):
     """One schedule over `calls` calls of the ring `iq`.  Returns (per-call checksums of channels
     [channel0, channel0 + w.shape[0]), their groups sorted, status tuples of four of them, the first `keep_audio`
-    calls' audio of those four, frames per call)."""
+    calls' audio of those four, frames per call).  sizes: IQ samples of call i (default: full blocks); reset_at: calls
+    in front of which the batch is reset (`cFmDecoder::Reset`, FmDecode.cpp:326-338: a drain, then every channel)."""
     b = make_batch()
     C = b.n_channels
     b.set_concurrency(concurrency)
@@ -74,9 +75,11 @@ def _run(torch, make_batch, iq, iq_stride, w, *, concurrency, lag, calls, debug=
     torch.cuda.synchronize()
     CW = w.shape[0]
     sums, nf, groups, kept = [], [], [], []
+    done_upto = 0
     picks = [0, 63, CW // 2, CW - 1]
 
     def finalize(i, lg):
+        assert len(sums) == i
         b.wait(stream=st, lag=lg)
         g = b.collect_rds_array(cap=4 * C, stream=st, lag=lg)
         groups.append(g[(g["channel"] >= channel0) & (g["channel"] < channel0 + CW)])
@@ -88,9 +91,15 @@ def _run(torch, make_batch, iq, iq_stride, w, *, concurrency, lag, calls, debug=
 
     with torch.cuda.stream(cur):
         for i in range(calls):
-            nf.append(b.process_device(iq[i % RING].data_ptr(), iq_stride, N, audio[i % nbuf].data_ptr(), a_stride,
+            if i in reset_at:
+                for j in range(len(sums), i):  # (what the host has not consumed yet)
+                    finalize(j, i - 1 - j)
+                done_upto = i
+                b.reset()
+            n = sizes[i % len(sizes)] if sizes else N
+            nf.append(b.process_device(iq[i % RING].data_ptr(), iq_stride, n, audio[i % nbuf].data_ptr(), a_stride,
                                        st, u8=u8))
-            if i >= lag:
+            if i - lag >= done_upto:
                 finalize(i - lag, lag)
             if stalls:
                 r = rnd.random()
@@ -100,7 +109,7 @@ def _run(torch, make_batch, iq, iq_stride, w, *, concurrency, lag, calls, debug=
                     torch.cuda.synchronize()
                 elif r < 0.16:
                     cur.synchronize()
-        for i in range(calls - lag, calls):  # (lag 0: nothing left)
+        for i in range(len(sums), calls):  # (lag 0: nothing left)
             finalize(i, calls - 1 - i)
     torch.cuda.synchronize()
     assert not b.take_rds_lost()
@@ -171,10 +180,19 @@ def test_config4_every_schedule_the_same_bits_over_300_calls(oracle, fmsig):
     schedules["two post streams"] = dict(concurrency=2, lag=3, debug=(("split_post", 1),))
     for name, kw in schedules.items():
         _same(name, _run(torch, make, iq, N, w, calls=calls, **kw), base)
+    # ragged calls (fewer audio frames than filter taps, odd lengths, full blocks) and two resets under way
+    sizes = [N, 30001, N, 1001, N, N, 330, 65535, N, 12346, N, N, N, 150, N, 33001]
+    rkw = dict(calls=calls // 2, sizes=sizes, reset_at=(calls // 6, calls // 3 + 1))
+    rbase = _run(torch, make, iq, N, w, concurrency=0, lag=0, **rkw)
+    for name in ("light streams, 3 late", "light streams, 1 late", "heavy stream", "own stream", "host stalls",
+                 "host stalls, heavy stream, caller's stream"):
+        _same("ragged, " + name, _run(torch, make, iq, N, w, **rkw, **OVERLAPPED[name]), rbase)
     make_big = lambda: pkg.Batch(params, 2 * C, record_callbacks=False)
     for ch0 in (0, C):
         _same("sub-batch at channel %d" % ch0,
               _run(torch, make_big, big, N, w, concurrency=2, lag=3, calls=calls, stalls=ch0 == C, channel0=ch0), base)
+    _same("ragged, sub-batch at channel %d" % C,
+          _run(torch, make_big, big, N, w, concurrency=2, lag=2, channel0=C, **rkw), rbase)
 
 
 @pytest.mark.parametrize("mode", ["u8", "fma-waived", "shuffle-waived"])
@@ -202,6 +220,10 @@ def test_config4_other_modes_every_schedule_the_same_bits(oracle, fmsig, mode):
                         lambda i: [fmsig.u8_to_f32(iq[i % RING][c].cpu().numpy().reshape(-1)) for c in picks])
     else:
         base = _run(torch, make, iq, N, w, concurrency=1, lag=0, calls=calls)
+        # the check has teeth: the parity mode's audio (~1e-5 RMS away) is another checksum in every call
+        exact = _run(torch, lambda: pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C,
+                                              record_callbacks=False), iq, N, w, concurrency=1, lag=0, calls=12)
+        assert (exact[0] != base[0][:12]).all()
     assert len(base[1]) > 10000
     for name, kw in OVERLAPPED.items():
         _same(name, _run(torch, make, iq, N, w, calls=calls, u8=u8, **kw), base)
