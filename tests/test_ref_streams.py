@@ -1,7 +1,8 @@
 """What the REFERENCE BINARY returned (tests/golden/ref_streams.npz, written by
 `python tools/ref_crosscheck.py --emit ...` in the build container: the reference's own DSP sources,
-compiled there, driven over 16 generator streams / 1233 calls -- three of them stations that send every
-RDS group type in versions A and B, clean and weak) against
+compiled there, driven over 28 generator streams / 1749 calls -- three of them stations that send every
+RDS group type in versions A and B, clean and weak; ten in regimes a clean station never reaches: tuned above the
+centre, over-deviated, noise only, silence, a pilot that comes and goes, off tune) against
 
   * the CPU oracle (`-m "not gpu"`): the restatement meets the reference's recorded outputs on every
     CPU run, not only when somebody re-runs the cross-check tool;
@@ -47,22 +48,14 @@ IDS = [s[0]["name"].replace(" ", "_")[:48] for s in STREAMS]
 
 
 def _blocks(fmsig, d):
-    gen = dict(d["gen"])
-    mono = gen.pop("mono", False)
-    sched = gen.pop("schedule", None)  # a station with a group schedule of its own (every group type, A and B)
-    p = (fmsig.mono_params if mono else fmsig.default_params)(d["fs"], **{"noise_sigma": 0.01, **gen})
-    dbits = fmsig.sched_dbits(fmsig.group_schedule(sched)) if sched else None
-    blocks, pos, sha = [], 0, hashlib.sha256()
-    for n in d["calls"]:
-        if n < 0:
-            blocks.append(None)
-        else:
-            b = fmsig.generate_f32_bits(p, dbits, pos, n) if sched else fmsig.generate_f32(p, pos, n)
-            sha.update(np.ascontiguousarray(b, dtype=np.float32).tobytes())
-            blocks.append(b)
-            pos += n
-    assert sha.hexdigest() == d["iq_sha256"], "the signal generator no longer produces the fixture's input"
+    blocks, sha = fmsig.stream_blocks(d["fs"], d["gen"], d["calls"])
+    assert sha == d["iq_sha256"], "the signal generator no longer produces the fixture's input"
     return blocks
+
+
+def _tune(d):
+    """cFmDecoder's tuning_offset (FmDecode.cpp:250): -0.15 fs unless the stream says otherwise."""
+    return d.get("tune", -0.15) * d["fs"]
 
 
 def _check_call(k, audio, stereo, getters, sha_ref, meta_ref):
@@ -77,7 +70,7 @@ def _check_call(k, audio, stereo, getters, sha_ref, meta_ref):
 @pytest.mark.parametrize("stream", STREAMS, ids=IDS)
 def test_oracle_reproduces_the_reference_records(oracle, fmsig, stream):
     d, sha, meta, frames, name = stream
-    o = oracle.OracleDecoder(d["fs"], -0.15 * d["fs"], 48000.0, 15000.0, d["D"], us_version=bool(d["us"]))
+    o = oracle.OracleDecoder(d["fs"], _tune(d), 48000.0, 15000.0, d["D"], us_version=bool(d["us"]))
     for k, b in enumerate(_blocks(fmsig, d)):
         if b is None:
             o.reset()
@@ -95,9 +88,9 @@ def test_oracle_reproduces_the_reference_records(oracle, fmsig, stream):
 def test_hip_path_reproduces_the_reference_records(fmsig, stream):
     pkg = load_package()
     d, sha, meta, frames, name = stream
-    dec = pkg.FmDecoder(d["fs"], -0.15 * d["fs"], 48000.0, 15000.0, d["D"], bool(d["us"]))
+    dec = pkg.FmDecoder(d["fs"], _tune(d), 48000.0, 15000.0, d["D"], bool(d["us"]))
     smallest = min(n for n in d["calls"] if n >= 0)
-    probe = pkg.Batch(pkg.make_params(d["fs"], -0.15 * d["fs"], 48000.0, 15000.0, d["D"], bool(d["us"])), 1)
+    probe = pkg.Batch(pkg.make_params(d["fs"], _tune(d), 48000.0, 15000.0, d["D"], bool(d["us"])), 1)
     min_samples = probe.min_samples()
     probe.close()
     if smallest < min_samples:

@@ -119,6 +119,41 @@ def generate_f32_bits(p, dbits, start, n):
     return out
 
 
+def stream_blocks(fs, gen, calls):
+    """The IQ blocks of a recorded stream (tests/golden/ref_streams.npz, tools/ref_crosscheck.py): `calls` = samples
+    per call (-1 = Reset -> None), `gen` = generator fields plus
+      mono      config-1 style station (no pilot, no RDS)
+      schedule  a named group schedule (group_schedule) instead of the repeating 0A group
+      alt, alt_calls   other generator fields for the calls [a, b) of every pair in alt_calls (a pilot that goes
+                away and comes back, ...); the sample position runs on
+      gain      per-call factor applied to the float samples (0 = a block of zeros: silence)
+    Returns (blocks, SHA-256 of all samples)."""
+    import hashlib
+    gen = dict(gen)
+    mono = gen.pop("mono", False)
+    sched = gen.pop("schedule", None)
+    gain = gen.pop("gain", None)
+    alt = gen.pop("alt", None)
+    alt_calls = gen.pop("alt_calls", [])
+    mk = mono_params if mono else default_params
+    p = mk(fs, **{"noise_sigma": 0.01, **gen})
+    p_alt = mk(fs, **{"noise_sigma": 0.01, **gen, **alt}) if alt else None
+    dbits = sched_dbits(group_schedule(sched)) if sched else None
+    blocks, pos, sha = [], 0, hashlib.sha256()
+    for k, n in enumerate(calls):
+        if n < 0:
+            blocks.append(None)
+            continue
+        q = p_alt if any(a <= k < b for a, b in alt_calls) else p
+        b = generate_f32_bits(q, dbits, pos, n) if sched else generate_f32(q, pos, n)
+        if gain is not None and gain[k] != 1.0:
+            b = np.zeros_like(b) if gain[k] == 0.0 else (b * np.float32(gain[k])).astype(np.float32)
+        sha.update(np.ascontiguousarray(b, dtype=np.float32).tobytes())
+        blocks.append(b)
+        pos += n
+    return blocks, sha.hexdigest()
+
+
 def block_b(group, ver_b=0, tp=0, pty=10, low5=0):
     """Second block of a group: type, version, TP, PTY and the five type-specific bits."""
     return (group << 12) | (int(ver_b) << 11) | (int(tp) << 10) | (pty << 5) | (low5 & 0x1F)

@@ -344,6 +344,31 @@ def streams(quick):
         ("6.4 MS/s, D = 1: CIC stage in front of the half-bands", 6.4e6, 1, 0, {"seed": 25},
          [32000] * 10 + [20000, 4000, 32000, 2048, 32000, 32000] + [32000] * 150),
         ("12 MS/s, D = 1: two CIC stages", 12.0e6, 1, 0, {"seed": 26}, [32000] * 12 + [16000, 32000]),
+        # (round 6) the branches an ordinary station on -0.15 fs never takes
+        # tuned ABOVE the centre: a negative table step, C's % on a negative product (FmDecode.cpp:45-58)
+        ("2.4 MS/s tuned +0.15 fs: negative tuner step", 2.4e6, 11, 0,
+         {"seed": 27, "f_offset": 0.15 * 2.4e6, "tune": 0.15}, full(30)),
+        ("1.0 MS/s tuned +0.25 fs", 1.0e6, 4, 0, {"seed": 28, "f_offset": 0.25e6, "tune": 0.25}, full(24)),
+        # lrint's round-half-even on the table step (FmDecode.cpp:250): -64 * tune = 10.5 -> 10, 9.5 -> 10
+        ("2.4 MS/s tuned -0.1640625 fs: step 10.5 rounds to even", 2.4e6, 11, 0,
+         {"seed": 29, "f_offset": -0.15625 * 2.4e6, "tune": -0.1640625}, full(20)),
+        ("2.4 MS/s tuned -0.1484375 fs: step 9.5 rounds to even", 2.4e6, 11, 0,
+         {"seed": 30, "f_offset": -0.15625 * 2.4e6, "tune": -0.1484375}, full(20)),
+        # 250 kHz of deviation: the FM PLL's NCO runs into its +-0.95 pi limits (FmDecode.cpp:305-312, 394-399)
+        ("2.4 MS/s over-deviated (250 kHz): NCO at its limits", 2.4e6, 11, 0, {"seed": 31, "dev": 250e3}, full(24)),
+        # no station at all: both PLLs wander, arctangent over all quadrants, the RDS state machine never syncs
+        ("2.4 MS/s noise only", 2.4e6, 11, 0, {"seed": 32, "amp": 0.0, "noise_sigma": 0.3}, full(24)),
+        # silence (blocks of zeros: atan2f(0, 0), empty meters), then 1e-4 and 4x of the normal amplitude
+        ("2.4 MS/s silence, tiny and huge amplitude", 2.4e6, 11, 0,
+         {"seed": 33, "gain": [1.0] * 18 + [0.0] * 5 + [1.0] * 14 + [1e-4] * 5 + [4.0] * 6 + [1.0] * 12}, full(60)),
+        # the pilot goes away and comes back: the stereo decision's lock counter (FmDecode.cpp:143-229), mono
+        # matrix in between (FmDecode.cpp:488-499)
+        ("2.4 MS/s pilot lost for 16 blocks and back", 2.4e6, 11, 0,
+         {"seed": 34, "alt": {"a_pilot": 0.0, "a_stereo": 0.0}, "alt_calls": [[24, 40]]}, full(70)),
+        # a station 30 kHz off the tuned frequency: the DC tracker and GetTuningOffset (FmDecode.cpp:361-415)
+        ("2.4 MS/s station 30 kHz off tune", 2.4e6, 11, 0, {"seed": 35, "f_offset": -0.15 * 2.4e6 + 30e3}, full(24)),
+        ("2.4 MS/s station 30 kHz off tune, 75 us, weak", 2.4e6, 11, 1,
+         {"seed": 36, "f_offset": -0.15 * 2.4e6 - 30e3, "noise_sigma": 0.08}, full(40)),
     ]
     if quick:
         s = [(n, fs, D, us, kw, calls[:max(6, len(calls) // 5)]) for n, fs, D, us, kw, calls in s]
@@ -496,34 +521,22 @@ def main():
         bad += check_fir(td, exes["reffir"], args)
         for name, fs, D, us, kw, calls in streams(args.quick):
             kw = dict(kw)
-            mono = kw.pop("mono", False)
-            sched = kw.pop("schedule", None)
-            p = (fmsig_py.mono_params if mono else fmsig_py.default_params)(fs, **{"noise_sigma": 0.01, **kw})
-            dbits = fmsig_py.sched_dbits(fmsig_py.group_schedule(sched)) if sched else None
-            blocks, pos = [], 0
-            for n in calls:
-                if n < 0:
-                    blocks.append(None)
-                else:
-                    blocks.append(fmsig_py.generate_f32_bits(p, dbits, pos, n) if sched
-                                  else fmsig_py.generate_f32(p, pos, n))
-                    pos += n
+            tune = kw.pop("tune", -0.15)  # cFmDecoder's tuning_offset as a fraction of fs
+            if args.quick and "gain" in kw:
+                kw["gain"] = kw["gain"][:len(calls)]
+            blocks, iq_sha = fmsig_py.stream_blocks(fs, kw, calls)
             fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
             with open(fin, "wb") as f:
-                f.write(struct.pack("<ddIII", fs, -0.15 * fs, D, us, len(calls)))
+                f.write(struct.pack("<ddIII", fs, tune * fs, D, us, len(calls)))
                 for n, b in zip(calls, blocks):
                     f.write(struct.pack("<i", n))
                     if b is not None:
                         f.write(np.ascontiguousarray(b, dtype=np.float32).tobytes())
             subprocess.check_call([exe, fin, fout])
             raw = open(fout, "rb").read()
-            o = oracle_py.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D, us_version=bool(us))
+            o = oracle_py.OracleDecoder(fs, tune * fs, 48000.0, 15000.0, D, us_version=bool(us))
             at, nbad = 0, 0
             rec_sha, rec_meta = [], []
-            iq_sha = hashlib.sha256()
-            for b in blocks:
-                if b is not None:
-                    iq_sha.update(np.ascontiguousarray(b, dtype=np.float32).tobytes())
             for k, (n, b) in enumerate(zip(calls, blocks)):
                 (nf,) = struct.unpack_from("<I", raw, at)
                 at += 4
@@ -567,9 +580,8 @@ def main():
             if args.emit:
                 i = len(emit) // 6
                 emit["s%02d_def" % i] = np.array(json.dumps(
-                    {"name": name, "fs": fs, "D": D, "us": us,
-                     "gen": dict(kw, mono=mono, **({"schedule": sched} if sched else {})), "calls": calls,
-                     "iq_sha256": iq_sha.hexdigest()}))
+                    {"name": name, "fs": fs, "D": D, "us": us, "tune": tune, "gen": kw, "calls": calls,
+                     "iq_sha256": iq_sha}))
                 emit["s%02d_audio_sha256" % i] = np.stack(rec_sha)
                 emit["s%02d_meta" % i] = np.array(rec_meta, dtype=np.uint32)  # nfloats, stereo, 4 getters' bits
                 emit["s%02d_frames" % i] = np.frombuffer(b"".join(fr_ref), dtype=np.uint8)
