@@ -259,6 +259,14 @@ inline Design make_design(const Params& p)
 {
   if (!(p.sample_rate_if > 0) || !(p.sample_rate_pcm > 0))
     throw std::invalid_argument("fmd: sample rates must be positive");
+  // The 19 kHz notch (cIirFilter::Init(ftBR, 19000, 5, pcm rate), FmDecode.cpp:285 / IirFilter.cpp:11-60) has its
+  // centre at or beyond Nyquist there: alpha = sin(w0) / 2Q <= 0, the poles leave the unit circle, and the
+  // reference's own audio runs away to NaN within a few blocks (cRadioReceiver only ever asks for 48 kHz,
+  // RadioReceiver.cpp:185).  Garbage cannot be met bit for bit (the sign of an invalid-operation NaN is the
+  // machine's): refused.
+  if (!(p.sample_rate_pcm > 2.0 * 19000.0))
+    throw std::invalid_argument("fmd: sample_rate_pcm must be above 38 kHz (the reference's 19 kHz notch filter is "
+                                "unstable at and below it: its audio diverges to NaN)");
   Design d{};
   d.D = p.downsample ? p.downsample : 1;
   d.fs_if = float(p.sample_rate_if);

@@ -96,6 +96,12 @@ def test_call_size_limits(fmsig):
     # unsupported configurations fail at construction, loudly
     with pytest.raises(pkg.FmdError):
         pkg.Batch(pkg.make_params(0.0, 0.0), 1)
+    # a PCM rate at or below 38 kHz: the reference's 19 kHz notch (FmDecode.cpp:285) is unstable there and its own
+    # audio diverges to NaN within a few blocks -- nothing to be bit-exact with
+    for pcm in (32000.0, 38000.0):
+        with pytest.raises(pkg.FmdError, match="38 kHz"):
+            pkg.Batch(pkg.make_params(2.4e6, -0.36e6, pcm, 14400.0, 11), 1)
+    pkg.Batch(pkg.make_params(2.4e6, -0.36e6, 38100.0, 15000.0, 11), 1).close()
     # (a baseband rate of 5.33 MHz and more -- the CIC stage -- is decoded since round 6: test_cic_first_stage)
     # the serial stage addresses its row buffers with 32-bit lane offsets: a batch that would pass 4 GB in one of
     # them (9000 channels without decimation: 65552 * 9000 * 8 bytes of IF-FIR output) runs as sub-batches that

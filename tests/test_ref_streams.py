@@ -1,6 +1,6 @@
 """What the REFERENCE BINARY returned (tests/golden/ref_streams.npz, written by
 `python tools/ref_crosscheck.py --emit ...` in the build container: the reference's own DSP sources,
-compiled there, driven over 28 generator streams / 1749 calls -- three of them stations that send every
+compiled there, driven over 32 generator streams / 1845 calls -- three of them stations that send every
 RDS group type in versions A and B, clean and weak; ten in regimes a clean station never reaches: tuned above the
 centre, over-deviated, noise only, silence, a pilot that comes and goes, off tune) against
 
@@ -58,6 +58,11 @@ def _tune(d):
     return d.get("tune", -0.15) * d["fs"]
 
 
+def _pcm(d):
+    """sample_rate_pcm, bandwidth_pcm (FmDecode.h:110-116)."""
+    return d.get("pcm", 48000.0), d.get("bw", 15000.0)
+
+
 def _check_call(k, audio, stereo, getters, sha_ref, meta_ref):
     assert audio.size == int(meta_ref[0]), (k, audio.size, int(meta_ref[0]))
     got = np.frombuffer(hashlib.sha256(np.ascontiguousarray(audio, dtype=np.float32).tobytes()).digest(), np.uint8)
@@ -70,7 +75,7 @@ def _check_call(k, audio, stereo, getters, sha_ref, meta_ref):
 @pytest.mark.parametrize("stream", STREAMS, ids=IDS)
 def test_oracle_reproduces_the_reference_records(oracle, fmsig, stream):
     d, sha, meta, frames, name = stream
-    o = oracle.OracleDecoder(d["fs"], _tune(d), 48000.0, 15000.0, d["D"], us_version=bool(d["us"]))
+    o = oracle.OracleDecoder(d["fs"], _tune(d), *_pcm(d), d["D"], us_version=bool(d["us"]))
     for k, b in enumerate(_blocks(fmsig, d)):
         if b is None:
             o.reset()
@@ -88,9 +93,9 @@ def test_oracle_reproduces_the_reference_records(oracle, fmsig, stream):
 def test_hip_path_reproduces_the_reference_records(fmsig, stream):
     pkg = load_package()
     d, sha, meta, frames, name = stream
-    dec = pkg.FmDecoder(d["fs"], _tune(d), 48000.0, 15000.0, d["D"], bool(d["us"]))
+    dec = pkg.FmDecoder(d["fs"], _tune(d), *_pcm(d), d["D"], bool(d["us"]))
     smallest = min(n for n in d["calls"] if n >= 0)
-    probe = pkg.Batch(pkg.make_params(d["fs"], _tune(d), 48000.0, 15000.0, d["D"], bool(d["us"])), 1)
+    probe = pkg.Batch(pkg.make_params(d["fs"], _tune(d), *_pcm(d), d["D"], bool(d["us"])), 1)
     min_samples = probe.min_samples()
     probe.close()
     if smallest < min_samples:

@@ -90,21 +90,22 @@ DRIVER = r"""
 #include <vector>
 #include "FmDecode.h"
 #include "RadioReceiver.h"
-// in : double fs, offset; u32 D, us, ncalls; then per call: i32 n (-1 = Reset()), n complex<float>
+// in : double fs, offset, pcm rate, pcm bandwidth; u32 D, us, ncalls; then per call: i32 n (-1 = Reset()), n complex<float>
 // out: per call: u32 nfloats, floats, i32 stereo, 4 floats (tuning, if, baseband, pilot); at the end:
 //      u32 nframes, per frame u32 len + bytes; u32 nnames, per name u32 len + bytes
 int main(int argc, char** argv)
 {
   FILE* in = fopen(argv[1], "rb");
   FILE* out = fopen(argv[2], "wb");
-  double fs, off;
+  double fs, off, pcm, bw;
   unsigned D, us, ncalls;
-  if (!in || !out || fread(&fs, 8, 1, in) != 1 || fread(&off, 8, 1, in) != 1 || fread(&D, 4, 1, in) != 1 ||
+  if (!in || !out || fread(&fs, 8, 1, in) != 1 || fread(&off, 8, 1, in) != 1 || fread(&pcm, 8, 1, in) != 1 ||
+      fread(&bw, 8, 1, in) != 1 || fread(&D, 4, 1, in) != 1 ||
       fread(&us, 4, 1, in) != 1 || fread(&ncalls, 4, 1, in) != 1)
     return 2;
   cRadioReceiver rx;
   void* mem = calloc(1, sizeof(cFmDecoder)); // members the constructor leaves alone read zero
-  cFmDecoder* dec = new (mem) cFmDecoder(&rx, fs, off, 48000.0, 15000.0, D, us != 0);
+  cFmDecoder* dec = new (mem) cFmDecoder(&rx, fs, off, pcm, bw, D, us != 0);
   std::vector<ComplexType> iq(65536);
   std::vector<float> audio(2 * 65536);
   for (unsigned k = 0; k < ncalls; k++)
@@ -369,6 +370,15 @@ def streams(quick):
         ("2.4 MS/s station 30 kHz off tune", 2.4e6, 11, 0, {"seed": 35, "f_offset": -0.15 * 2.4e6 + 30e3}, full(24)),
         ("2.4 MS/s station 30 kHz off tune, 75 us, weak", 2.4e6, 11, 1,
          {"seed": 36, "f_offset": -0.15 * 2.4e6 - 30e3, "noise_sigma": 0.08}, full(40)),
+        # other PCM rates and bandwidths (the constructor takes any, FmDecode.h:110-116; cRadioReceiver passes
+        # 48000 and min(15000, 0.45 * rate), RadioReceiver.cpp:185, 289): resampler step and cutoff, the Kaiser
+        # low-pass's length (27 / 25 / 58 taps), notch and de-emphasis coefficients
+        ("2.4 MS/s, 44.1 kHz PCM", 2.4e6, 11, 0, {"seed": 37, "pcm": 44100.0}, full(24)),
+        # (at and below 38 kHz the reference's 19 kHz notch is unstable and its audio runs away to NaN: refused by
+        # the product, not recorded; 40 kHz: the low-pass's 21 kHz stop edge lies beyond Nyquist)
+        ("2.4 MS/s, 40 kHz PCM", 2.4e6, 11, 0, {"seed": 38, "pcm": 40000.0}, full(24)),
+        ("1.0 MS/s, 96 kHz PCM", 1.0e6, 4, 0, {"seed": 39, "pcm": 96000.0}, full(24)),
+        ("2.4 MS/s, 48 kHz PCM, 10 kHz bandwidth, 75 us", 2.4e6, 11, 1, {"seed": 40, "bw": 10000.0}, full(24)),
     ]
     if quick:
         s = [(n, fs, D, us, kw, calls[:max(6, len(calls) // 5)]) for n, fs, D, us, kw, calls in s]
@@ -522,19 +532,20 @@ def main():
         for name, fs, D, us, kw, calls in streams(args.quick):
             kw = dict(kw)
             tune = kw.pop("tune", -0.15)  # cFmDecoder's tuning_offset as a fraction of fs
+            pcm, bw = kw.pop("pcm", 48000.0), kw.pop("bw", 15000.0)  # sample_rate_pcm, bandwidth_pcm
             if args.quick and "gain" in kw:
                 kw["gain"] = kw["gain"][:len(calls)]
             blocks, iq_sha = fmsig_py.stream_blocks(fs, kw, calls)
             fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
             with open(fin, "wb") as f:
-                f.write(struct.pack("<ddIII", fs, tune * fs, D, us, len(calls)))
+                f.write(struct.pack("<ddddIII", fs, tune * fs, pcm, bw, D, us, len(calls)))
                 for n, b in zip(calls, blocks):
                     f.write(struct.pack("<i", n))
                     if b is not None:
                         f.write(np.ascontiguousarray(b, dtype=np.float32).tobytes())
             subprocess.check_call([exe, fin, fout])
             raw = open(fout, "rb").read()
-            o = oracle_py.OracleDecoder(fs, tune * fs, 48000.0, 15000.0, D, us_version=bool(us))
+            o = oracle_py.OracleDecoder(fs, tune * fs, pcm, bw, D, us_version=bool(us))
             at, nbad = 0, 0
             rec_sha, rec_meta = [], []
             for k, (n, b) in enumerate(zip(calls, blocks)):
@@ -580,7 +591,7 @@ def main():
             if args.emit:
                 i = len(emit) // 6
                 emit["s%02d_def" % i] = np.array(json.dumps(
-                    {"name": name, "fs": fs, "D": D, "us": us, "tune": tune, "gen": kw, "calls": calls,
+                    {"name": name, "fs": fs, "D": D, "us": us, "tune": tune, "pcm": pcm, "bw": bw, "gen": kw, "calls": calls,
                      "iq_sha256": iq_sha}))
                 emit["s%02d_audio_sha256" % i] = np.stack(rec_sha)
                 emit["s%02d_meta" % i] = np.array(rec_meta, dtype=np.uint32)  # nfloats, stereo, 4 getters' bits
