@@ -311,6 +311,36 @@ def fir_cases():
     return out
 
 
+def fuzz_streams(count, seed=20261003):
+    """Random points of the constructor's parameter space and of the signal's (a fixed seed: the same list every
+    time): IF rate, downsample (baseband 180-420 kHz), tuning offset anywhere in +-0.4 fs with the station up to
+    20 kHz beside it, PCM rate and bandwidth, 50 / 75 us, deviation, amplitude, noise, pilot and RDS levels, tones,
+    call sizes from 2000 samples to full blocks with a Reset now and then."""
+    import random
+    r = random.Random(seed)
+    out = []
+    for i in range(count):
+        fs = r.choice([250e3, 400e3, 1.0e6, 1.2e6, 1.44e6, 1.8e6, 2.048e6, 2.4e6, 2.56e6, 2.88e6, 3.2e6])
+        ds = [d for d in range(1, 20) if 180e3 <= fs / d <= 420e3]
+        D = r.choice(ds)
+        tune = round(r.uniform(-0.4, 0.4), 4)
+        pcm = r.choice([48000.0, 48000.0, 44100.0, 40000.0, 64000.0, 96000.0])
+        bw = r.choice([15000.0, 15000.0, 12000.0, min(15000.0, 0.45 * pcm), 17000.0])
+        us = r.random() < 0.3
+        gen = {"seed": 1000 + i, "f_offset": tune * fs + r.uniform(-20e3, 20e3), "tune": tune, "pcm": pcm, "bw": bw,
+               "dev": r.choice([75e3, 75e3, 40e3, 100e3, 130e3]), "amp": round(r.uniform(0.05, 0.9), 3),
+               "noise_sigma": round(10 ** r.uniform(-3, -0.8), 4), "a_pilot": r.choice([0.09, 0.09, 0.05, 0.0, 0.12]),
+               "a_rds": r.choice([0.06, 0.06, 0.03, 0.0, 0.1]), "f_left": round(r.uniform(100, 9000), 1),
+               "f_right": round(r.uniform(100, 9000), 1), "pi": r.randrange(1, 0xFFFF)}
+        nmax = min(N, 32700 * D)  # (baseband block + 51 <= the reference's 32768-entry half-band buffers: include/fmd.h)
+        calls = []
+        for _ in range(r.randrange(8, 15)):
+            u = r.random()
+            calls.append(nmax if u < 0.5 else -1 if u < 0.56 and calls else r.randrange(2000, nmax + 1))
+        out.append(("fuzz %02d: %g MS/s D=%d tune %+.3f pcm %g" % (i, fs / 1e6, D, tune, pcm), fs, D, int(us), gen, calls))
+    return out
+
+
 def streams(quick):
     """(name, fs, D, us, generator kwargs, list of call sizes; -1 = Reset)."""
     full = lambda k: [N] * k  # noqa: E731
@@ -380,6 +410,7 @@ def streams(quick):
         ("1.0 MS/s, 96 kHz PCM", 1.0e6, 4, 0, {"seed": 39, "pcm": 96000.0}, full(24)),
         ("2.4 MS/s, 48 kHz PCM, 10 kHz bandwidth, 75 us", 2.4e6, 11, 1, {"seed": 40, "bw": 10000.0}, full(24)),
     ]
+    s += fuzz_streams(40)
     if quick:
         s = [(n, fs, D, us, kw, calls[:max(6, len(calls) // 5)]) for n, fs, D, us, kw, calls in s]
     return s
