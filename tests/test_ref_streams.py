@@ -113,3 +113,49 @@ def test_hip_path_reproduces_the_reference_records(fmsig, stream):
                     sha[k], meta[k])
     assert dec.sink.frames.get(0, []) == frames
     assert dec.sink.names.get(0, "")[:8] == name[:8]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stream", STREAMS, ids=IDS)
+def test_batch_dispatch_reproduces_the_reference_records(fmsig, stream):
+    """The same records through the dispatch the benchmark runs: a batch of 1024 channels (the whole-CU serial
+    stage, the two-tile IF kernel where the geometry has one, the ring resampler, the light part's streams),
+    overlapped calls on device buffers, every channel fed the stream -- three channels' audio, status getters, UECP
+    frames and name against what the reference's own code returned."""
+    import torch
+    pkg = load_package()
+    d, sha, meta, frames, name = stream
+    C, check = 1024, (0, 511, 1023)
+    params = pkg.make_params(d["fs"], _tune(d), *_pcm(d), d["D"], bool(d["us"]))
+    b = pkg.Batch(params, C)
+    if min(n for n in d["calls"] if n >= 0) < b.min_samples():
+        b.close()
+        pytest.skip("calls below fmd_batch_min_samples()")
+    b.set_concurrency(2)
+    a_stride = (b.max_audio_floats(65536) + 63) // 64 * 64
+    audio = torch.zeros((C, a_stride), dtype=torch.float32, device="cuda")
+    iq = torch.zeros((C, 65536, 2), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for k, blk in enumerate(_blocks(fmsig, d)):
+        if blk is None:
+            b.reset()
+            for c in check:
+                s = b.status(c)
+                _check_call(k, np.zeros(0, np.float32), s.stereo_detected,
+                            [s.tuning_offset, s.interface_level, s.baseband_level, s.pilot_level], sha[k], meta[k])
+            continue
+        n = blk.size // 2
+        iq[:, :n] = torch.from_numpy(blk).cuda().view(1, n, 2)
+        nf = b.process_device(iq.data_ptr(), 65536, n, audio.data_ptr(), a_stride, st)
+        b.wait(stream=st)
+        b.collect_rds_array(cap=4 * C, run_group_decoder=True, stream=st)
+        torch.cuda.synchronize()
+        a = audio[list(check), :nf].cpu().numpy()
+        for j, c in enumerate(check):
+            s = b.status(c)
+            _check_call(k, a[j], s.stereo_detected,
+                        [s.tuning_offset, s.interface_level, s.baseband_level, s.pilot_level], sha[k], meta[k])
+    for c in check:
+        assert b.sink.frames.get(c, []) == frames, c
+        assert b.sink.names.get(c, "")[:8] == name[:8], c
+    b.close()
