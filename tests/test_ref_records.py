@@ -88,6 +88,28 @@ def test_oracle_group_decoder_reproduces_the_reference_frames(oracle, rec):
     assert o.channel_name()[:8] == (names[-1] if names else "")
 
 
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_product_group_decoder_against_the_oracle_on_arbitrary_groups(pkg, oracle, k):
+    """20 000 arbitrary groups per style (tools/ref_crosscheck.py::fuzz_group_lists: noise; one station with counting
+    segment addresses and text bytes incl. the control characters the text decoders look for; the same with the
+    station changing) through the product's host group decoder and the oracle's: the same frames, the same name.
+    (`tools/ref_crosscheck.py --fuzz-groups 12 --only-groups` ran twelve such lists of 50 000 through the
+    REFERENCE'S DecodeRDS in the build container: oracle == reference on all 600 000 groups / 994 000 frames.)"""
+    from tools.ref_crosscheck import fuzz_group_lists
+    name, groups = fuzz_group_lists(k + 1, n=20000)[k]
+    L = oracle.lib()
+    L.fmo_debug_push_group.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    o = oracle.OracleDecoder(2.4e6, -0.36e6, 48000.0, 15000.0, 11)
+    gd = pkg.GroupDecoder()
+    for g in groups:
+        row = [int(x) for x in g]
+        L.fmo_debug_push_group(o._h, (ctypes.c_uint16 * 4)(*row))
+        gd.push(row)
+    fr = o.uecp_frames()
+    assert len(fr) > 20000 and gd.frames == fr, name
+    assert gd.name[:8] == o.channel_name()[:8]
+
+
 def _fir_blocks(fmsig, d):
     p = fmsig.default_params(d["fs"], noise_sigma=0.01, seed=d["seed"])
     blocks, pos, sha = [], 0, hashlib.sha256()

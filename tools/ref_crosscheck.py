@@ -434,6 +434,52 @@ def _read_frames(raw, at):
     return frames, names, at
 
 
+def fuzz_group_lists(count, n=50000):
+    """`count` more lists of n groups each, checked but not recorded (--fuzz-groups): arbitrary payloads in three
+    styles -- pure noise; one station with segment addresses that mostly count up per type and version, text bytes
+    that are mostly printable with the control characters the text decoders look for (0x0A, 0x0B, 0x0D, 0x1F) mixed
+    in; the same with the station changing every few hundred groups."""
+    import numpy as np
+    out = []
+    for k in range(count):
+        rng = np.random.default_rng(777000 + k)
+        style = k % 3
+        pis = [int(x) for x in rng.integers(0, 65536, 4)] + [0]
+        cur = pis[0]
+        ctr = {}
+        g = []
+        for i in range(n):
+            if style == 2 and rng.random() < 0.004:
+                cur = pis[int(rng.integers(0, len(pis)))]
+            if style == 0:
+                g.append((pis[int(rng.integers(0, 3))], int(rng.integers(0, 65536)), int(rng.integers(0, 65536)),
+                          int(rng.integers(0, 65536))))
+                continue
+            t, v = int(rng.integers(0, 16)), int(rng.integers(0, 2))
+            if rng.random() < 0.5:
+                t = [0, 2, 2, 4, 10, 3, 14, 1][int(rng.integers(0, 8))]
+            key = (t, v)
+            low5 = ctr.get(key, 0) if rng.random() < 0.8 else int(rng.integers(0, 32))
+            ctr[key] = (low5 + 1) & 31
+            if rng.random() < 0.02:
+                ctr[key] ^= 16  # a text A/B flag toggles
+            b = (t << 12) | (v << 11) | (int(rng.integers(0, 64)) << 5) | low5
+
+            def word():
+                if rng.random() < 0.7:
+                    ch = [int(rng.integers(0x20, 0x7F)) if rng.random() < 0.9
+                          else [0x0A, 0x0B, 0x0D, 0x1F, 0x00, 0xFF, 0xFE, 0xFD][int(rng.integers(0, 8))] for _ in range(2)]
+                    return (ch[0] << 8) | ch[1]
+                return int(rng.integers(0, 65536))
+            c = cur if (v and rng.random() < 0.9) else word()
+            d = word()
+            if t == 3 and v == 0:
+                d = [0x4BD7, 0xCD46, d][int(rng.integers(0, 3))]
+            g.append((cur, b, c, d))
+        out.append(("fuzz list %d (style %d)" % (k, style), np.array(g, dtype=np.uint16).reshape(-1, 4)))
+    return out
+
+
 def check_groups(td, exe, args):
     """Group lists through the reference's DecodeRDS and through the oracle's group decoder."""
     import ctypes
@@ -441,7 +487,8 @@ def check_groups(td, exe, args):
     L = oracle_py.lib()
     L.fmo_debug_push_group.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     bad, emit = 0, {}
-    for i, (name, g) in enumerate(group_sequences()):
+    recorded = group_sequences()
+    for i, (name, g) in enumerate(recorded + fuzz_group_lists(args.fuzz_groups)):
         fin, fout = os.path.join(td, "g_in.bin"), os.path.join(td, "g_out.bin")
         with open(fin, "wb") as f:
             f.write(struct.pack("<I", len(g)))
@@ -458,6 +505,8 @@ def check_groups(td, exe, args):
             name, len(g), len(frames), len(names), "equal" if ok else "DIFFER (oracle has %d frames, name %r / %r)" % (
                 len(fr_o), o.channel_name(), last)))
         bad += not ok
+        if i >= len(recorded):
+            continue
         emit["g%02d_name" % i] = np.array(name)
         emit["g%02d_groups" % i] = g
         emit["g%02d_frames" % i] = np.frombuffer(b"".join(frames), dtype=np.uint8)
@@ -534,6 +583,9 @@ def main():
     ap.add_argument("--keep", action="store_true", help="keep the temporary directory (prints its path)")
     ap.add_argument("--quick", action="store_true", help="a fifth of every stream")
     ap.add_argument("--emit", metavar="NPZ", help="write the reference binary's outputs as a fixture")
+    ap.add_argument("--fuzz-groups", type=int, default=0, metavar="K",
+                    help="K more lists of 50 000 arbitrary groups each through DecodeRDS (checked, not recorded)")
+    ap.add_argument("--only-groups", action="store_true", help="stop after the group lists")
     args = ap.parse_args()
     emit = {}
     if not os.path.isdir(REF):
@@ -559,6 +611,9 @@ def main():
         exe = exes["refdrv"]
         bad = 0
         bad += check_groups(td, exes["refgroups"], args)
+        if args.only_groups:
+            print("ref_crosscheck: group lists: %s" % ("oracle == reference" if not bad else "%d MISMATCHES" % bad))
+            return 1 if bad else 0
         bad += check_fir(td, exes["reffir"], args)
         for name, fs, D, us, kw, calls in streams(args.quick):
             kw = dict(kw)
