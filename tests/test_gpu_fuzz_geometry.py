@@ -137,3 +137,71 @@ def test_random_geometry_bit_exact(oracle, fmsig, case):
                       if ch == c)
         assert mine == sorted((k, tuple(bl)) for k, bl in refs[c].rds_groups()), c
     b.close()
+
+
+def _drive(pkg, torch, oracle, fmsig, fs, D, C, calls, seed, stream, results, key, barrier=None):
+    """One overlapped batch, outputs consumed a call late, three channels against the oracle; errors into results."""
+    try:
+        with torch.cuda.stream(stream):
+            st = stream.cuda_stream
+            gen = fmsig.DeviceGenerator([fmsig.channel_params(fs, c, base_seed=seed) for c in range(C)], "cuda")
+            b = pkg.Batch(pkg.make_params(fs, -0.15 * fs, 48000.0, 15000.0, D), C, record_callbacks=False)
+            b.set_concurrency(2)
+            check = [0, C // 2, C - 1]
+            refs = {c: oracle.OracleDecoder(fs, -0.15 * fs, 48000.0, 15000.0, D) for c in check}
+            a_stride = (b.max_audio_floats(N) + 63) // 64 * 64
+            audio = [torch.zeros((C, a_stride), dtype=torch.float32, device="cuda") for _ in range(2)]
+            iq = [torch.zeros((C, N, 2), dtype=torch.float32, device="cuda") for _ in range(2)]
+            nfs, pos = [], 0
+
+            def verify(k, lg):
+                b.wait(stream=st, lag=lg)
+                b.collect_rds_array(cap=4 * C, stream=st, lag=lg)
+                stream.synchronize()
+                a = audio[k % 2][:, :nfs[k]].cpu().numpy()
+                for c in check:
+                    ref = refs[c].process_stream(iq[k % 2][c, :calls[k]].cpu().numpy().reshape(-1))
+                    assert ref.size == nfs[k] and np.array_equal(a[c].view(np.uint32), ref.view(np.uint32)), (key, k, c)
+
+            for k, n in enumerate(calls):
+                blk = torch.zeros((C, n, 2), dtype=torch.float32, device="cuda")
+                gen.generate(blk, pos, n)
+                iq[k % 2][:, :n] = blk
+                stream.synchronize()
+                if barrier is not None:
+                    barrier.wait()  # both threads submit at the same moment
+                nfs.append(b.process_device(iq[k % 2].data_ptr(), N, n, audio[k % 2].data_ptr(), a_stride, st))
+                if k >= 1:
+                    verify(k - 1, 1)
+                pos += n
+            verify(len(calls) - 1, 0)
+            b.close()
+        results[key] = "ok"
+    except BaseException as e:  # noqa: BLE001 -- reported by the test's thread
+        results[key] = repr(e)
+        if barrier is not None:
+            barrier.abort()
+
+
+def test_two_batches_of_different_geometry_from_two_threads(oracle, fmsig):
+    """Two decoders of different geometry in one process, each driven by a thread of its own on a stream of its own,
+    their overlapped calls submitted at the same moment (a barrier in front of every call): the library keeps no
+    state between decoders (the reference's one process-wide static, `ps_text`, RDSGroupDecoder.cpp:311, is
+    per-decoder here) -- each batch's audio is the oracle's, bit for bit."""
+    import threading
+
+    import torch
+    pkg = load_package()
+    torch.cuda.synchronize()
+    results = {}
+    barrier = threading.Barrier(2, timeout=120)
+    calls = [N, 30001, N, 12346, N, N, 2500, N]
+    specs = [("2.4M", 2.4e6, 11, 1024, 5000), ("1.0M", 1.0e6, 4, 1100, 9000)]
+    threads = [threading.Thread(target=_drive, args=(pkg, torch, oracle, fmsig, fs, D, C, calls, seed,
+                                                     torch.cuda.Stream(priority=-1), results, key, barrier))
+               for key, fs, D, C, seed in specs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert results == {"2.4M": "ok", "1.0M": "ok"}, results
