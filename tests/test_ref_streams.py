@@ -1,6 +1,6 @@
 """What the REFERENCE BINARY returned (tests/golden/ref_streams.npz, written by
 `python tools/ref_crosscheck.py --emit ...` in the build container: the reference's own DSP sources,
-compiled there, driven over 72 generator streams / 2289 calls -- three of them stations that send every
+compiled there, driven over 74 generator streams / 2301 calls -- three of them stations that send every
 RDS group type in versions A and B, clean and weak; ten in regimes a clean station never reaches: tuned above the
 centre, over-deviated, noise only, silence, a pilot that comes and goes, off tune) against
 

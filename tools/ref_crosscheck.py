@@ -409,6 +409,10 @@ def streams(quick):
         ("2.4 MS/s, 40 kHz PCM", 2.4e6, 11, 0, {"seed": 38, "pcm": 40000.0}, full(24)),
         ("1.0 MS/s, 96 kHz PCM", 1.0e6, 4, 0, {"seed": 39, "pcm": 96000.0}, full(24)),
         ("2.4 MS/s, 48 kHz PCM, 10 kHz bandwidth, 75 us", 2.4e6, 11, 1, {"seed": 40, "bw": 10000.0}, full(24)),
+        # the longest calls the precondition allows where it binds (D = 1, 2: baseband block + 51 <= the reference's
+        # 32768-entry half-band buffers, include/fmd.h), next to shorter ones
+        ("400 kHz, D = 1: calls at the size limit (32717)", 400e3, 1, 0, {"seed": 41}, [32717, 32717, 20001, 32717, 32716, 32717]),
+        ("500 kHz, D = 2: calls at the size limit (65434)", 500e3, 2, 0, {"seed": 42}, [65434, 65433, 65434, 30000, 65434, 65434]),
     ]
     s += fuzz_streams(40)
     if quick:
