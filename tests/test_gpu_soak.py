@@ -38,6 +38,7 @@ OVERLAPPED = {
                                                         debug=(("lpf_late", 0),)),
     "caller's stream": dict(concurrency=2, lag=3, own_stream=True),
     "ordered after every call": dict(concurrency=1, lag=0),
+    "groups by device export": dict(concurrency=2, lag=3, export=True),
 }
 
 
@@ -55,11 +56,13 @@ def _a_stride(pkg, params):
 
 
 def _run(torch, make_batch, iq, iq_stride, w, *, concurrency, lag, calls, debug=(), stalls=False, own_stream=False,
-         channel0=0, keep_audio=0, u8=False, sizes=None, reset_at=()):
+         channel0=0, keep_audio=0, u8=False, sizes=None, reset_at=(), export=False):
     """One schedule over `calls` calls of the ring `iq`.  Returns (per-call checksums of channels
     [channel0, channel0 + w.shape[0]), their groups sorted, status tuples of four of them, the first `keep_audio`
     calls' audio of those four, frames per call).  sizes: IQ samples of call i (default: full blocks); reset_at: calls
-    in front of which the batch is reset (`cFmDecoder::Reset`, FmDecode.cpp:326-338: a drain, then every channel)."""
+    in front of which the batch is reset (`cFmDecoder::Reset`, FmDecode.cpp:326-338: a drain, then every channel);
+    export: the groups leave through fmd_batch_export_rds_device (records in device memory, what the gather sends)
+    instead of the host drain."""
     b = make_batch()
     C = b.n_channels
     b.set_concurrency(concurrency)
@@ -75,13 +78,25 @@ def _run(torch, make_batch, iq, iq_stride, w, *, concurrency, lag, calls, debug=
     torch.cuda.synchronize()
     CW = w.shape[0]
     sums, nf, groups, kept = [], [], [], []
+    rec = torch.zeros((4 * C, 4), dtype=torch.int32, device="cuda") if export else None
+    pkg_dtype = np.dtype([("channel", "<u4"), ("call_index", "<u4"), ("blocks", "<u2", (4,))])
     done_upto = 0
     picks = [0, 63, CW // 2, CW - 1]
 
     def finalize(i, lg):
         assert len(sums) == i
         b.wait(stream=st, lag=lg)
-        g = b.collect_rds_array(cap=4 * C, stream=st, lag=lg)
+        if export:
+            assert not b.export_rds_device(rec.data_ptr(), 4 * C, channel_offset=7, stream=st, lag=lg)
+            r = rec.cpu().numpy()  # (stream-ordered behind the export kernel)
+            r = r[r[:, 0] != 0]
+            g = np.zeros(len(r), dtype=pkg_dtype)
+            g["channel"] = r[:, 0] - 8
+            g["call_index"] = r[:, 1]
+            g["blocks"] = np.stack([r[:, 2] & 0xffff, (r[:, 2] >> 16) & 0xffff, r[:, 3] & 0xffff,
+                                    (r[:, 3] >> 16) & 0xffff], axis=1)
+        else:
+            g = b.collect_rds_array(cap=4 * C, stream=st, lag=lg)
         groups.append(g[(g["channel"] >= channel0) & (g["channel"] < channel0 + CW)])
         a = audio[i % nbuf][channel0:channel0 + CW].view(torch.int32).to(torch.int64)
         sums.append((a[:, :nf[i]] * w[:, :nf[i]]).sum())
