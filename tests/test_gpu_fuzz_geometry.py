@@ -40,7 +40,7 @@ def _case(i):
         C = r.choice([1, 3, 64, 65, 200, 1000, 1024, 1100, 2049, 4160, 4160, 8320])
     shared = (not cic) and r.random() < 0.25
     table = r.choice([64, 256, 256, 1, 2, 3, 1000]) if shared else r.choice([0, 0, 0, 1, 7, 100, 1000])
-    u8 = (not shared) and r.random() < 0.4
+    u8 = r.random() < 0.4  # (a shared capture of bytes: one station's, the float captures are three summed)
     mode = r.choice([0, 1, 2, 2, 2])
     lag = r.choice([0, 1]) if mode == 2 else 0
     pcm = r.choice([48000.0, 48000.0, 48000.0, 44100.0, 96000.0])
@@ -115,7 +115,11 @@ def test_random_geometry_bit_exact(oracle, fmsig, case):
                     assert np.float32(f_o).view(np.uint32) == np.float32(f_g).view(np.uint32), (k, c)
 
     for k, n in enumerate(case["calls"]):
-        if shared:
+        if shared and u8:
+            g3 = torch.zeros((3, n, 2), dtype=torch.uint8, device="cuda")
+            gen.generate(g3, pos, n)
+            iq[k % 2][:, :n] = g3[1]
+        elif shared:
             g3 = torch.zeros((3, n, 2), dtype=torch.float32, device="cuda")
             gen.generate(g3, pos, n)
             iq[k % 2][:, :n] = g3.sum(dim=0)  # (three stations summed into the one capture; every capture the same)
